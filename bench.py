@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SpMM GEdges/s + achieved-HBM fraction.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--op spmm_sum]
+
+N = 1 (default): BASELINE.json config 3 — random CSR, 2M x 2M, nnz = 20M,
+dense F = 128 fp32, one `spmm_sum` forward per step, inputs resident in HBM.
+N > 1 (launched by torch.distributed.run, one rank per GPU): the same per-GPU
+rows/edges on every rank (weak scaling, BASELINE config 4's structure): rank r
+owns rows [r*2M, (r+1)*2M) of A (20M edges, columns over all N*2M nodes) and
+the matching 2M-row block of B; a step = RCCL all-gather of B + local SpMM.
+
+Prints ONE JSON line on rank 0 (contract in the task brief): whole-job
+GEdges/s, the roofline object of the dominant kernel (algorithmic bytes /
+HIP-event kernel time vs 8 TB/s) and the CPU baseline (oracle C port timed on
+this box's host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
+
+M_PER_GPU = 2_000_000
+NNZ_PER_GPU = 20_000_000
+FEAT = 128
+
+
+def algorithmic_bytes(nnz: int, M: int, F: int, has_value: bool = True, arg_out: bool = False) -> int:
+    """no-reuse gather model with the API's int64 indices."""
+    per_edge = 8 + (4 if has_value else 0) + 4 * F
+    per_row = 8 + 4 * F + (8 * F if arg_out else 0)
+    return nnz * per_edge + M * per_row
+
+
+def make_workload(M: int, N: int, nnz: int, F: int, seed: int, device):
+    """SURVEY.md §8(d) generator: uniform random CSR, duplicates allowed."""
+    from paddle_sparse_amd import ops
+
+    g = torch.Generator(device=device).manual_seed(seed)
+    row = torch.sort(torch.randint(0, M, (nnz,), generator=g, device=device))[0]
+    col = torch.randint(0, N, (nnz,), generator=g, device=device)
+    val = torch.randn(nnz, generator=g, device=device)
+    rowptr = ops.ind2ptr(row, M)
+    del row
+    return rowptr, col, val
+
+
+def cpu_baseline(rowptr, col, val, B, budget_s: float = 12.0):
+    """Oracle C port (OpenMP over rows) timed on this box's host cores on a
+    bounded row-prefix of the same workload; also used to check the GPU."""
+    import oracle
+
+    threads = min(os.cpu_count() or 1, 64)
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    M = rowptr.numel() - 1
+    sample_rows = min(M, 1_000_000)
+    rp = rowptr[: sample_rows + 1].cpu().numpy()
+    e = int(rp[-1])
+    c = col[:e].cpu().numpy()
+    v = val[:e].cpu().numpy()
+    Bh = B.cpu().numpy()
+    oracle.spmm("sum", rp[:1001], c, v, Bh, threads=threads)  # warm the pool
+    best, reps, t_all = float("inf"), 0, time.perf_counter()
+    out = None
+    while reps < 5 and (time.perf_counter() - t_all) < budget_s:
+        t0 = time.perf_counter()
+        out, _ = oracle.spmm("sum", rp, c, v, Bh, threads=threads)
+        best = min(best, time.perf_counter() - t0)
+        reps += 1
+    info = {
+        "value": round(e / best / 1e9, 4),
+        "unit": "GEdges/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"first {sample_rows} rows ({e} edges) of the same CSR x the full B, "
+                  f"oracle_spmm_omp, best of {reps}",
+    }
+    return info, out, sample_rows
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--op", default="spmm_sum", choices=["spmm_sum", "spmm_mean", "spmm_max", "spmm_min"])
+    ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    from paddle_sparse_amd import ops
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: PLC0415
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    M, nnz, F = M_PER_GPU, NNZ_PER_GPU, FEAT
+    N = M * world
+    rowptr, col, val = make_workload(M, N, nnz, F, seed=2 + rank, device=device)
+    g = torch.Generator(device=device).manual_seed(100 + rank)
+    B_local = torch.randn(M, F, generator=g, device=device)
+    B_full = torch.empty(N, F, device=device) if world > 1 else B_local
+    fn = getattr(ops, args.op)
+    ops.spmm_set_variant(args.variant)
+
+    def step():
+        if world > 1:
+            dist.all_gather_into_tensor(B_full, B_local)
+        return fn(rowptr, col, val, B_full)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+
+    # kernel-only time: HIP events on the launch stream around each launch
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        if world > 1:
+            dist.all_gather_into_tensor(B_full, B_local)
+        a.record()
+        out = fn(rowptr, col, val, B_full)
+        b.record()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
+    if isinstance(out, tuple):
+        out = out[0]
+
+    t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, kern_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * nnz / (elapsed / args.steps) / 1e9
+        alg = algorithmic_bytes(nnz, M, F, True, args.op in ("spmm_max", "spmm_min"))
+        achieved = alg / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = ROOT / "profiles" / "traffic.json"
+        if tfile.exists():
+            traffic = json.loads(tfile.read_text()).get(f"{args.op}_c3", {}).get("hbm_bytes_per_launch")
+        line = {
+            "metric": f"{args.op}_gedges_per_s",
+            "value": round(value, 4),
+            "unit": "GEdges/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.op} fwd, uniform random CSR {M}x{N} per GPU, nnz={nnz} per GPU, "
+                            f"dense F={F} fp32 (BASELINE config 3 per GPU)"
+                            + (f"; + RCCL all-gather of B ({N}x{F}) every step" if world > 1 else ""),
+                "rows_per_gpu": M, "nnz_per_gpu": nnz, "feat": F, "index_dtype": "int64",
+                "variant": args.variant,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "spmm_row_kernel",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg,
+                "kernel_ms": round(kern_ms, 4),
+                "kernel_gedges_per_s": round(nnz / (kern_ms * 1e-3) / 1e9, 4),
+            },
+        }
+        if not args.no_cpu and args.op == "spmm_sum":
+            info, ref, rows = cpu_baseline(rowptr, col, val, B_full)
+            got = out[:rows].cpu().numpy()
+            scale = np.abs(ref).max()
+            line["cpu_baseline"] = info
+            line["check_max_abs_err_vs_oracle"] = float(np.abs(got - ref).max() / scale)
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

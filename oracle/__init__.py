@@ -1,0 +1,163 @@
+"""TEST INFRASTRUCTURE — CPU oracle for the hot path.
+
+Nothing under oracle/ is part of the product.  Only tests/,
+__graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import, load or
+execute it, and only as the checker / the timed CPU baseline.
+
+Contents
+  convert_oracle.c   ind2ptr / ptr2ind, restating csrc/cpu/convert_cpu.cpp
+  spmm_oracle.c      SpMM fwd/bwd (upstream pytorch_sparse algorithm; the
+                     reference tree has no SpMM)
+  storage_oracle.py  numpy restatement of storage.py / coalesce.py /
+                     transpose.py / reduce.py
+
+oracle/_ref (a build of the reference's own C++): NOT buildable in this
+image — csrc/*.cpp include <paddle/extension.h> (no Paddle headers on disk)
+and csrc/cpu/utils.h:4 includes parallel_hashmap/phmap.h from an empty,
+un-fetched submodule.  The oracle is therefore pinned by the reference's
+known-answer tests only (tests/golden/reference_kats.json).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+HERE = Path(__file__).resolve().parent
+BUILD_DIR = HERE / "_build"
+LIB_PATH = BUILD_DIR / "liboracle.so"
+SOURCES = [HERE / "convert_oracle.c", HERE / "spmm_oracle.c"]
+
+SUM, MEAN, MIN, MAX = 0, 1, 2, 3
+REDUCE_ID = {"sum": SUM, "add": SUM, "mean": MEAN, "min": MIN, "max": MAX}
+
+
+def build(force: bool = False) -> Path:
+    """gcc recipe for the C restatement (separate roundings, OpenMP for the
+    row-parallel baseline entry point)."""
+    BUILD_DIR.mkdir(exist_ok=True)
+    newest = max(s.stat().st_mtime for s in SOURCES)
+    if not force and LIB_PATH.exists() and LIB_PATH.stat().st_mtime >= newest:
+        return LIB_PATH
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        raise RuntimeError("gcc not found; cannot build the oracle")
+    cmd = [gcc, "-O2", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off",
+           "-Wall", "-o", str(LIB_PATH), *map(str, SOURCES)]
+    subprocess.run(cmd, check=True)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            build()
+        _lib = ctypes.CDLL(str(LIB_PATH))
+    return _lib
+
+
+def _p(a, ctype):
+    return None if a is None else a.ctypes.data_as(ctypes.POINTER(ctype))
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def ind2ptr(ind, M: int) -> np.ndarray:
+    ind = _i64(ind)
+    out = np.empty(M + 1, dtype=np.int64)
+    lib().oracle_ind2ptr(_p(ind, ctypes.c_int64), ctypes.c_int64(ind.size),
+                         ctypes.c_int64(M), _p(out, ctypes.c_int64))
+    return out
+
+
+def ptr2ind(ptr, E: int) -> np.ndarray:
+    ptr = _i64(ptr)
+    out = np.empty(E, dtype=np.int64)
+    lib().oracle_ptr2ind(_p(ptr, ctypes.c_int64), ctypes.c_int64(ptr.size - 1),
+                         ctypes.c_int64(E), _p(out, ctypes.c_int64))
+    return out
+
+
+def spmm(reduce: str, rowptr, col, value, mat, threads: int = 1):
+    """Returns (out, arg_out or None).  threads > 1 uses the OpenMP entry."""
+    rowptr, col = _i64(rowptr), _i64(col)
+    value, mat = _f32(value), _f32(mat)
+    M, K = rowptr.size - 1, mat.shape[1]
+    rid = REDUCE_ID[reduce]
+    out = np.empty((M, K), dtype=np.float32)
+    arg = np.empty((M, K), dtype=np.int64) if rid in (MIN, MAX) else None
+    fn = lib().oracle_spmm if threads <= 1 else lib().oracle_spmm_omp
+    if threads > 1:
+        os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    fn(ctypes.c_int(rid), _p(rowptr, ctypes.c_int64), _p(col, ctypes.c_int64),
+       _p(value, ctypes.c_float), _p(mat, ctypes.c_float), ctypes.c_int64(M),
+       ctypes.c_int64(K), ctypes.c_int64(col.size), _p(out, ctypes.c_float),
+       _p(arg, ctypes.c_int64))
+    return out, arg
+
+
+def spmm_abs_sum(rowptr, col, value, mat) -> np.ndarray:
+    rowptr, col = _i64(rowptr), _i64(col)
+    value, mat = _f32(value), _f32(mat)
+    M, K = rowptr.size - 1, mat.shape[1]
+    out = np.empty((M, K), dtype=np.float64)
+    lib().oracle_spmm_abs_sum(_p(rowptr, ctypes.c_int64), _p(col, ctypes.c_int64),
+                              _p(value, ctypes.c_float), _p(mat, ctypes.c_float),
+                              ctypes.c_int64(M), ctypes.c_int64(K),
+                              _p(out, ctypes.c_double))
+    return out
+
+
+def spmm_value_bw(reduce: str, row, rowptr, col, mat, grad) -> np.ndarray:
+    row, rowptr, col = _i64(row), _i64(rowptr), _i64(col)
+    mat, grad = _f32(mat), _f32(grad)
+    out = np.empty(col.size, dtype=np.float32)
+    lib().oracle_spmm_value_bw(ctypes.c_int(REDUCE_ID[reduce]), _p(row, ctypes.c_int64),
+                               _p(rowptr, ctypes.c_int64), _p(col, ctypes.c_int64),
+                               _p(mat, ctypes.c_float), _p(grad, ctypes.c_float),
+                               ctypes.c_int64(col.size), ctypes.c_int64(mat.shape[1]),
+                               _p(out, ctypes.c_float))
+    return out
+
+
+def spmm_mat_bw(reduce: str, row, rowptr, col, value, grad, N: int) -> np.ndarray:
+    row, rowptr, col = _i64(row), _i64(rowptr), _i64(col)
+    value, grad = _f32(value), _f32(grad)
+    K = grad.shape[1]
+    out = np.empty((N, K), dtype=np.float32)
+    lib().oracle_spmm_mat_bw(ctypes.c_int(REDUCE_ID[reduce]), _p(row, ctypes.c_int64),
+                             _p(rowptr, ctypes.c_int64), _p(col, ctypes.c_int64),
+                             _p(value, ctypes.c_float), _p(grad, ctypes.c_float),
+                             ctypes.c_int64(col.size), ctypes.c_int64(N),
+                             ctypes.c_int64(K), _p(out, ctypes.c_float))
+    return out
+
+
+def spmm_minmax_bw(col, value, mat, grad, arg_out, want_value=True, want_mat=True):
+    col, arg_out = _i64(col), _i64(arg_out)
+    value, mat, grad = _f32(value), _f32(mat), _f32(grad)
+    M, K = grad.shape
+    N = mat.shape[0]
+    gv = np.empty(col.size, dtype=np.float32) if want_value else None
+    gm = np.empty((N, K), dtype=np.float32) if want_mat else None
+    lib().oracle_spmm_minmax_bw(_p(col, ctypes.c_int64), _p(value, ctypes.c_float),
+                                _p(mat, ctypes.c_float), _p(grad, ctypes.c_float),
+                                _p(arg_out, ctypes.c_int64), ctypes.c_int64(M),
+                                ctypes.c_int64(N), ctypes.c_int64(K),
+                                ctypes.c_int64(col.size), _p(gv, ctypes.c_float),
+                                _p(gm, ctypes.c_float))
+    return gv, gm

@@ -1,0 +1,228 @@
+"""TEST INFRASTRUCTURE — CPU oracle, never part of the shipped path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+import this module.
+
+numpy restatement of the reference's Python hot path (the reference runs it
+on Paddle ops + paddle_scatter, neither importable here):
+
+  ctor sort ............ /root/reference/paddle_sparse/storage.py:158-171
+  index_sort ........... /root/reference/paddle_sparse/utils.py:14-23
+  rowcount/colptr/colcount ... storage.py:373-420
+  csr2csc / csc2csr .... storage.py:425-447
+  is_coalesced/coalesce  storage.py:449-486
+  coalesce() ........... /root/reference/paddle_sparse/coalesce.py:25-29
+  t() / transpose() .... /root/reference/paddle_sparse/transpose.py:9-33,41-65
+  reduction() .......... /root/reference/paddle_sparse/reduce.py:12-71
+
+Third-party arithmetic that is not under /root/reference:
+  paddle_scatter.segment_csr / scatter / scatter_add (unpinned HEAD,
+  README.md:21-24).  Restated with pytorch_scatter's published semantics:
+  empty segment -> 0, mean = sum / max(count, 1) (floor division for integer
+  dtypes), min/max return values only.
+  paddle.argsort (utils.py:22, stable=False by default): for duplicate keys
+  the permutation is not unique; this oracle (and the HIP radix sort) use the
+  STABLE permutation, which is one of the valid answers and the only
+  reproducible one.
+
+Pinned by the reference's known answers (tests/golden/reference_kats.json,
+from test/test_storage.py, test/test_coalesce.py, test/test_transpose.py,
+README.md:204-264).  reduce(dim=0/1), mean/min coalesce: "parity unpinned"
+(test/test_reduce.py only covers dim=None).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+REDUCTIONS = ("sum", "add", "mean", "min", "max")
+
+
+def index_sort(keys: np.ndarray) -> np.ndarray:
+    """utils.py:22 `inputs.argsort()` under the stable convention."""
+    return np.argsort(np.asarray(keys, dtype=np.int64), kind="stable").astype(np.int64)
+
+
+def _is_int(a: np.ndarray) -> bool:
+    return np.issubdtype(a.dtype, np.integer)
+
+
+def segment_csr(src: np.ndarray, indptr: np.ndarray, reduce: str = "sum") -> np.ndarray:
+    """pytorch_scatter.segment_csr along dim 0 (call sites storage.py:471,
+    reduce.py:51).  Accumulates in segment order in src's dtype."""
+    assert reduce in REDUCTIONS
+    src = np.asarray(src)
+    indptr = np.asarray(indptr, dtype=np.int64)
+    nseg = indptr.size - 1
+    out = np.zeros((nseg,) + src.shape[1:], dtype=src.dtype)
+    for i in range(nseg):
+        lo, hi = int(indptr[i]), int(indptr[i + 1])
+        if hi <= lo:
+            continue
+        seg = src[lo:hi]
+        if reduce in ("sum", "add", "mean"):
+            acc = seg[0].copy()
+            for j in range(1, hi - lo):
+                acc = acc + seg[j]
+            if reduce == "mean":
+                acc = acc // (hi - lo) if _is_int(src) else (acc / src.dtype.type(hi - lo)).astype(src.dtype)
+            out[i] = acc
+        elif reduce == "min":
+            out[i] = seg.min(axis=0)
+        else:
+            out[i] = seg.max(axis=0)
+    return out
+
+
+def segment_csr_fast(src: np.ndarray, indptr: np.ndarray, reduce: str = "sum") -> np.ndarray:
+    """Vectorised segment_csr for large inputs (same results for integer
+    dtypes; floating sums may differ from the sequential order in the last
+    bits, so compare with a tolerance)."""
+    src = np.asarray(src)
+    indptr = np.asarray(indptr, dtype=np.int64)
+    nseg = indptr.size - 1
+    out = np.zeros((nseg,) + src.shape[1:], dtype=src.dtype)
+    cnt = indptr[1:] - indptr[:-1]
+    nz = cnt > 0
+    if not nz.any() or src.shape[0] == 0:
+        return out
+    starts = indptr[:-1][nz]
+    ufunc = {"sum": np.add, "add": np.add, "mean": np.add, "min": np.minimum, "max": np.maximum}[reduce]
+    # reduceat reduces [starts[i], starts[i+1]); empty segments were dropped,
+    # so consecutive non-empty starts delimit exactly one segment each except
+    # the last, which must stop at its own end.
+    last_end = int(indptr[1:][nz][-1])
+    red = ufunc.reduceat(src[:last_end], starts, axis=0)
+    if reduce == "mean":
+        c = cnt[nz].reshape((-1,) + (1,) * (src.ndim - 1))
+        red = red // c if _is_int(src) else (red / c.astype(src.dtype)).astype(src.dtype)
+    out[nz] = red
+    return out
+
+
+def scatter(src: np.ndarray, index: np.ndarray, dim_size: int, reduce: str = "sum") -> np.ndarray:
+    """pytorch_scatter.scatter(src, index, dim=0, dim_size=..., reduce) as used
+    by reduce.py:42 and storage.py:414 (scatter_add)."""
+    assert reduce in REDUCTIONS
+    src = np.asarray(src)
+    index = np.asarray(index, dtype=np.int64)
+    out = np.zeros((dim_size,) + src.shape[1:], dtype=src.dtype)
+    if reduce in ("sum", "add", "mean"):
+        np.add.at(out, index, src)
+        if reduce == "mean":
+            cnt = np.bincount(index, minlength=dim_size).astype(np.int64)
+            cnt = np.maximum(cnt, 1).reshape((-1,) + (1,) * (src.ndim - 1))
+            out = out // cnt if _is_int(src) else (out / cnt.astype(src.dtype)).astype(src.dtype)
+        return out
+    touched = np.zeros(dim_size, dtype=bool)
+    touched[index] = True
+    if reduce == "min":
+        init = np.iinfo(src.dtype).max if _is_int(src) else np.inf
+        out[...] = init
+        np.minimum.at(out, index, src)
+    else:
+        init = np.iinfo(src.dtype).min if _is_int(src) else -np.inf
+        out[...] = init
+        np.maximum.at(out, index, src)
+    out[~touched] = 0
+    return out
+
+
+class Storage:
+    """Plain-numpy mirror of SparseStorage's canonical state + lazy caches."""
+
+    def __init__(self, row, col, value=None, sparse_sizes=None, is_sorted=False):
+        row = np.asarray(row, dtype=np.int64)
+        col = np.asarray(col, dtype=np.int64)
+        # storage.py:65-91 size inference
+        M = sparse_sizes[0] if sparse_sizes and sparse_sizes[0] is not None else (int(row.max()) + 1 if row.size else 0)
+        N = sparse_sizes[1] if sparse_sizes and sparse_sizes[1] is not None else (int(col.max()) + 1 if col.size else 0)
+        self.M, self.N = int(M), int(N)
+        self.row, self.col = row, col
+        self.value = None if value is None else np.asarray(value)
+        # storage.py:158-171
+        if not is_sorted and col.size > 0:
+            key = row * self.N + col
+            if (key[1:] < key[:-1]).any():
+                perm = index_sort(key)
+                self.row, self.col = row[perm], col[perm]
+                if self.value is not None:
+                    self.value = self.value[perm]
+
+    # storage.py:211-222 via csrc/cpu/convert_cpu.cpp:6-30
+    def rowptr(self):
+        return np.searchsorted(self.row, np.arange(self.M + 1), side="left").astype(np.int64)
+
+    def rowcount(self):  # storage.py:373-381
+        p = self.rowptr()
+        return p[1:] - p[:-1]
+
+    def colcount(self):  # storage.py:405-420
+        return np.bincount(self.col, minlength=self.N).astype(np.int64)
+
+    def colptr(self):  # storage.py:386-400
+        out = np.zeros(self.N + 1, dtype=np.int64)
+        out[1:] = np.cumsum(self.colcount())
+        return out
+
+    def csr2csc(self):  # storage.py:425-434
+        return index_sort(self.M * self.col + self.row)
+
+    def csc2csr(self):  # storage.py:439-447
+        return index_sort(self.csr2csc())
+
+    def is_coalesced(self):  # storage.py:449-452
+        key = np.concatenate([[-1], self.N * self.row + self.col])
+        return bool((key[1:] > key[:-1]).all())
+
+    def coalesce(self, reduce="add"):  # storage.py:454-486
+        key = np.concatenate([[-1], self.N * self.row + self.col])
+        mask = key[1:] > key[:-1]
+        if mask.all():
+            return self
+        value = self.value
+        if value is not None:
+            ptr = np.concatenate([np.nonzero(mask)[0], [value.shape[0]]]).astype(np.int64)
+            value = segment_csr_fast(value, ptr, reduce) if value.shape[0] > 4096 else segment_csr(value, ptr, reduce)
+        return Storage(self.row[mask], self.col[mask], value, (self.M, self.N), is_sorted=True)
+
+
+def coalesce(index, value, m, n, op="add"):
+    """coalesce.py:25-29."""
+    index = np.asarray(index, dtype=np.int64)
+    st = Storage(index[0], index[1], value, (m, n), is_sorted=False).coalesce(op)
+    return np.stack([st.row, st.col]), st.value
+
+
+def transpose(index, value, m, n, coalesced=True):
+    """transpose.py:41-65."""
+    index = np.asarray(index, dtype=np.int64)
+    row, col = index[1], index[0]
+    if coalesced:
+        st = Storage(row, col, value, (n, m), is_sorted=False).coalesce()
+        row, col, value = st.row, st.col, st.value
+    return np.stack([row, col]), value
+
+
+def t(st: Storage) -> Storage:
+    """transpose.py:9-33 (method form): permute by csr2csc, swap roles."""
+    perm = st.csr2csc()
+    value = None if st.value is None else st.value[perm]
+    return Storage(st.col[perm], st.row[perm], value, (st.N, st.M), is_sorted=True)
+
+
+def reduction(st: Storage, dim, reduce="sum", dtype=np.float32):
+    """reduce.py:12-71 for dim in {None, 0, 1}."""
+    value = st.value
+    if dim is None:
+        if value is not None:
+            return {"sum": value.sum, "add": value.sum, "mean": value.mean, "min": value.min, "max": value.max}[reduce]()
+        return dtype(st.col.size) if reduce in ("sum", "add") else dtype(1)
+    if dim == 0:
+        if value is not None:
+            return scatter(value, st.col, st.N, reduce)
+        return st.colcount().astype(dtype) if reduce in ("sum", "add") else np.ones(st.N, dtype)
+    if dim == 1:
+        if value is not None:
+            return segment_csr_fast(value, st.rowptr(), reduce)
+        return st.rowcount().astype(dtype) if reduce in ("sum", "add") else np.ones(st.M, dtype)
+    raise ValueError(dim)

@@ -1,0 +1,61 @@
+"""ctypes binding of the C-ABI HIP core (include/paddle_sparse_hip.h).
+
+The library is the product: if it is missing or does not load, importing the
+ops fails loudly — there is no CPU or eager fallback anywhere in this package.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_int, c_int64, c_size_t, c_void_p, c_char_p
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "libpaddle_sparse_hip.so"
+
+SUM, MEAN, MIN, MAX = 0, 1, 2, 3
+REDUCE_ID = {"sum": SUM, "add": SUM, "mean": MEAN, "min": MIN, "max": MAX}
+
+# name -> (restype, argtypes); mirrors include/paddle_sparse_hip.h one to one
+# (tests/test_abi.py parses the header and checks this table against it).
+SIGNATURES = {
+    "psa_last_error": (c_char_p, []),
+    "psa_abi_version": (c_int, []),
+    "psa_sparse_cuda_version": (c_int64, []),
+    "psa_ind2ptr": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "psa_ptr2ind": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "psa_spmm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                         c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "psa_spmm_set_variant": (c_int, [c_int]),
+}
+
+_lib = None
+
+
+class HipCoreError(RuntimeError):
+    """A C-ABI call returned a non-zero psa_status."""
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP core is not built. Run "
+            "`python -m paddle_sparse_amd.build` (needs hipcc, gfx950). "
+            "paddle_sparse_amd has no CPU fallback."
+        )
+    lib = ctypes.CDLL(str(LIB_PATH))
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = symbol missing: fail loudly
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.psa_abi_version() != 1:
+        raise ImportError("libpaddle_sparse_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(status: int) -> None:
+    if status != 0:
+        msg = load().psa_last_error().decode()
+        raise HipCoreError(f"psa_status {status}: {msg}")

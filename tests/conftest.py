@@ -1,0 +1,36 @@
+"""pytest configuration: the `gpu` marker and shared fixtures.
+
+`-m "not gpu"` runs on a CPU-only box: oracle vs golden vectors, host logic,
+C-ABI symbol checks.  `-m gpu` tests are the parity tests proper and call the
+HIP kernels through the C-ABI on a real MI355X.
+"""
+import json
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (HIP kernels run)")
+
+
+@pytest.fixture(scope="session")
+def kats():
+    with open(ROOT / "tests" / "golden" / "reference_kats.json") as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """Make sure the oracle (gcc) and the HIP core (hipcc) are built."""
+    import oracle
+    from paddle_sparse_amd import build as hip_build
+
+    oracle.build()
+    hip_build.build()
+    yield

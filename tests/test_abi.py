@@ -1,0 +1,69 @@
+"""CPU suite: the C-ABI library loads and exports every symbol that
+include/paddle_sparse_hip.h declares (no compute calls: no GPU needed)."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+HEADER = ROOT / "include" / "paddle_sparse_hip.h"
+
+
+def declared_functions():
+    text = HEADER.read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(psa_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_something():
+    names = declared_functions()
+    assert "psa_spmm" in names and "psa_ind2ptr" in names and len(names) >= 7
+
+
+def test_library_exports_every_declared_symbol():
+    from paddle_sparse_amd import _lib
+
+    lib = ctypes.CDLL(str(_lib.LIB_PATH))
+    for name in declared_functions():
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+
+
+def test_binding_table_matches_header():
+    from paddle_sparse_amd import _lib
+
+    assert sorted(_lib.SIGNATURES) == declared_functions()
+    _lib.load()  # sets restype/argtypes for every symbol
+
+
+def test_version_probes_without_gpu():
+    from paddle_sparse_amd import _lib, ops
+
+    lib = _lib.load()
+    assert lib.psa_abi_version() == 1
+    # csrc/version.cpp:14-22 / __init__.py:18-32: HIP build must report -1
+    assert lib.psa_sparse_cuda_version() == -1
+    v = ops.sparse_cuda_version()
+    assert v.tolist() == [-1] and not v.is_cuda
+
+
+def test_ops_reject_cpu_tensors():
+    import torch
+    from paddle_sparse_amd import ops
+
+    ind = torch.tensor([0, 1, 1], dtype=torch.int64)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        ops.ind2ptr(ind, 3)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        ops.ptr2ind(ind, 3)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        ops.spmm_sum(ind, ind, None, torch.zeros(2, 2))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from paddle_sparse_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "nope.so")
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()

@@ -1,0 +1,76 @@
+"""GPU parity: ind2ptr / ptr2ind through the C-ABI vs the oracle, bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from util import random_csr, skewed_csr
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_kats(kats):
+    from paddle_sparse_amd import ops
+
+    for c in kats["ind2ptr"]["cases"]:
+        got = ops.ind2ptr(dev(np.array(c["row"], np.int64)), c["M"])
+        assert got.cpu().tolist() == c["rowptr"]
+    for c in kats["ptr2ind"]["cases"]:
+        got = ops.ptr2ind(dev(np.array(c["rowptr"], np.int64)), c["E"])
+        assert got.cpu().tolist() == c["row"]
+
+
+@pytest.mark.parametrize("M,nnz,seed", [
+    (1, 1, 0), (1, 700, 1), (7, 0, 2), (64, 64, 3), (65, 1, 4), (1000, 10000, 5),
+    (100000, 300, 6),      # long runs of empty rows -> wave-cooperative path
+    (257, 100000, 7),      # many duplicates per row
+    (300000, 3000000, 8),
+])
+def test_random(M, nnz, seed):
+    from paddle_sparse_amd import ops
+
+    row, rowptr, _, _ = random_csr(M, 4, nnz, seed)
+    got = ops.ind2ptr(dev(row), M).cpu().numpy()
+    assert np.array_equal(got, oracle.ind2ptr(row, M))
+    back = ops.ptr2ind(dev(rowptr), nnz).cpu().numpy()
+    assert np.array_equal(back, oracle.ptr2ind(rowptr, nnz))
+    assert np.array_equal(back, row)
+
+
+def test_first_and_last_rows_only():
+    from paddle_sparse_amd import ops
+
+    M = 50000
+    row = np.array([0, 0, M - 1, M - 1, M - 1], np.int64)
+    got = ops.ind2ptr(dev(row), M).cpu().numpy()
+    assert np.array_equal(got, oracle.ind2ptr(row, M))
+    row = np.array([M // 2], np.int64)
+    got = ops.ind2ptr(dev(row), M).cpu().numpy()
+    assert np.array_equal(got, oracle.ind2ptr(row, M))
+
+
+def test_skewed_rows():
+    from paddle_sparse_amd import ops
+
+    row, rowptr, _, _ = skewed_csr(5000, 10, seed=3, long_rows=(0, 63, 64, 4999), long_deg=5000)
+    nnz = row.size
+    assert np.array_equal(ops.ind2ptr(dev(row), 5000).cpu().numpy(), rowptr)
+    assert np.array_equal(ops.ptr2ind(dev(rowptr), nnz).cpu().numpy(), row)
+
+
+def test_roundtrip_full_size():
+    """C3-sized round trip (size-independent property: ptr2ind(ind2ptr(r)) == r)."""
+    from paddle_sparse_amd import ops
+
+    M, nnz = 2_000_000, 20_000_000
+    g = torch.Generator(device="cuda").manual_seed(0)
+    row = torch.sort(torch.randint(0, M, (nnz,), generator=g, device="cuda"))[0]
+    rowptr = ops.ind2ptr(row, M)
+    assert int(rowptr[0]) == 0 and int(rowptr[-1]) == nnz
+    assert bool((rowptr[1:] >= rowptr[:-1]).all())
+    assert torch.equal(rowptr, torch.searchsorted(row, torch.arange(M + 1, device="cuda")))
+    assert torch.equal(ops.ptr2ind(rowptr, nnz), row)

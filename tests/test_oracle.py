@@ -1,0 +1,224 @@
+"""CPU suite: pin the oracle (oracle/) against the reference's known answers
+and against independent third-party implementations available in this image
+(numpy, scipy, torch-CPU torch.sparse.mm).  No GPU, no HIP compute."""
+import numpy as np
+import pytest
+import scipy.sparse
+import torch
+
+import oracle
+from oracle import storage_oracle as so
+from util import random_csr, skewed_csr
+
+
+# ---- ind2ptr / ptr2ind: reference KATs test/test_storage.py:20-32 ---------
+def test_ind2ptr_kats(kats):
+    for c in kats["ind2ptr"]["cases"]:
+        assert oracle.ind2ptr(c["row"], c["M"]).tolist() == c["rowptr"]
+
+
+def test_ptr2ind_kats(kats):
+    for c in kats["ptr2ind"]["cases"]:
+        assert oracle.ptr2ind(c["rowptr"], c["E"]).tolist() == c["row"]
+
+
+@pytest.mark.parametrize("M,nnz,seed", [(1, 1, 0), (7, 0, 1), (100, 1000, 2), (5000, 300, 3), (1, 500, 4)])
+def test_ind2ptr_vs_searchsorted(M, nnz, seed):
+    row, rowptr, _, _ = random_csr(M, 10, nnz, seed)
+    got = oracle.ind2ptr(row, M)
+    assert np.array_equal(got, rowptr)
+    assert np.array_equal(oracle.ptr2ind(got, nnz), row)
+
+
+# ---- storage / coalesce / transpose KATs ----------------------------------
+def test_storage_sort_kat(kats):
+    k = kats["storage_sort"]
+    st = so.Storage(k["row"], k["col"], np.array(k["value"], np.float32))
+    assert st.row.tolist() == k["out_row"] and st.col.tolist() == k["out_col"]
+    assert st.value.tolist() == k["out_value"]
+    assert [st.M, st.N] == k["sparse_sizes"]
+
+
+def test_storage_caching_kat(kats):
+    k = kats["storage_caching"]
+    st = so.Storage(k["row"], k["col"])
+    assert st.rowcount().tolist() == k["rowcount"]
+    assert st.rowptr().tolist() == k["rowptr"]
+    assert st.colcount().tolist() == k["colcount"]
+    assert st.colptr().tolist() == k["colptr"]
+    assert st.csr2csc().tolist() == k["csr2csc"]
+    assert st.csc2csr().tolist() == k["csc2csr"]
+    assert np.array_equal(st.rowptr(), oracle.ind2ptr(st.row, st.M))
+
+
+def test_storage_set_value_csc_kat(kats):
+    k = kats["storage_set_value_csc"]
+    st = so.Storage(k["row"], k["col"], np.array(k["value"], np.float32))
+    # storage.py:246-247: value given in CSC order -> value[csc2csr]
+    assert np.array(k["value"])[st.csc2csr()].tolist() == k["csc_value"]
+
+
+def test_storage_coalesce_kat(kats):
+    k = kats["storage_coalesce"]
+    st = so.Storage(k["row"], k["col"], np.array(k["value"], np.float32))
+    assert not st.is_coalesced()
+    st = st.coalesce()
+    assert st.is_coalesced()
+    assert st.row.tolist() == k["out_row"] and st.col.tolist() == k["out_col"]
+    assert st.value.tolist() == k["out_value"]
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64, np.int32, np.int64])
+def test_coalesce_kats(kats, dtype):
+    k = kats["coalesce"]
+    index = np.array([k["row"], k["col"]])
+    idx, val = so.coalesce(index, None, k["m"], k["n"])
+    assert idx.tolist() == k["out_index"] and val is None
+    idx, val = so.coalesce(index, np.array(k["value"], dtype), k["m"], k["n"])
+    assert idx.tolist() == k["out_index"] and val.tolist() == k["out_add"]
+    idx, val = so.coalesce(index, np.array(k["value"], dtype), k["m"], k["n"], op="max")
+    assert idx.tolist() == k["out_index"] and val.tolist() == k["out_max"]
+
+
+def test_transpose_kats(kats):
+    for name in ("transpose_matrix", "transpose"):
+        k = kats[name]
+        idx, val = so.transpose(np.array([k["row"], k["col"]]), np.array(k["value"], np.float32), k["m"], k["n"])
+        assert idx.tolist() == k["out_index"]
+        assert val.tolist() == k["out_value"]
+
+
+def test_reduce_dim_none_kat(kats):
+    k = kats["reduce_dim_none"]
+    st = so.Storage(k["row"], k["col"], np.array(k["value"], np.float32))
+    for r in ("sum", "mean", "max", "min"):
+        assert so.reduction(st, None, r) == k[r]
+
+
+def test_segment_csr_fast_matches_loop():
+    rng = np.random.default_rng(0)
+    src = rng.integers(-50, 50, (300, 3)).astype(np.int64)
+    cuts = np.sort(rng.integers(0, 301, 40))
+    indptr = np.concatenate([[0], cuts, [300]]).astype(np.int64)
+    for r in ("sum", "mean", "min", "max"):
+        assert np.array_equal(so.segment_csr(src, indptr, r), so.segment_csr_fast(src, indptr, r))
+
+
+def test_coalesce_random_vs_scipy():
+    """C1-shaped: 10k-edge unsorted COO with duplicates; scipy sums duplicates."""
+    rng = np.random.default_rng(0)
+    M = N = 1000
+    row, col = rng.integers(0, M, 10000), rng.integers(0, N, 10000)
+    val = rng.integers(-8, 8, 10000).astype(np.float32)  # exact in fp32
+    idx, out = so.coalesce(np.stack([row, col]), val, M, N)
+    ref = scipy.sparse.coo_matrix((val, (row, col)), (M, N)).tocsr()
+    ref.sum_duplicates()
+    ref.sort_indices()
+    refc = ref.tocoo()
+    # scipy drops nothing here (explicit zeros are kept by sum_duplicates)
+    assert np.array_equal(idx[0], refc.row) and np.array_equal(idx[1], refc.col)
+    assert np.array_equal(out, refc.data)
+
+
+# ---- SpMM: README KAT + third-party cross-checks ---------------------------
+def test_spmm_readme_kat(kats):
+    k = kats["spmm"]
+    row, col = np.array(k["index"])
+    rowptr = oracle.ind2ptr(row, k["m"])
+    out, _ = oracle.spmm("sum", rowptr, col, np.array(k["value"], np.float32), np.array(k["matrix"], np.float32))
+    assert out.tolist() == k["out"]
+
+
+def test_spmm_survey_vectors():
+    """torch-CPU outputs on the README matrix + one empty row."""
+    rowptr = np.array([0, 2, 3, 5, 5])
+    col = np.array([0, 2, 1, 0, 1])
+    val = np.array([1, 2, 4, 1, 3], np.float32)
+    B = np.array([[1, 4], [2, 5], [3, 6]], np.float32)
+    assert oracle.spmm("sum", rowptr, col, val, B)[0].tolist() == [[7, 16], [8, 20], [7, 19], [0, 0]]
+    assert oracle.spmm("mean", rowptr, col, val, B)[0].tolist() == [[3.5, 8], [8, 20], [3.5, 9.5], [0, 0]]
+    out, arg = oracle.spmm("max", rowptr, col, val, B)
+    assert out.tolist() == [[6, 12], [8, 20], [6, 15], [0, 0]]
+    assert arg.tolist() == [[1, 1], [2, 2], [4, 4], [5, 5]]
+    out, arg = oracle.spmm("min", rowptr, col, val, B)
+    assert out.tolist() == [[1, 4], [8, 20], [1, 4], [0, 0]]
+    assert arg.tolist() == [[0, 0], [2, 2], [3, 3], [5, 5]]
+    row = oracle.ptr2ind(rowptr, 5)
+    g = np.ones((4, 2), np.float32)
+    assert oracle.spmm_mat_bw("sum", row, rowptr, col, val, g, 3).tolist() == [[2, 2], [7, 7], [2, 2]]
+    assert oracle.spmm_value_bw("sum", row, rowptr, col, B, g).tolist() == [5, 9, 7, 5, 7]
+
+
+def _torch_csr(rowptr, col, val, M, N, requires_grad=False):
+    v = torch.tensor(val, dtype=torch.float64, requires_grad=requires_grad)
+    return torch.sparse_csr_tensor(torch.tensor(rowptr), torch.tensor(col), v, size=(M, N)), v
+
+
+@pytest.mark.parametrize("reduce,treduce", [("sum", "sum"), ("mean", "mean"), ("max", "amax"), ("min", "amin")])
+@pytest.mark.parametrize("K", [1, 7, 32])
+def test_spmm_vs_torch_cpu(reduce, treduce, K):
+    M, N, nnz = 200, 150, 1500
+    row, rowptr, col, val = random_csr(M, N, nnz, seed=K, sort_cols=True)
+    # torch's CSR reducers need coalesced columns per row: dedup (row, col)
+    key = row * N + col
+    keep = np.concatenate([[True], key[1:] != key[:-1]])
+    row, col, val = row[keep], col[keep], val[keep]
+    rowptr = oracle.ind2ptr(row, M)
+    B = np.random.default_rng(1).standard_normal((N, K)).astype(np.float32)
+    out, _ = oracle.spmm(reduce, rowptr, col, val, B)
+    A, _ = _torch_csr(rowptr, col, val, M, N)
+    ref = torch.sparse.mm(A, torch.tensor(B, dtype=torch.float64), treduce).numpy()
+    S = oracle.spmm_abs_sum(rowptr, col, val, B)
+    assert np.all(np.abs(out - ref) <= 1e-5 * S + 1e-30)
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean"])
+def test_spmm_backward_vs_torch_cpu(reduce):
+    M, N, nnz, K = 120, 90, 800, 5
+    row, rowptr, col, val = random_csr(M, N, nnz, seed=11, sort_cols=True)
+    key = row * N + col
+    keep = np.concatenate([[True], key[1:] != key[:-1]])
+    row, col, val = row[keep], col[keep], val[keep]
+    rowptr = oracle.ind2ptr(row, M)
+    rng = np.random.default_rng(2)
+    B = rng.standard_normal((N, K)).astype(np.float32)
+    G = rng.standard_normal((M, K)).astype(np.float32)
+    A, v = _torch_csr(rowptr, col, val, M, N, requires_grad=True)
+    Bt = torch.tensor(B, dtype=torch.float64, requires_grad=True)
+    torch.sparse.mm(A, Bt, reduce).backward(torch.tensor(G, dtype=torch.float64))
+    gB = oracle.spmm_mat_bw(reduce, row, rowptr, col, val, G, N)
+    gV = oracle.spmm_value_bw(reduce, row, rowptr, col, B, G)
+    np.testing.assert_allclose(gB, Bt.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(gV, v.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_spmm_vs_scipy_with_duplicates_and_skew():
+    row, rowptr, col, val = skewed_csr(300, 200, seed=5, long_rows=(0, 17), long_deg=400)
+    B = np.random.default_rng(3).standard_normal((200, 16)).astype(np.float32)
+    out, _ = oracle.spmm("sum", rowptr, col, val, B)
+    ref = scipy.sparse.csr_matrix((val.astype(np.float64), col, rowptr), (300, 200)) @ B.astype(np.float64)
+    S = oracle.spmm_abs_sum(rowptr, col, val, B)
+    assert np.all(np.abs(out - ref) <= 1e-5 * S + 1e-30)
+    # OpenMP entry point = same arithmetic per row
+    out2, _ = oracle.spmm("sum", rowptr, col, val, B, threads=4)
+    assert np.array_equal(out, out2)
+
+
+def test_spmm_minmax_backward_matches_definition():
+    row, rowptr, col, val = random_csr(50, 40, 300, seed=9)
+    rng = np.random.default_rng(4)
+    B = rng.standard_normal((40, 6)).astype(np.float32)
+    G = rng.standard_normal((50, 6)).astype(np.float32)
+    out, arg = oracle.spmm("max", rowptr, col, val, B)
+    gv, gm = oracle.spmm_minmax_bw(col, val, B, G, arg)
+    gv_ref = np.zeros(300, np.float64)
+    gm_ref = np.zeros((40, 6), np.float64)
+    for i in range(50):
+        for k in range(6):
+            e = arg[i, k]
+            if e == 300:
+                continue
+            gv_ref[e] += float(B[col[e], k]) * float(G[i, k])
+            gm_ref[col[e], k] += float(val[e]) * float(G[i, k])
+    np.testing.assert_allclose(gv, gv_ref, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(gm, gm_ref, rtol=1e-5, atol=1e-5)

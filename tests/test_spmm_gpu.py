@@ -1,0 +1,159 @@
+"""GPU parity: psa_spmm (sum/mean/min/max) through the C-ABI vs the oracle.
+
+Tolerance (north-star: 1e-5 relative for fp32 reductions): per element
+|gpu - oracle| <= 1e-5 * S, S = sum_e |w_e * mat[col[e],k]| (the quantity the
+rounding error of either summation order is relative to).  arg_out of
+min/max is an index and must match bit-exactly whenever the winner is unique.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from util import random_csr, skewed_csr
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5
+
+
+def dev(a):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def run_gpu(reduce, rowptr, col, val, B):
+    from paddle_sparse_amd import ops
+
+    fn = getattr(ops, f"spmm_{reduce}")
+    res = fn(dev(rowptr), dev(col), dev(val), dev(B))
+    torch.cuda.synchronize()
+    if isinstance(res, tuple):
+        return res[0].cpu().numpy(), res[1].cpu().numpy()
+    return res.cpu().numpy(), None
+
+
+def check(reduce, rowptr, col, val, B):
+    out, arg = run_gpu(reduce, rowptr, col, val, B)
+    ref, ref_arg = oracle.spmm(reduce, rowptr, col, val, B)
+    S = oracle.spmm_abs_sum(rowptr, col, val, B)
+    err = np.abs(out.astype(np.float64) - ref.astype(np.float64))
+    assert np.all(err <= RTOL * S + 1e-30), f"max err ratio {np.max(err / (S + 1e-30))}"
+    if reduce in ("min", "max"):
+        nnz = col.size
+        # values the winners point at must reproduce out exactly
+        w = np.ones(nnz, np.float32) if val is None else val
+        valid = arg != nnz
+        assert np.array_equal(valid, ref_arg != nnz)
+        k_idx = np.broadcast_to(np.arange(B.shape[1]), arg.shape)
+        picked = w[arg[valid]] * B[col[arg[valid]], k_idx[valid]]
+        assert np.array_equal(picked, out[valid])
+        assert np.all(out[~valid] == 0)
+        assert np.array_equal(arg, ref_arg)
+    return out
+
+
+def test_readme_kat(kats):
+    k = kats["spmm"]
+    row, col = np.array(k["index"], np.int64)
+    rowptr = oracle.ind2ptr(row, k["m"])
+    out, _ = run_gpu("sum", rowptr, col, np.array(k["value"], np.float32), np.array(k["matrix"], np.float32))
+    assert out.tolist() == k["out"]
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max"])
+@pytest.mark.parametrize("K", [1, 2, 3, 4, 8, 12, 16, 32, 33, 64, 100, 128, 256, 260, 512])
+def test_random_k(reduce, K):
+    M, N, nnz = 777, 555, 6000
+    row, rowptr, col, val = random_csr(M, N, nnz, seed=K)
+    B = np.random.default_rng(K + 1).standard_normal((N, K)).astype(np.float32)
+    check(reduce, rowptr, col, val, B)
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max"])
+def test_no_value(reduce):
+    row, rowptr, col, _ = random_csr(500, 400, 4000, seed=3, with_value=False)
+    B = np.random.default_rng(7).standard_normal((400, 64)).astype(np.float32)
+    check(reduce, rowptr, col, None, B)
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max"])
+@pytest.mark.parametrize("K", [4, 64, 128])
+def test_skewed_and_empty_rows(reduce, K):
+    row, rowptr, col, val = skewed_csr(400, 300, seed=K, long_rows=(0, 5, 399), long_deg=777)
+    B = np.random.default_rng(2).standard_normal((300, K)).astype(np.float32)
+    check(reduce, rowptr, col, val, B)
+
+
+def test_all_rows_empty():
+    rowptr = np.zeros(101, np.int64)
+    col = np.zeros(0, np.int64)
+    B = np.ones((10, 8), np.float32)
+    for reduce in ("sum", "mean", "min", "max"):
+        out, arg = run_gpu(reduce, rowptr, col, np.zeros(0, np.float32), B)
+        assert np.all(out == 0)
+        if arg is not None:
+            assert np.all(arg == 0)  # sentinel = nnz = 0
+
+
+def test_ties_pick_first_edge():
+    """Equal candidates: arg_out is the first winner in edge order."""
+    rowptr = np.array([0, 6], np.int64)
+    col = np.array([1, 0, 1, 0, 1, 0], np.int64)
+    val = np.ones(6, np.float32)
+    B = np.array([[5.0] * 128, [5.0] * 128], np.float32)
+    for reduce in ("min", "max"):
+        out, arg = run_gpu(reduce, rowptr, col, val, B)
+        assert np.all(out == 5.0) and np.all(arg == 0)
+
+
+@pytest.mark.parametrize("variant", [0, 2, 3, 4])
+def test_variants_k128(variant):
+    from paddle_sparse_amd import ops
+
+    row, rowptr, col, val = random_csr(3000, 2000, 40000, seed=variant)
+    B = np.random.default_rng(5).standard_normal((2000, 128)).astype(np.float32)
+    prev = ops.spmm_set_variant(variant)
+    try:
+        for reduce in ("sum", "mean", "max"):
+            check(reduce, rowptr, col, val, B)
+    finally:
+        ops.spmm_set_variant(prev)
+
+
+def test_config2_shape_vs_oracle():
+    """BASELINE config 2: CSR 100k x 100k, nnz = 1M, F = 64."""
+    M = N = 100_000
+    row, rowptr, col, val = random_csr(M, N, 1_000_000, seed=1)
+    B = np.random.default_rng(1).standard_normal((N, 64)).astype(np.float32)
+    check("sum", rowptr, col, val, B)
+
+
+def test_linearity_full_size():
+    """BASELINE config 3 size (2M x 2M, nnz 20M, F=128): size-independent
+    properties instead of the oracle — linearity in B, and A @ ones == row sums."""
+    from paddle_sparse_amd import ops
+
+    M = N = 2_000_000
+    nnz, K = 20_000_000, 128
+    g = torch.Generator(device="cuda").manual_seed(2)
+    row = torch.sort(torch.randint(0, M, (nnz,), generator=g, device="cuda"))[0]
+    col = torch.randint(0, N, (nnz,), generator=g, device="cuda")
+    val = torch.randn(nnz, generator=g, device="cuda")
+    rowptr = ops.ind2ptr(row, M)
+    B1 = torch.randn(N, K, generator=g, device="cuda")
+    B2 = torch.randn(N, K, generator=g, device="cuda")
+    o1 = ops.spmm_sum(rowptr, col, val, B1)
+    o2 = ops.spmm_sum(rowptr, col, val, B2)
+    o12 = ops.spmm_sum(rowptr, col, val, B1 + 2 * B2)
+    scale = torch.zeros(M, device="cuda").index_add_(0, row, val.abs())
+    err = (o12 - (o1 + 2 * o2)).abs().max(dim=1)[0]
+    assert bool((err <= 1e-4 * (scale * 6 + 1e-6)).all())
+    ones = torch.ones(N, K, device="cuda")
+    rs = torch.zeros(M, device="cuda", dtype=torch.float64).index_add_(0, row, val.double())
+    o = ops.spmm_sum(rowptr, col, val, ones)
+    assert bool(((o[:, 0].double() - rs).abs() <= 1e-5 * scale.double() + 1e-6).all())
+    assert bool((o == o[:, :1]).all())
+    # mean / max agree with sum-derived quantities
+    deg = (rowptr[1:] - rowptr[:-1]).clamp(min=1).float()
+    om = ops.spmm_mean(rowptr, col, val, B1)
+    assert bool(((om - o1 / deg[:, None]).abs() <= 1e-5 * (scale / deg * 6)[:, None] + 1e-6).all())
