@@ -57,12 +57,25 @@ def make_workload(M: int, N: int, nnz: int, F: int, seed: int, device):
     return rowptr, col, val
 
 
+def host_threads() -> int:
+    """Cores this process may really use: affinity, capped by the cgroup CPU
+    quota (the GPU box gives a 1-GPU job a 16-CPU share of a larger host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(rowptr, col, val, B, budget_s: float = 12.0):
     """Oracle C port (OpenMP over rows) timed on this box's host cores on a
     bounded row-prefix of the same workload; also used to check the GPU."""
     import oracle
 
-    threads = min(os.cpu_count() or 1, 64)
+    threads = host_threads()
     os.environ["OMP_NUM_THREADS"] = str(threads)
     M = rowptr.numel() - 1
     sample_rows = min(M, 1_000_000)
