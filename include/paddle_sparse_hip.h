@@ -115,6 +115,76 @@ int psa_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
  * compute identical results up to fp32 summation order; listed in DESIGN.md. */
 int psa_spmm_set_variant(int variant);
 
+/* ---- index_sort: stable LSD radix sort (bit-exact permutation) ----------- */
+
+/* Replaces index_sort (paddle_sparse/utils.py:14-23: `inputs.argsort()`),
+ * whose call sites are the constructor sort (storage.py:164-169), csr2csc
+ * (storage.py:430-432) and csc2csr (storage.py:444-445).
+ * keys: int64[n], values in [0, max_value) — max_value is the hint the
+ * reference signature already carries (M*N); it selects the number of 8-bit
+ * passes.  perm_out: int64[n], the STABLE sorting permutation
+ * (== numpy argsort(kind="stable")); sorted_out: int64[n] or NULL.
+ * keys is not modified.  workspace: psa_index_sort_workspace_bytes(n,
+ * max_value) bytes of device memory, 16-byte aligned.  n < 2^31. */
+size_t psa_index_sort_workspace_bytes(int64_t n, int64_t max_value);
+int psa_index_sort(const int64_t* keys, int64_t n, int64_t max_value,
+                   int64_t* sorted_out, int64_t* perm_out, void* workspace,
+                   size_t workspace_bytes, psa_stream_t stream);
+
+/* keys[i] = a[i] * mul + b[i]  (storage.py:159-162 key = row*N + col,
+ * storage.py:430 key = M*col + row).  If unsorted_flag != NULL, *unsorted_flag
+ * (device int32, caller-zeroed) is set to 1 when some keys[i] < keys[i-1]
+ * (the reference's sortedness test, storage.py:163). */
+int psa_make_keys(const int64_t* a, const int64_t* b, int64_t mul, int64_t n,
+                  int64_t* keys, int32_t* unsorted_flag, psa_stream_t stream);
+
+/* out[i, :] = src[perm[i], :] for rows of row_bytes bytes (any dtype):
+ * the `x[perm]` gathers of storage.py:166-169, transpose.py:14-22,
+ * tensor.py:252-257. */
+int psa_gather_rows(const void* src, const int64_t* perm, int64_t n,
+                    int64_t row_bytes, void* out, psa_stream_t stream);
+
+/* inv[perm[i]] = i.  Same result as the reference's second sort in csc2csr
+ * (storage.py:444-445 sorts a permutation to invert it), in one pass. */
+int psa_invert_permutation(const int64_t* perm, int64_t n, int64_t* inv,
+                           psa_stream_t stream);
+
+/* ---- coalesce on sorted keys (storage.py:454-486) ------------------------ */
+
+/* Phase 1: *count_out (device int64) = number of distinct values in
+ * sorted_keys[n] (the reference's mask.sum(); mask.all() <=> count == n).
+ * workspace: psa_unique_workspace_bytes(n) bytes; it carries per-block
+ * offsets into phase 2 and must stay untouched in between. */
+size_t psa_unique_workspace_bytes(int64_t n);
+int psa_unique_count(const int64_t* sorted_keys, int64_t n, void* workspace,
+                     size_t workspace_bytes, int64_t* count_out,
+                     psa_stream_t stream);
+
+/* Phase 2 (after the caller has read the count and sized the outputs):
+ * ptr_out int64[count+1] = start of every run of equal keys, ptr_out[count]
+ * = n (the reference's `ptr`, storage.py:467-470); row_out/col_out
+ * int64[count] = key / N, key % N of each distinct key (the reference's
+ * row[mask], col[mask], storage.py:462-463).  Any of ptr_out or the
+ * (row_out, col_out) pair may be NULL.  count: the device scalar written by
+ * phase 1. */
+int psa_unique_write(const int64_t* sorted_keys, int64_t n, int64_t N,
+                     const void* workspace, const int64_t* count,
+                     int64_t* ptr_out, int64_t* row_out, int64_t* col_out,
+                     psa_stream_t stream);
+
+/* out[s, :] = REDUCE_{i in [ptr[s], ptr[s+1])} src[perm ? perm[i] : i, :]
+ * for src rows of D elements of `dtype` (psa_dtype).  Stands in for
+ * paddle_scatter.segment_csr at storage.py:471 (with perm = the sort
+ * permutation, so value[perm] is never materialised), reduce.py:51 and
+ * tensor.py:437.  Semantics = pytorch_scatter segment_csr: empty segment ->
+ * 0, mean = sum / count (floor division for integer dtypes), min/max values
+ * only.  Sums run in segment order.  n_hint = ptr[nseg] if known (selects the
+ * wave-per-segment kernel for long segments), else 0. */
+int psa_segment_reduce(int reduce, int dtype, const void* src,
+                       const int64_t* perm, const int64_t* ptr, int64_t nseg,
+                       int64_t D, int64_t n_hint, void* out,
+                       psa_stream_t stream);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

@@ -25,6 +25,19 @@ SIGNATURES = {
     "psa_spmm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                          c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "psa_spmm_set_variant": (c_int, [c_int]),
+    "psa_index_sort_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "psa_index_sort": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p,
+                               c_void_p, c_size_t, c_void_p]),
+    "psa_make_keys": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p,
+                              c_void_p, c_void_p]),
+    "psa_gather_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "psa_invert_permutation": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "psa_unique_workspace_bytes": (c_size_t, [c_int64]),
+    "psa_unique_count": (c_int, [c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "psa_unique_write": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p]),
+    "psa_segment_reduce": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64,
+                                   c_int64, c_int64, c_void_p, c_void_p]),
 }
 
 _lib = None

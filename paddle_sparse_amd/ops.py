@@ -123,3 +123,132 @@ def spmm_max(rowptr, col, value, mat) -> Tuple[torch.Tensor, torch.Tensor]:
 def spmm_set_variant(variant: int) -> int:
     """Bench/test hook: pick the SpMM kernel variant (0 = auto)."""
     return _lib.load().psa_spmm_set_variant(int(variant))
+
+
+# ---------------------------------------------------------------------------
+# sort / gather / coalesce building blocks
+# ---------------------------------------------------------------------------
+
+_DTYPE_ID = {
+    torch.float32: 0, torch.float64: 1, torch.int32: 2, torch.int64: 3,
+    torch.float16: 4, torch.bfloat16: 5,
+}
+
+
+def _workspace(nbytes: int, device) -> torch.Tensor:
+    # torch's caching allocator hands back >= 512-byte aligned blocks
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def index_sort(keys: torch.Tensor, max_value: Optional[int] = None,
+               with_sorted_inputs: bool = False
+               ) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
+    """paddle_sparse/utils.py:14-23 — returns (sorted | None, perm).
+
+    Stable LSD radix sort in HIP; `max_value` (exclusive bound on the keys, the
+    reference passes M*N) selects the number of 8-bit passes.  perm is the
+    stable sorting permutation, bit-identical to numpy argsort(kind="stable").
+    """
+    keys = _index(keys, "keys")
+    n = keys.numel()
+    if max_value is None:
+        max_value = (int(keys.max()) + 1) if n else 1
+    max_value = max(int(max_value), 1)
+    perm = torch.empty(n, dtype=torch.int64, device=keys.device)
+    out = torch.empty(n, dtype=torch.int64, device=keys.device) if with_sorted_inputs else None
+    lib = _lib.load()
+    nbytes = lib.psa_index_sort_workspace_bytes(n, max_value)
+    ws = _workspace(nbytes, keys.device)
+    with torch.cuda.device(keys.device):
+        check(lib.psa_index_sort(_ptr(keys), n, max_value, _ptr(out), _ptr(perm),
+                                 _ptr(ws), ws.numel(), _stream()))
+    return out, perm
+
+
+def make_keys(a: torch.Tensor, b: torch.Tensor, mul: int, check_sorted: bool = False
+              ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """keys = a * mul + b  (+ device flag "some key is smaller than its
+    predecessor", storage.py:159-163)."""
+    a, b = _index(a, "a"), _index(b, "b")
+    if a.numel() != b.numel():
+        raise ValueError("a and b must have the same length")
+    keys = torch.empty_like(a)
+    flag = torch.zeros(1, dtype=torch.int32, device=a.device) if check_sorted else None
+    with torch.cuda.device(a.device):
+        check(_lib.load().psa_make_keys(_ptr(a), _ptr(b), int(mul), a.numel(), _ptr(keys),
+                                        _ptr(flag), _stream()))
+    return keys, flag
+
+
+def gather_rows(src: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
+    """src[perm] along dim 0 for any dtype / trailing shape."""
+    _gpu(src, "src")
+    perm = _index(perm, "perm")
+    src = src.contiguous()
+    n = perm.numel()
+    out = torch.empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    row_bytes = src.element_size()
+    for s in src.shape[1:]:
+        row_bytes *= s
+    with torch.cuda.device(src.device):
+        check(_lib.load().psa_gather_rows(_ptr(src), _ptr(perm), n, row_bytes, _ptr(out), _stream()))
+    return out
+
+
+def invert_permutation(perm: torch.Tensor) -> torch.Tensor:
+    perm = _index(perm, "perm")
+    inv = torch.empty_like(perm)
+    with torch.cuda.device(perm.device):
+        check(_lib.load().psa_invert_permutation(_ptr(perm), perm.numel(), _ptr(inv), _stream()))
+    return inv
+
+
+def segment_csr(src: torch.Tensor, indptr: torch.Tensor, reduce: str = "sum",
+                perm: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """paddle_scatter.segment_csr(src, indptr, reduce=...) along dim 0
+    (call sites storage.py:471, reduce.py:51); with `perm`, reduces
+    src[perm] without materialising it."""
+    _gpu(src, "src")
+    indptr = _index(indptr, "indptr")
+    if src.dtype not in _DTYPE_ID:
+        raise TypeError(f"segment_csr: unsupported dtype {src.dtype}")
+    src = src.contiguous()
+    if perm is not None:
+        perm = _index(perm, "perm")
+    nseg = indptr.numel() - 1
+    D = 1
+    for s in src.shape[1:]:
+        D *= s
+    n_rows = perm.numel() if perm is not None else src.shape[0]
+    out = torch.empty((nseg,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    with torch.cuda.device(src.device):
+        check(_lib.load().psa_segment_reduce(REDUCE_ID[reduce], _DTYPE_ID[src.dtype], _ptr(src),
+                                             _ptr(perm), _ptr(indptr), nseg, D, n_rows,
+                                             _ptr(out), _stream()))
+    return out
+
+
+def unique_sorted(sorted_keys: torch.Tensor, N: int, want_ptr: bool = True,
+                  want_rowcol: bool = True):
+    """Run-length structure of SORTED keys (storage.py:455-470 without the
+    bool-mask selects).  Returns (count, ptr | None, row | None, col | None)
+    with row = key // N, col = key % N of each distinct key.  One host sync
+    (reading the count to size the outputs) — the reference has three."""
+    sorted_keys = _index(sorted_keys, "sorted_keys")
+    n = sorted_keys.numel()
+    dev = sorted_keys.device
+    lib = _lib.load()
+    ws = _workspace(lib.psa_unique_workspace_bytes(n), dev)
+    count_d = torch.empty(1, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.psa_unique_count(_ptr(sorted_keys), n, _ptr(ws), ws.numel(), _ptr(count_d), _stream()))
+        count = int(count_d.item())
+        ptr = torch.empty(count + 1, dtype=torch.int64, device=dev) if want_ptr else None
+        row = torch.empty(count, dtype=torch.int64, device=dev) if want_rowcol else None
+        col = torch.empty(count, dtype=torch.int64, device=dev) if want_rowcol else None
+        if n > 0 and (want_ptr or want_rowcol):
+            check(lib.psa_unique_write(_ptr(sorted_keys), n, int(N), _ptr(ws), _ptr(count_d),
+                                       _ptr(ptr), _ptr(row), _ptr(col), _stream()))
+        elif want_ptr:
+            ptr.zero_()
+    return count, ptr, row, col

@@ -1,0 +1,161 @@
+"""GPU parity: index_sort (bit-exact stable permutation), key construction,
+gathers, permutation inverse, unique/segment reduce — vs numpy / the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import storage_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("n,max_value,seed", [
+    (1, 1, 0), (1, 10, 1), (5, 1, 2), (63, 7, 3), (64, 300, 4), (2047, 1 << 20, 5),
+    (2048, 256, 6), (2049, 257, 7), (10000, 1000 * 1000, 8), (100000, 3, 9),
+    (300000, 1 << 40, 10), (1000003, 1 << 48, 11), (5000000, 1 << 33, 12),
+    (2500000, (1 << 62) + 12345, 13),
+])
+def test_index_sort_matches_stable_argsort(n, max_value, seed):
+    from paddle_sparse_amd import ops
+
+    rng = np.random.default_rng(seed)
+    keys = rng.integers(0, max_value, n, dtype=np.int64)
+    srt, perm = ops.index_sort(dev(keys), max_value, with_sorted_inputs=True)
+    ref = so.index_sort(keys)
+    assert np.array_equal(perm.cpu().numpy(), ref)
+    assert np.array_equal(srt.cpu().numpy(), keys[ref])
+    none, perm2 = ops.index_sort(dev(keys), max_value)
+    assert none is None and torch.equal(perm, perm2)
+
+
+def test_index_sort_heavy_duplicates_and_sorted_input():
+    from paddle_sparse_amd import ops
+
+    rng = np.random.default_rng(0)
+    keys = np.repeat(rng.integers(0, 50, 40), rng.integers(1, 30000, 40)).astype(np.int64)
+    rng.shuffle(keys)
+    _, perm = ops.index_sort(dev(keys), 50)
+    assert np.array_equal(perm.cpu().numpy(), so.index_sort(keys))
+    keys = np.sort(keys)
+    _, perm = ops.index_sort(dev(keys), 50)
+    assert np.array_equal(perm.cpu().numpy(), np.arange(keys.size))
+    # max_value unknown -> derived from the data
+    _, perm = ops.index_sort(dev(keys[::-1].copy()))
+    assert np.array_equal(perm.cpu().numpy(), so.index_sort(keys[::-1]))
+
+
+def test_index_sort_empty():
+    from paddle_sparse_amd import ops
+
+    srt, perm = ops.index_sort(torch.empty(0, dtype=torch.int64, device="cuda"), 10, True)
+    assert perm.numel() == 0 and srt.numel() == 0
+
+
+def test_make_keys_and_flag():
+    from paddle_sparse_amd import ops
+
+    rng = np.random.default_rng(1)
+    a, b = rng.integers(0, 1 << 24, 100000), rng.integers(0, 1 << 24, 100000)
+    keys, flag = ops.make_keys(dev(a), dev(b), 1 << 24, check_sorted=True)
+    assert np.array_equal(keys.cpu().numpy(), a * (1 << 24) + b)
+    assert int(flag.item()) == 1
+    order = np.lexsort((b, a))
+    keys, flag = ops.make_keys(dev(a[order]), dev(b[order]), 1 << 24, check_sorted=True)
+    assert int(flag.item()) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64, torch.int32, torch.int64, torch.float16, torch.bfloat16, torch.uint8])
+@pytest.mark.parametrize("tail", [(), (1,), (2,), (3,), (4, 5), (64,)])
+def test_gather_rows(dtype, tail):
+    from paddle_sparse_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(0)
+    src = (torch.rand((1000,) + tail, generator=g, device="cuda") * 100).to(dtype)
+    perm = torch.randperm(1000, generator=g, device="cuda")
+    assert torch.equal(ops.gather_rows(src, perm), src[perm])
+    idx = torch.randint(0, 1000, (3333,), generator=g, device="cuda")
+    assert torch.equal(ops.gather_rows(src, idx), src[idx])
+
+
+def test_invert_permutation():
+    from paddle_sparse_amd import ops
+
+    perm = torch.randperm(123457, device="cuda")
+    inv = ops.invert_permutation(perm)
+    assert torch.equal(inv[perm], torch.arange(123457, device="cuda"))
+    # same answer as the reference's "sort the permutation" (storage.py:444-445)
+    assert np.array_equal(inv.cpu().numpy(), so.index_sort(perm.cpu().numpy()))
+
+
+@pytest.mark.parametrize("n,distinct,seed", [(1, 1, 0), (64, 5, 1), (2048, 2048, 2), (2049, 10, 3), (100000, 30000, 4), (700000, 650000, 5)])
+def test_unique_sorted(n, distinct, seed):
+    from paddle_sparse_amd import ops
+
+    rng = np.random.default_rng(seed)
+    N = 1000
+    pool = np.sort(rng.choice(10**7, distinct, replace=False))
+    keys = np.sort(rng.choice(pool, n)).astype(np.int64)
+    count, ptr, row, col = ops.unique_sorted(dev(keys), N)
+    mask = np.concatenate([[True], keys[1:] != keys[:-1]])
+    assert count == mask.sum()
+    assert np.array_equal(ptr.cpu().numpy(), np.concatenate([np.nonzero(mask)[0], [n]]))
+    assert np.array_equal(row.cpu().numpy(), keys[mask] // N)
+    assert np.array_equal(col.cpu().numpy(), keys[mask] % N)
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max"])
+@pytest.mark.parametrize("npdtype,tdtype", [(np.float32, torch.float32), (np.float64, torch.float64), (np.int32, torch.int32), (np.int64, torch.int64)])
+@pytest.mark.parametrize("tail", [(), (2,), (5,)])
+def test_segment_csr_vs_oracle(reduce, npdtype, tdtype, tail):
+    from paddle_sparse_amd import ops
+
+    rng = np.random.default_rng(7)
+    n, nseg = 5000, 700
+    src = rng.integers(-40, 40, (n,) + tail).astype(npdtype)  # exact in every dtype
+    cuts = np.sort(rng.integers(0, n + 1, nseg - 1))
+    indptr = np.concatenate([[0], cuts, [n]]).astype(np.int64)
+    got = ops.segment_csr(dev(src), dev(indptr), reduce).cpu().numpy()
+    ref = so.segment_csr(src, indptr, reduce)
+    if reduce == "mean" and npdtype in (np.float32, np.float64):
+        np.testing.assert_allclose(got, ref, rtol=1e-6)
+    else:
+        assert np.array_equal(got, ref)
+    # gathered form: reduce src[perm] without materialising it
+    perm = rng.permutation(n).astype(np.int64)
+    got = ops.segment_csr(dev(src), dev(indptr), reduce, perm=dev(perm)).cpu().numpy()
+    ref = so.segment_csr(src[perm], indptr, reduce)
+    if reduce == "mean" and npdtype in (np.float32, np.float64):
+        np.testing.assert_allclose(got, ref, rtol=1e-6)
+    else:
+        assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("tdtype", [torch.float16, torch.bfloat16])
+def test_segment_csr_half(tdtype):
+    from paddle_sparse_amd import ops
+
+    rng = np.random.default_rng(3)
+    src = rng.integers(-8, 8, (3000, 2)).astype(np.float32)
+    indptr = np.concatenate([[0], np.sort(rng.integers(0, 3001, 400)), [3000]]).astype(np.int64)
+    for reduce in ("sum", "min", "max"):
+        got = ops.segment_csr(dev(src).to(tdtype), dev(indptr), reduce).float().cpu().numpy()
+        assert np.array_equal(got, so.segment_csr(src, indptr, reduce))
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max"])
+def test_segment_csr_long_segments_wave_kernel(reduce):
+    from paddle_sparse_amd import ops
+
+    rng = np.random.default_rng(5)
+    n, nseg = 200000, 300
+    src = rng.integers(-5, 5, n).astype(np.float32)
+    cuts = np.sort(rng.integers(0, n + 1, nseg - 1))
+    cuts[10] = cuts[9]  # an empty segment
+    indptr = np.concatenate([[0], cuts, [n]]).astype(np.int64)
+    got = ops.segment_csr(dev(src), dev(indptr), reduce).cpu().numpy()
+    ref = so.segment_csr_fast(src, indptr, reduce)
+    np.testing.assert_allclose(got, ref, rtol=1e-6, atol=0)
