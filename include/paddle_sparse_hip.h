@@ -110,6 +110,35 @@ int psa_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
              int64_t K, int64_t nnz, float* out, int64_t* arg_out,
              psa_stream_t stream);
 
+/* ---- SpMM backward (fp32) ------------------------------------------------ */
+
+/* grad wrt the sparse values for sum/mean (upstream spmm_value_bw):
+ * out[e] = sum_k mat[col[e],k] * grad[row(e),k], divided by max(deg(row(e)),1)
+ * for PSA_MEAN.  row(e) is implied by rowptr (one wave per CSR row), so the
+ * upstream `row` argument is not needed.  out: f32[nnz]. */
+int psa_spmm_value_bw(int reduce, const int64_t* rowptr, const int64_t* col,
+                      const float* mat, const float* grad, int64_t M, int64_t K,
+                      int64_t nnz, float* out, psa_stream_t stream);
+
+/* CSC-ordered edge weights for grad wrt the dense operand (sum/mean):
+ * out[j] = (value ? value[csr2csc[j]] : 1) / (mean ? max(deg(row_csc[j]),1) : 1)
+ * with row_csc = row[csr2csc].  gB = psa_spmm(PSA_SUM, colptr, row_csc, out,
+ * gOut) — upstream torch_sparse/matmul.py spmm_sum/spmm_mean backward. */
+int psa_transpose_weights(const float* value, const int64_t* csr2csc,
+                          const int64_t* row_csc, const int64_t* rowptr,
+                          int64_t nnz, int mean, float* out,
+                          psa_stream_t stream);
+
+/* min/max backward through arg_out (entries == nnz are masked):
+ *   grad_value[arg] += mat[col[arg],k] * grad[i,k]   (f32[nnz], or NULL)
+ *   grad_mat[col[arg],k] += w_arg * grad[i,k]        (f32[N,K], or NULL)
+ * Both outputs are zero-filled by the call; accumulation uses float atomics
+ * (summation order is not fixed; results agree to fp32 rounding). */
+int psa_spmm_minmax_bw(const int64_t* col, const float* value, const float* mat,
+                       const float* grad, const int64_t* arg_out, int64_t M,
+                       int64_t N, int64_t K, int64_t nnz, float* grad_value,
+                       float* grad_mat, psa_stream_t stream);
+
 /* Test/bench hook: choose the SpMM kernel variant for subsequent psa_spmm
  * calls of this process (0 = auto).  Returns the previous value.  Variants
  * compute identical results up to fp32 summation order; listed in DESIGN.md. */
@@ -149,6 +178,17 @@ int psa_gather_rows(const void* src, const int64_t* perm, int64_t n,
 int psa_invert_permutation(const int64_t* perm, int64_t n, int64_t* inv,
                            psa_stream_t stream);
 
+/* out[b] = #{i : index[i] == b} for b in [0, size): colcount
+ * (storage.py:414-418, scatter_add of ones).  out: int64[size]. */
+int psa_bincount(const int64_t* index, int64_t n, int64_t size, int64_t* out,
+                 psa_stream_t stream);
+
+/* ptr_out[0] = 0, ptr_out[i+1] = counts[0] + ... + counts[i]: colptr from
+ * colcount (storage.py:397-398, zeros + cumsum).  ptr_out: int64[n+1]. */
+size_t psa_count2ptr_workspace_bytes(int64_t n);
+int psa_count2ptr(const int64_t* counts, int64_t n, int64_t* ptr_out,
+                  void* workspace, size_t workspace_bytes, psa_stream_t stream);
+
 /* ---- coalesce on sorted keys (storage.py:454-486) ------------------------ */
 
 /* Phase 1: *count_out (device int64) = number of distinct values in
@@ -184,6 +224,18 @@ int psa_segment_reduce(int reduce, int dtype, const void* src,
                        const int64_t* perm, const int64_t* ptr, int64_t nseg,
                        int64_t D, int64_t n_hint, void* out,
                        psa_stream_t stream);
+
+/* out[index[i], :] = REDUCE over i of src[i, :]; src [n, D] of `dtype`
+ * (f32/f64/i32/i64), out [dim_size, D].  Stands in for
+ * paddle_scatter.scatter at reduce.py:40-42 (reduce over dim 0, index = col).
+ * Rows no index points at are 0; mean = sum / count (floor for integers).
+ * workspace (psa_scatter_workspace_bytes(dim_size) bytes) is needed for
+ * mean/min/max.  Float sums use atomics: order not fixed. */
+size_t psa_scatter_workspace_bytes(int64_t dim_size);
+int psa_scatter_reduce(int reduce, int dtype, const void* src,
+                       const int64_t* index, int64_t n, int64_t D,
+                       int64_t dim_size, void* out, void* workspace,
+                       size_t workspace_bytes, psa_stream_t stream);
 
 #ifdef __cplusplus
 } /* extern "C" */

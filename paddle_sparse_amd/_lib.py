@@ -25,6 +25,12 @@ SIGNATURES = {
     "psa_spmm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                          c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "psa_spmm_set_variant": (c_int, [c_int]),
+    "psa_spmm_value_bw": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                  c_int64, c_int64, c_void_p, c_void_p]),
+    "psa_transpose_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                      c_int, c_void_p, c_void_p]),
+    "psa_spmm_minmax_bw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                   c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "psa_index_sort_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "psa_index_sort": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p,
                                c_void_p, c_size_t, c_void_p]),
@@ -32,12 +38,18 @@ SIGNATURES = {
                               c_void_p, c_void_p]),
     "psa_gather_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "psa_invert_permutation": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "psa_bincount": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "psa_count2ptr_workspace_bytes": (c_size_t, [c_int64]),
+    "psa_count2ptr": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "psa_unique_workspace_bytes": (c_size_t, [c_int64]),
     "psa_unique_count": (c_int, [c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_void_p]),
     "psa_unique_write": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p]),
     "psa_segment_reduce": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64,
                                    c_int64, c_int64, c_void_p, c_void_p]),
+    "psa_scatter_workspace_bytes": (c_size_t, [c_int64]),
+    "psa_scatter_reduce": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int64, c_int64,
+                                   c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
 _lib = None

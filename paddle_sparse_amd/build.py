@@ -29,6 +29,7 @@ HIPCC_FLAGS = [
     "-Wall",
     "-Wno-unused-function",
     "-fno-gpu-rdc",
+    "-munsafe-fp-atomics",  # native global_atomic_add_f32 (no CAS loop)
 ]
 
 

@@ -1,0 +1,50 @@
+"""coalesce(index, value, m, n, op) — paddle_sparse/coalesce.py:8-29.
+
+The reference builds an unsorted SparseStorage (argsort + 3 gathers,
+storage.py:158-171) and then coalesces it (storage.py:454-486).  The same
+result is produced here in one fused chain that never materialises the
+permuted row/col/value arrays:
+
+    keys = row*n + col            make_keys (also tells if already sorted)
+    sorted_keys, perm             index_sort (stable LSD radix, HIP)
+    count, ptr, row', col'        unique_sorted (row'/col' = key / n, key % n)
+    value' = reduce value[perm]   segment_csr(perm=perm)
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import ops
+
+
+def _coalesce_sorted_stream(row, col, value, m: int, n: int, op: str):
+    nnz = col.numel()
+    if nnz == 0:
+        return row, col, value
+    keys, unsorted = ops.make_keys(row, col, n, check_sorted=True)
+    perm = None
+    if int(unsorted.item()):
+        keys, perm = ops.index_sort(keys, m * n, with_sorted_inputs=True)
+    count, ptr, new_row, new_col = ops.unique_sorted(keys, n)
+    if count == nnz and perm is None:
+        return row, col, value  # sorted and duplicate-free already
+    if value is not None:
+        if count == nnz:
+            value = ops.gather_rows(value, perm)
+        else:
+            value = ops.segment_csr(value, ptr, op, perm=perm)
+    return new_row, new_col, value
+
+
+def coalesce(index: torch.Tensor, value: Optional[torch.Tensor], m: int, n: int,
+             op: str = "add") -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """Row-wise sorts `index` and merges duplicate entries with `op`
+    ("add"/"sum", "mean", "min", "max").  Returns (index[2, nnz'], value)."""
+    row, col = index[0].contiguous(), index[1].contiguous()
+    assert row.dtype == torch.int64 and col.dtype == torch.int64
+    if value is not None:
+        assert value.shape[0] == col.numel()
+    row, col, value = _coalesce_sorted_stream(row, col, value, m, n, op)
+    return torch.stack([row, col], dim=0), value

@@ -1,0 +1,237 @@
+// SpMM backward pieces, fp32, gfx950.  Not in the reference (README.md:47-50);
+// semantics are upstream pytorch_sparse (spmm_value_bw_cpu and the Python
+// backward of torch_sparse/matmul.py), restated in oracle/spmm_oracle.c.
+//
+//   psa_spmm_value_bw      gV[e] = <mat[col[e],:], gOut[row(e),:]> (/deg for
+//                          mean) — SDDMM-shaped.  One wave per CSR row: the
+//                          gOut row is read once per ROW (kept in registers),
+//                          so HBM traffic is the forward's, not the 2x of an
+//                          edge-parallel kernel; dots fold with wave shuffles.
+//   psa_transpose_weights  w'[j] = value[csr2csc[j]] (/deg(row) for mean): the
+//                          CSC-ordered weights that turn gB = A^T gOut into a
+//                          plain psa_spmm over (colptr, row[csr2csc], w').
+//   psa_spmm_minmax_bw     scatter through arg_out with float atomics.
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+
+template <int VEC>
+struct Vec;
+template <>
+struct Vec<1> {
+  using T = float;
+};
+template <>
+struct Vec<4> {
+  using T = float4;
+};
+
+template <int VEC>
+__device__ __forceinline__ void load_vec(const float* p, float (&dst)[VEC]) {
+  using T = typename Vec<VEC>::T;
+  const T v = *reinterpret_cast<const T*>(p);
+  const float* f = reinterpret_cast<const float*>(&v);
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) dst[i] = f[i];
+}
+
+template <int VEC, int LPR, int U>
+__global__ void __launch_bounds__(kThreads)
+spmm_value_bw_kernel(const int64_t* __restrict__ rowptr,
+                     const int64_t* __restrict__ col,
+                     const float* __restrict__ mat,
+                     const float* __restrict__ grad, float* __restrict__ out,
+                     int64_t M, int64_t K, int mean) {
+  constexpr int G = 64 / LPR;
+  constexpr int TILE = LPR * VEC;
+  static_assert(64 % (G * U) == 0, "edge batch must divide the wave");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * kWaves + wave;
+  if (row >= M) return;
+  const int g = lane / LPR;
+  const int l = lane % LPR;
+  const int64_t s = rowptr[row];
+  const int64_t e = rowptr[row + 1];
+  const float denom = (mean && e - s > 1) ? static_cast<float>(e - s) : 1.0f;
+  const int64_t ntiles = (K + TILE - 1) / TILE;
+  const float* grow = grad + row * K;
+
+  float gr[VEC];
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) gr[i] = 0.f;
+  if (l * VEC < K) load_vec<VEC>(grow + l * VEC, gr);  // tile 0 stays in registers
+
+  for (int64_t base = s; base < e; base += 64) {
+    const int n = (e - base) < 64 ? static_cast<int>(e - base) : 64;
+    int64_t c_l = 0;
+    if (lane < n) c_l = col[base + lane];
+    for (int j = 0; j < n; j += G * U) {
+      float dot[U];
+      int64_t c[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = j + u * G + g;
+        c[u] = __shfl(static_cast<long long>(c_l), idx);
+        ok[u] = idx < n;
+        dot[u] = 0.f;
+      }
+      for (int64_t t = 0; t < ntiles; ++t) {
+        const int64_t k0 = t * TILE + l * VEC;
+        const bool kact = k0 < K;
+        float gt[VEC];
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) gt[i] = gr[i];
+        if (t > 0) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) gt[i] = 0.f;
+          if (kact) load_vec<VEC>(grow + k0, gt);
+        }
+        float b[U][VEC];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) b[u][i] = 0.f;
+          if (ok[u] && kact) load_vec<VEC>(mat + c[u] * K + k0, b[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) dot[u] += b[u][i] * gt[i];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float p = dot[u];
+#pragma unroll
+        for (int off = LPR / 2; off >= 1; off >>= 1) p += __shfl_xor(p, off);
+        if (l == 0 && ok[u]) out[base + j + u * G + g] = p / denom;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(kThreads)
+transpose_weights_kernel(const float* __restrict__ value,
+                         const int64_t* __restrict__ csr2csc,
+                         const int64_t* __restrict__ row_csc,
+                         const int64_t* __restrict__ rowptr, int64_t nnz,
+                         int mean, float* __restrict__ out) {
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (j >= nnz) return;
+  float w = value ? value[csr2csc[j]] : 1.f;
+  if (mean) {
+    const int64_t r = row_csc[j];
+    const int64_t deg = rowptr[r + 1] - rowptr[r];
+    w = w / static_cast<float>(deg > 0 ? deg : 1);
+  }
+  out[j] = w;
+}
+
+__global__ void __launch_bounds__(kThreads)
+spmm_minmax_bw_kernel(const int64_t* __restrict__ col,
+                      const float* __restrict__ value,
+                      const float* __restrict__ mat,
+                      const float* __restrict__ grad,
+                      const int64_t* __restrict__ arg_out, int64_t MK, int64_t K,
+                      int64_t nnz, float* __restrict__ grad_value,
+                      float* __restrict__ grad_mat) {
+  const int64_t t = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (t >= MK) return;
+  const int64_t e = arg_out[t];
+  if (e == nnz) return;  // empty row sentinel
+  const int64_t k = t % K;
+  const float g = grad[t];
+  const int64_t c = col[e];
+  if (grad_value) atomicAdd(grad_value + e, mat[c * K + k] * g);
+  if (grad_mat) atomicAdd(grad_mat + c * K + k, (value ? value[e] : 1.f) * g);
+}
+
+template <int VEC, int LPR, int U>
+int launch_value_bw(const int64_t* rowptr, const int64_t* col, const float* mat,
+                    const float* grad, float* out, int64_t M, int64_t K,
+                    int mean, hipStream_t s) {
+  const int64_t gx = psa::ceil_div(M, kWaves);
+  PSA_REQUIRE(gx <= 0x7fffffff, "M too large for one launch");
+  hipLaunchKernelGGL((spmm_value_bw_kernel<VEC, LPR, U>),
+                     dim3(static_cast<unsigned>(gx)), dim3(kThreads), 0, s,
+                     rowptr, col, mat, grad, out, M, K, mean);
+  PSA_LAUNCH_CHECK();
+  return PSA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int psa_spmm_value_bw(int reduce, const int64_t* rowptr, const int64_t* col,
+                      const float* mat, const float* grad, int64_t M, int64_t K,
+                      int64_t nnz, float* out, psa_stream_t stream) {
+  PSA_REQUIRE(reduce == PSA_SUM || reduce == PSA_MEAN, "reduce must be sum or mean");
+  PSA_REQUIRE(M >= 0 && K >= 0 && nnz >= 0, "negative size");
+  if (nnz == 0) return PSA_OK;
+  PSA_REQUIRE(out != nullptr, "out is NULL");
+  hipStream_t s = psa::as_stream(stream);
+  if (M == 0 || K == 0) {
+    PSA_HIP(hipMemsetAsync(out, 0, sizeof(float) * nnz, s));
+    return PSA_OK;
+  }
+  PSA_REQUIRE(rowptr && col && mat && grad, "NULL pointer");
+  const int mean = reduce == PSA_MEAN;
+  const bool v4 = (K % 4 == 0) && psa::aligned(mat, 16) && psa::aligned(grad, 16);
+  if (v4) {
+    const int64_t q = K / 4;
+    if (q <= 4) return launch_value_bw<4, 4, 1>(rowptr, col, mat, grad, out, M, K, mean, s);
+    if (q <= 8) return launch_value_bw<4, 8, 1>(rowptr, col, mat, grad, out, M, K, mean, s);
+    if (q <= 16) return launch_value_bw<4, 16, 2>(rowptr, col, mat, grad, out, M, K, mean, s);
+    if (q <= 32) return launch_value_bw<4, 32, 4>(rowptr, col, mat, grad, out, M, K, mean, s);
+    return launch_value_bw<4, 64, 8>(rowptr, col, mat, grad, out, M, K, mean, s);
+  }
+  if (K <= 4) return launch_value_bw<1, 4, 1>(rowptr, col, mat, grad, out, M, K, mean, s);
+  if (K <= 16) return launch_value_bw<1, 16, 2>(rowptr, col, mat, grad, out, M, K, mean, s);
+  return launch_value_bw<1, 64, 8>(rowptr, col, mat, grad, out, M, K, mean, s);
+}
+
+int psa_transpose_weights(const float* value, const int64_t* csr2csc,
+                          const int64_t* row_csc, const int64_t* rowptr,
+                          int64_t nnz, int mean, float* out,
+                          psa_stream_t stream) {
+  PSA_REQUIRE(nnz >= 0, "negative size");
+  if (nnz == 0) return PSA_OK;
+  PSA_REQUIRE(out != nullptr, "out is NULL");
+  PSA_REQUIRE(value == nullptr || csr2csc != nullptr, "csr2csc needed with value");
+  PSA_REQUIRE(!mean || (row_csc && rowptr), "row_csc/rowptr needed for mean");
+  const int64_t blocks = psa::ceil_div(nnz, kThreads);
+  PSA_REQUIRE(blocks <= 0x7fffffff, "nnz too large for one launch");
+  hipLaunchKernelGGL(transpose_weights_kernel, dim3(static_cast<unsigned>(blocks)),
+                     dim3(kThreads), 0, psa::as_stream(stream), value, csr2csc,
+                     row_csc, rowptr, nnz, mean, out);
+  PSA_LAUNCH_CHECK();
+  return PSA_OK;
+}
+
+int psa_spmm_minmax_bw(const int64_t* col, const float* value, const float* mat,
+                       const float* grad, const int64_t* arg_out, int64_t M,
+                       int64_t N, int64_t K, int64_t nnz, float* grad_value,
+                       float* grad_mat, psa_stream_t stream) {
+  PSA_REQUIRE(M >= 0 && N >= 0 && K >= 0 && nnz >= 0, "negative size");
+  hipStream_t s = psa::as_stream(stream);
+  if (grad_value && nnz) PSA_HIP(hipMemsetAsync(grad_value, 0, sizeof(float) * nnz, s));
+  if (grad_mat && N * K) PSA_HIP(hipMemsetAsync(grad_mat, 0, sizeof(float) * N * K, s));
+  if (M * K == 0 || nnz == 0 || (!grad_value && !grad_mat)) return PSA_OK;
+  PSA_REQUIRE(col && grad && arg_out, "NULL pointer");
+  PSA_REQUIRE(!grad_value || mat, "mat needed for grad_value");
+  const int64_t blocks = psa::ceil_div(M * K, kThreads);
+  PSA_REQUIRE(blocks <= 0x7fffffff, "M*K too large for one launch");
+  hipLaunchKernelGGL(spmm_minmax_bw_kernel, dim3(static_cast<unsigned>(blocks)),
+                     dim3(kThreads), 0, s, col, value, mat, grad, arg_out, M * K,
+                     K, nnz, grad_value, grad_mat);
+  PSA_LAUNCH_CHECK();
+  return PSA_OK;
+}
+
+}  // extern "C"

@@ -44,6 +44,101 @@ invert_perm_kernel(const int64_t* __restrict__ perm, int64_t n,
   if (i < n) inv[perm[i]] = i;
 }
 
+// out[index[i]] += 1 (colcount, storage.py:414-418 scatter_add of ones).
+__global__ void __launch_bounds__(kThreads)
+bincount_kernel(const int64_t* __restrict__ index, int64_t n, int64_t size,
+                unsigned long long* __restrict__ out) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (i >= n) return;
+  const int64_t b = index[i];
+  if (b >= 0 && b < size) atomicAdd(out + b, 1ull);
+}
+
+// ---- counts -> pointer (exclusive scan with a trailing total) -------------
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kThreads * kScanItems;
+
+__device__ __forceinline__ int64_t wave_incl_scan(int64_t x, int lane) {
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int64_t o = __shfl_up(static_cast<long long>(x), off);
+    if (lane >= off) x += o;
+  }
+  return x;
+}
+
+__global__ void __launch_bounds__(kThreads)
+scan_block_sums_kernel(const int64_t* __restrict__ in, int64_t n,
+                       int64_t* __restrict__ block_sums) {
+  __shared__ int64_t wsum[kThreads / 64];
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kScanTile;
+  int64_t acc = 0;
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    const int64_t i = base + j * kThreads + threadIdx.x;
+    acc += i < n ? in[i] : 0;
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(static_cast<long long>(acc), off);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int64_t t = 0;
+    for (int w = 0; w < kThreads / 64; ++w) t += wsum[w];
+    block_sums[blockIdx.x] = t;
+  }
+}
+
+__global__ void __launch_bounds__(1024)
+scan_sums_kernel(int64_t* __restrict__ block_sums, int64_t nb) {
+  __shared__ int64_t wtot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t per = (nb + 1023) / 1024;
+  const int64_t b = tid * per;
+  const int64_t e = b + per < nb ? b + per : nb;
+  int64_t sum = 0;
+  for (int64_t i = b; i < e; ++i) sum += block_sums[i];
+  const int64_t incl = wave_incl_scan(sum, lane);
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  int64_t run = incl - sum;
+  for (int w = 0; w < wave; ++w) run += wtot[w];
+  for (int64_t i = b; i < e; ++i) {
+    const int64_t c = block_sums[i];
+    block_sums[i] = run;
+    run += c;
+  }
+}
+
+// ptr[0] = 0, ptr[i+1] = counts[0] + ... + counts[i]
+__global__ void __launch_bounds__(kThreads)
+scan_write_kernel(const int64_t* __restrict__ in, int64_t n,
+                  const int64_t* __restrict__ block_offsets,
+                  int64_t* __restrict__ ptr) {
+  __shared__ int64_t wsum[kThreads / 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t chunk = static_cast<int64_t>(blockIdx.x) * kScanTile + wave * (kScanItems * 64);
+  int64_t incl[kScanItems];
+  int64_t carry = 0;
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    const int64_t i = chunk + j * 64 + lane;
+    const int64_t x = i < n ? in[i] : 0;
+    incl[j] = wave_incl_scan(x, lane) + carry;
+    carry = __shfl(static_cast<long long>(incl[j]), 63);
+  }
+  if (lane == 0) wsum[wave] = carry;
+  __syncthreads();
+  int64_t base = block_offsets[blockIdx.x];
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+#pragma unroll
+  for (int j = 0; j < kScanItems; ++j) {
+    const int64_t i = chunk + j * 64 + lane;
+    if (i < n) ptr[i + 1] = base + incl[j];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) ptr[0] = 0;
+}
+
 template <typename T>
 int launch_gather(const void* src, const int64_t* perm, int64_t n,
                   int64_t row_bytes, void* out, hipStream_t s) {
@@ -90,6 +185,54 @@ int psa_gather_rows(const void* src, const int64_t* perm, int64_t n,
   if (row_bytes % 2 == 0 && psa::aligned(src, 2) && psa::aligned(out, 2))
     return launch_gather<uint16_t>(src, perm, n, row_bytes, out, s);
   return launch_gather<uint8_t>(src, perm, n, row_bytes, out, s);
+}
+
+int psa_bincount(const int64_t* index, int64_t n, int64_t size, int64_t* out,
+                 psa_stream_t stream) {
+  PSA_REQUIRE(n >= 0 && size >= 0, "negative size");
+  hipStream_t s = psa::as_stream(stream);
+  if (size > 0) {
+    PSA_REQUIRE(out != nullptr, "out is NULL");
+    PSA_HIP(hipMemsetAsync(out, 0, sizeof(int64_t) * size, s));
+  }
+  if (n == 0 || size == 0) return PSA_OK;
+  PSA_REQUIRE(index != nullptr, "index is NULL");
+  const int64_t blocks = psa::ceil_div(n, kThreads);
+  PSA_REQUIRE(blocks <= 0x7fffffff, "n too large for one launch");
+  hipLaunchKernelGGL(bincount_kernel, dim3(static_cast<unsigned>(blocks)),
+                     dim3(kThreads), 0, s, index, n, size,
+                     reinterpret_cast<unsigned long long*>(out));
+  PSA_LAUNCH_CHECK();
+  return PSA_OK;
+}
+
+size_t psa_count2ptr_workspace_bytes(int64_t n) {
+  return static_cast<size_t>(psa::ceil_div(n > 0 ? n : 1, kScanTile)) * sizeof(int64_t) + 256;
+}
+
+int psa_count2ptr(const int64_t* counts, int64_t n, int64_t* ptr_out,
+                  void* workspace, size_t workspace_bytes, psa_stream_t stream) {
+  PSA_REQUIRE(n >= 0, "negative size");
+  PSA_REQUIRE(ptr_out != nullptr, "ptr_out is NULL");
+  hipStream_t s = psa::as_stream(stream);
+  if (n == 0) {
+    PSA_HIP(hipMemsetAsync(ptr_out, 0, sizeof(int64_t), s));
+    return PSA_OK;
+  }
+  PSA_REQUIRE(counts != nullptr, "counts is NULL");
+  if (workspace == nullptr || workspace_bytes < psa_count2ptr_workspace_bytes(n)) {
+    psa::set_error("psa_count2ptr: workspace too small");
+    return PSA_ERR_WORKSPACE;
+  }
+  const int64_t nb = psa::ceil_div(n, kScanTile);
+  PSA_REQUIRE(nb <= 0x7fffffff, "n too large for one launch");
+  int64_t* sums = static_cast<int64_t*>(workspace);
+  const dim3 grid(static_cast<unsigned>(nb)), block(kThreads);
+  hipLaunchKernelGGL(scan_block_sums_kernel, grid, block, 0, s, counts, n, sums);
+  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, s, sums, nb);
+  hipLaunchKernelGGL(scan_write_kernel, grid, block, 0, s, counts, n, sums, ptr_out);
+  PSA_LAUNCH_CHECK();
+  return PSA_OK;
 }
 
 int psa_invert_permutation(const int64_t* perm, int64_t n, int64_t* inv,

@@ -1,0 +1,90 @@
+"""SpMM on the SparseTensor surface: spmm / matmul / `@`, with autograd.
+
+The reference lists these as "Support later" (README.md:47-50) and documents
+the functional form `spmm(index, value, m, n, matrix)` (README.md:267-306).
+Semantics and the backward formulas are upstream pytorch_sparse
+(torch_sparse/matmul.py): sum/mean differentiate wrt the dense operand with
+an SpMM over the CSC view and wrt the values with an SDDMM-shaped kernel;
+min/max route gradients through arg_out.  All compute is HIP
+(psa_spmm, psa_spmm_value_bw, psa_transpose_weights, psa_spmm_minmax_bw).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+from .coalesce import coalesce
+from .storage import SparseStorage
+from .tensor import SparseTensor
+
+
+class _SpMM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, value: Optional[torch.Tensor], mat: torch.Tensor,
+                storage: SparseStorage, reduce: str):
+        rowptr, col = storage.rowptr(), storage.col()
+        out, arg = ops._spmm(reduce, rowptr, col, value, mat)
+        ctx.storage, ctx.reduce = storage, reduce
+        ctx.save_for_backward(value, mat, arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):
+        value, mat, arg = ctx.saved_tensors
+        st, reduce = ctx.storage, ctx.reduce
+        need_value = value is not None and ctx.needs_input_grad[0]
+        need_mat = ctx.needs_input_grad[1]
+        grad_out = grad_out.contiguous()
+        grad_value = grad_mat = None
+        if reduce in ("min", "max"):
+            grad_value, grad_mat = ops.spmm_minmax_bw(st.col(), value, mat, grad_out, arg,
+                                                     want_value=need_value, want_mat=need_mat)
+        else:
+            mean = reduce == "mean"
+            if need_value:
+                grad_value = ops.spmm_value_bw(None, st.rowptr(), st.col(), mat, grad_out,
+                                               "mean" if mean else "sum")
+            if need_mat:
+                row_csc = st._row_in_csc_order()
+                w = None
+                if value is not None or mean:
+                    w = ops.transpose_weights(value, st.csr2csc(), row_csc, st.rowptr(), mean)
+                grad_mat = ops.spmm_sum(st.colptr(), row_csc, w, grad_out)
+        return grad_value, grad_mat, None, None
+
+
+def spmm_sparse(src: SparseTensor, other: torch.Tensor, reduce: str = "sum") -> torch.Tensor:
+    """out = reduce-SpMM(src, other) for a dense `other` [N, K] (fp32)."""
+    if reduce == "add":
+        reduce = "sum"
+    if reduce not in ("sum", "mean", "min", "max"):
+        raise ValueError(reduce)
+    if other.dim() != 2 or other.shape[0] != src.sparse_size(1):
+        raise ValueError(f"dense operand must be [{src.sparse_size(1)}, K]")
+    value = src.storage.value()
+    if value is not None and value.dim() != 1:
+        raise ValueError("spmm needs scalar edge values")
+    return _SpMM.apply(value, other, src.storage, reduce)
+
+
+def matmul(src: SparseTensor, other, reduce: str = "sum") -> torch.Tensor:
+    if isinstance(other, torch.Tensor):
+        return spmm_sparse(src, other, reduce)
+    raise NotImplementedError("sparse @ sparse (spspmm) is not part of this build (SURVEY.md §8(f) f-4)")
+
+
+def spmm(index: torch.Tensor, value: Optional[torch.Tensor], m: int, n: int,
+         matrix: torch.Tensor, reduce: str = "sum") -> torch.Tensor:
+    """README.md:269-285 functional form: (index, value) COO of an m x n matrix
+    times `matrix` [n, K].  Entries are sorted (duplicates added) first."""
+    index, value = coalesce(index, value, m, n, op="add")
+    src = SparseTensor(row=index[0].contiguous(), col=index[1].contiguous(), value=value,
+                       sparse_sizes=(m, n), is_sorted=True, trust_data=True)
+    return spmm_sparse(src, matrix, reduce)
+
+
+SparseTensor.spmm = lambda self, other, reduce="sum": spmm_sparse(self, other, reduce)
+SparseTensor.matmul = lambda self, other, reduce="sum": matmul(self, other, reduce)
+SparseTensor.__matmul__ = lambda self, other: matmul(self, other, "sum")

@@ -252,3 +252,113 @@ def unique_sorted(sorted_keys: torch.Tensor, N: int, want_ptr: bool = True,
         elif want_ptr:
             ptr.zero_()
     return count, ptr, row, col
+
+
+# ---------------------------------------------------------------------------
+# SpMM backward
+# ---------------------------------------------------------------------------
+
+def _f32(x: torch.Tensor, name: str) -> torch.Tensor:
+    _gpu(x, name)
+    if x.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32 (got {x.dtype})")
+    return x.contiguous()
+
+
+def spmm_value_bw(row, rowptr, col, mat, grad, reduce: str = "sum") -> torch.Tensor:
+    """Upstream spmm_value_bw(row, rowptr, col, mat, grad, reduce): gradient
+    wrt the nnz values for sum/mean.  `row` is accepted for signature parity
+    but not read (one wave per CSR row knows its row)."""
+    rowptr, col = _index(rowptr, "rowptr"), _index(col, "col")
+    mat, grad = _f32(mat, "mat"), _f32(grad, "grad")
+    if reduce not in ("sum", "add", "mean"):
+        raise ValueError("spmm_value_bw: reduce must be sum or mean")
+    M, K, nnz = rowptr.numel() - 1, mat.shape[1], col.numel()
+    if grad.shape != (M, K):
+        raise ValueError("grad must be [M, K]")
+    out = torch.empty(nnz, dtype=torch.float32, device=mat.device)
+    with torch.cuda.device(mat.device):
+        check(_lib.load().psa_spmm_value_bw(REDUCE_ID[reduce], _ptr(rowptr), _ptr(col), _ptr(mat),
+                                            _ptr(grad), M, K, nnz, _ptr(out), _stream()))
+    return out
+
+
+def transpose_weights(value, csr2csc, row_csc, rowptr, mean: bool) -> torch.Tensor:
+    """Edge weights in CSC order for gB = A^T gOut (value[csr2csc], scaled by
+    1/deg(row) for mean)."""
+    csr2csc = _index(csr2csc, "csr2csc")
+    nnz = csr2csc.numel()
+    if value is not None:
+        value = _f32(value, "value")
+    if mean:
+        row_csc, rowptr = _index(row_csc, "row_csc"), _index(rowptr, "rowptr")
+    out = torch.empty(nnz, dtype=torch.float32, device=csr2csc.device)
+    with torch.cuda.device(csr2csc.device):
+        check(_lib.load().psa_transpose_weights(_ptr(value), _ptr(csr2csc),
+                                                _ptr(row_csc) if mean else None,
+                                                _ptr(rowptr) if mean else None,
+                                                nnz, int(mean), _ptr(out), _stream()))
+    return out
+
+
+def spmm_minmax_bw(col, value, mat, grad, arg_out, want_value: bool = True, want_mat: bool = True):
+    """Backward of spmm_min / spmm_max through arg_out.  Returns
+    (grad_value | None, grad_mat | None)."""
+    col = _index(col, "col")
+    mat, grad = _f32(mat, "mat"), _f32(grad, "grad")
+    _gpu(arg_out, "arg_out")
+    arg_out = arg_out.contiguous()
+    if value is not None:
+        value = _f32(value, "value")
+    (N, K), M, nnz = mat.shape, grad.shape[0], col.numel()
+    gv = torch.empty(nnz, dtype=torch.float32, device=mat.device) if want_value else None
+    gm = torch.empty((N, K), dtype=torch.float32, device=mat.device) if want_mat else None
+    with torch.cuda.device(mat.device):
+        check(_lib.load().psa_spmm_minmax_bw(_ptr(col), _ptr(value), _ptr(mat), _ptr(grad),
+                                             _ptr(arg_out), M, N, K, nnz, _ptr(gv), _ptr(gm),
+                                             _stream()))
+    return gv, gm
+
+
+def bincount(index: torch.Tensor, size: int) -> torch.Tensor:
+    """int64[size] occurrence counts (colcount, storage.py:414-418)."""
+    index = _index(index, "index")
+    out = torch.empty(size, dtype=torch.int64, device=index.device)
+    with torch.cuda.device(index.device):
+        check(_lib.load().psa_bincount(_ptr(index), index.numel(), size, _ptr(out), _stream()))
+    return out
+
+
+def count2ptr(counts: torch.Tensor) -> torch.Tensor:
+    """[0, cumsum(counts)] as int64[n+1] (colptr, storage.py:397-398)."""
+    counts = _index(counts, "counts")
+    n = counts.numel()
+    out = torch.empty(n + 1, dtype=torch.int64, device=counts.device)
+    lib = _lib.load()
+    ws = _workspace(lib.psa_count2ptr_workspace_bytes(n), counts.device)
+    with torch.cuda.device(counts.device):
+        check(lib.psa_count2ptr(_ptr(counts), n, _ptr(out), _ptr(ws), ws.numel(), _stream()))
+    return out
+
+
+def scatter(src: torch.Tensor, index: torch.Tensor, dim_size: int, reduce: str = "sum") -> torch.Tensor:
+    """paddle_scatter.scatter(src, index, 0, None, dim_size, reduce) as called
+    by reduce.py:42 (reduction over sparse dim 0, index = col)."""
+    _gpu(src, "src")
+    index = _index(index, "index")
+    if src.dtype not in (torch.float32, torch.float64, torch.int32, torch.int64):
+        raise TypeError(f"scatter: unsupported dtype {src.dtype}")
+    src = src.contiguous()
+    if src.shape[0] != index.numel():
+        raise ValueError("src.shape[0] must equal index.numel()")
+    D = 1
+    for s in src.shape[1:]:
+        D *= s
+    out = torch.empty((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+    lib = _lib.load()
+    ws = _workspace(lib.psa_scatter_workspace_bytes(dim_size), src.device)
+    with torch.cuda.device(src.device):
+        check(lib.psa_scatter_reduce(REDUCE_ID[reduce], _DTYPE_ID[src.dtype], _ptr(src), _ptr(index),
+                                     index.numel(), D, dim_size, _ptr(out), _ptr(ws), ws.numel(),
+                                     _stream()))
+    return out

@@ -1,0 +1,77 @@
+"""sum / mean / min / max over a SparseTensor — paddle_sparse/reduce.py:12-93.
+
+dim=1 is a segmented reduction over CSR rows (reduce.py:50-51) and dim=0 a
+scatter by column (reduce.py:40-42); both run as HIP kernels.  dim=None and
+dim>1 reduce the dense value tensor with the framework's own reducers, as the
+reference does.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+from .tensor import SparseTensor
+
+_DENSE = {"sum": "sum", "add": "sum", "mean": "mean", "min": "amin", "max": "amax"}
+
+
+def _check(reduce: str) -> None:
+    if reduce not in _DENSE:
+        raise ValueError(reduce)
+
+
+def reduction(src: SparseTensor, dim: Optional[int] = None, reduce: str = "sum") -> torch.Tensor:
+    _check(reduce)
+    value = src.storage.value()
+    additive = reduce in ("sum", "add")
+
+    if dim is None:
+        if value is not None:
+            return getattr(value, {"sum": "sum", "add": "sum", "mean": "mean", "min": "min", "max": "max"}[reduce])()
+        return torch.full([], src.nnz() if additive else 1, dtype=src.dtype(), device=src.device())
+
+    if dim < 0:
+        dim = src.dim() + dim
+
+    if dim == 0:
+        if value is not None:
+            return ops.scatter(value, src.storage.col(), src.size(1), reduce)
+        if additive:
+            return src.storage.colcount().to(src.dtype())
+        return torch.ones(src.size(1), dtype=src.dtype(), device=src.device())
+    if dim == 1:
+        if value is not None:
+            return ops.segment_csr(value, src.storage.rowptr(), reduce)
+        if additive:
+            return src.storage.rowcount().to(src.dtype())
+        return torch.ones(src.size(0), dtype=src.dtype(), device=src.device())
+    if value is not None:
+        # reduce.py:59-69; the reference indexes `[0]` into paddle's min/max
+        # result (a torch idiom that does not hold for Paddle) — the intended
+        # value-wise reduction over the dense dim is what is returned here.
+        return getattr(value, _DENSE[reduce])(dim - 1)
+    raise ValueError
+
+
+def sum(src: SparseTensor, dim: Optional[int] = None) -> torch.Tensor:
+    return reduction(src, dim, reduce="sum")
+
+
+def mean(src: SparseTensor, dim: Optional[int] = None) -> torch.Tensor:
+    return reduction(src, dim, reduce="mean")
+
+
+def min(src: SparseTensor, dim: Optional[int] = None) -> torch.Tensor:
+    return reduction(src, dim, reduce="min")
+
+
+def max(src: SparseTensor, dim: Optional[int] = None) -> torch.Tensor:
+    return reduction(src, dim, reduce="max")
+
+
+SparseTensor.sum = lambda self, dim=None: sum(self, dim)
+SparseTensor.mean = lambda self, dim=None: mean(self, dim)
+SparseTensor.min = lambda self, dim=None: min(self, dim)
+SparseTensor.max = lambda self, dim=None: max(self, dim)

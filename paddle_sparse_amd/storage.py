@@ -1,0 +1,390 @@
+"""SparseStorage — COO/CSR/CSC state with lazy caches, on MI355X HBM.
+
+Same constructor, accessors and cache semantics as the reference class
+(paddle_sparse/storage.py:31-776); the attribute names (`_row`, `_rowptr`,
+`_col`, `_value`, `_rowcount`, `_colptr`, `_colcount`, `_csr2csc`, `_csc2csr`)
+are kept because the reference's tests read them.  Every nnz-sized pass on
+the hot path goes to a HIP kernel through paddle_sparse_amd.ops:
+
+  ctor sort (storage.py:158-171) ... make_keys + index_sort + gather_rows
+  row()/rowptr() (195-222) ......... ptr2ind / ind2ptr
+  colcount()/colptr() (386-420) .... bincount / count2ptr (or ind2ptr)
+  csr2csc()/csc2csr() (425-447) .... make_keys + index_sort / invert_permutation
+  is_coalesced()/coalesce() (449-486) unique_sorted + segment_csr
+
+Tensors are torch tensors; torch supplies allocation, views and O(1) glue
+(`rowptr[1:] - rowptr[:-1]`), as Paddle does in the reference.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Callable, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .utils import index_sort, is_pinned_tensor
+
+layouts: List[str] = ["coo", "csr", "csc"]
+
+_CACHES = ("rowcount", "colptr", "colcount", "csr2csc", "csc2csr")
+_FIELDS = ("row", "rowptr", "col", "value") + _CACHES
+
+
+def get_layout(layout: Optional[str] = None) -> str:
+    if layout is None:
+        layout = "coo"
+        warnings.warn('`layout` argument unset, using default layout "coo". '
+                      "This may lead to unexpected behaviour.")
+    assert layout in layouts
+    return layout
+
+
+def _check_index(t: torch.Tensor, like: torch.Tensor, numel: Optional[int], what: str) -> torch.Tensor:
+    assert t.dtype == torch.int64, f"{what} must be int64"
+    assert t.device == like.device, f"{what} must live on {like.device}"
+    assert t.dim() == 1, f"{what} must be 1-D"
+    if numel is not None:
+        assert t.numel() == numel, f"{what} has {t.numel()} entries, expected {numel}"
+    return t.contiguous()
+
+
+class SparseStorage(object):
+    def __init__(
+        self,
+        row: Optional[torch.Tensor] = None,
+        rowptr: Optional[torch.Tensor] = None,
+        col: Optional[torch.Tensor] = None,
+        value: Optional[torch.Tensor] = None,
+        sparse_sizes: Optional[Tuple[Optional[int], Optional[int]]] = None,
+        rowcount: Optional[torch.Tensor] = None,
+        colptr: Optional[torch.Tensor] = None,
+        colcount: Optional[torch.Tensor] = None,
+        csr2csc: Optional[torch.Tensor] = None,
+        csc2csr: Optional[torch.Tensor] = None,
+        is_sorted: bool = False,
+        trust_data: bool = False,
+    ):
+        assert row is not None or rowptr is not None
+        assert col is not None
+        col = _check_index(col, col, None, "col")
+        nnz = col.numel()
+
+        # storage.py:65-91 — infer (M, N) when not given; validate otherwise
+        given_m = sparse_sizes[0] if sparse_sizes is not None else None
+        given_n = sparse_sizes[1] if sparse_sizes is not None else None
+        if given_m is None:
+            if rowptr is not None:
+                M = rowptr.numel() - 1
+            else:
+                M = int(row.max()) + 1 if row.numel() > 0 else 0
+        else:
+            M = int(given_m)
+            if rowptr is not None:
+                assert rowptr.numel() - 1 == M
+            elif row.numel() > 0:
+                assert trust_data or int(row.max()) < M
+        if given_n is None:
+            N = int(col.max()) + 1 if nnz > 0 else 0
+        else:
+            N = int(given_n)
+            if nnz > 0:
+                assert trust_data or int(col.max()) < N
+
+        if row is not None:
+            row = _check_index(row, col, nnz, "row")
+        if rowptr is not None:
+            rowptr = _check_index(rowptr, col, M + 1, "rowptr")
+        if value is not None:
+            assert value.device == col.device
+            assert value.shape[0] == nnz
+            value = value.contiguous()
+        if rowcount is not None:
+            rowcount = _check_index(rowcount, col, M, "rowcount")
+        if colptr is not None:
+            colptr = _check_index(colptr, col, N + 1, "colptr")
+        if colcount is not None:
+            colcount = _check_index(colcount, col, N, "colcount")
+        if csr2csc is not None:
+            csr2csc = _check_index(csr2csc, col, nnz, "csr2csc")
+        if csc2csr is not None:
+            csc2csr = _check_index(csc2csr, col, nnz, "csc2csr")
+
+        self._row, self._rowptr, self._col, self._value = row, rowptr, col, value
+        self._sparse_sizes: Tuple[int, int] = (M, N)
+        self._rowcount, self._colptr, self._colcount = rowcount, colptr, colcount
+        self._csr2csc, self._csc2csr = csr2csc, csc2csr
+        self._row_csc: Optional[torch.Tensor] = None  # row[csr2csc], private
+
+        # storage.py:158-171 — sort by (row, col) unless told it is sorted
+        if not is_sorted and nnz > 0:
+            keys, unsorted = ops.make_keys(self.row(), self._col, N, check_sorted=True)
+            if int(unsorted.item()):
+                _, perm = index_sort(keys, M * N)
+                self._row = ops.gather_rows(self.row(), perm)
+                self._col = ops.gather_rows(self._col, perm)
+                if value is not None:
+                    self._value = ops.gather_rows(value, perm)
+                self._csr2csc = None
+                self._csc2csr = None
+
+    @classmethod
+    def empty(cls):
+        z = torch.empty(0, dtype=torch.int64)
+        return cls(row=z, col=z.clone(), sparse_sizes=(0, 0), is_sorted=True, trust_data=True)
+
+    # ---- canonical state --------------------------------------------------
+    def has_row(self) -> bool:
+        return self._row is not None
+
+    def row(self) -> torch.Tensor:
+        if self._row is None:
+            if self._rowptr is None:
+                raise ValueError
+            self._row = ops.ptr2ind(self._rowptr, self._col.numel())  # storage.py:202
+        return self._row
+
+    def has_rowptr(self) -> bool:
+        return self._rowptr is not None
+
+    def rowptr(self) -> torch.Tensor:
+        if self._rowptr is None:
+            if self._row is None:
+                raise ValueError
+            self._rowptr = ops.ind2ptr(self._row, self._sparse_sizes[0])  # storage.py:218
+        return self._rowptr
+
+    def col(self) -> torch.Tensor:
+        return self._col
+
+    def has_value(self) -> bool:
+        return self._value is not None
+
+    def value(self) -> Optional[torch.Tensor]:
+        return self._value
+
+    def _prepare_value(self, value, layout):
+        if value is not None:
+            if get_layout(layout) == "csc":  # storage.py:246-247
+                value = ops.gather_rows(value, self.csc2csr())
+            value = value.contiguous()
+            assert value.device == self._col.device
+            assert value.shape[0] == self._col.numel()
+        return value
+
+    def set_value_(self, value: Optional[torch.Tensor], layout: Optional[str] = None):
+        self._value = self._prepare_value(value, layout)
+        return self
+
+    def set_value(self, value: Optional[torch.Tensor], layout: Optional[str] = None):
+        return self._replace(value=self._prepare_value(value, layout))
+
+    def sparse_sizes(self) -> Tuple[int, int]:
+        return self._sparse_sizes
+
+    def sparse_size(self, dim: int) -> int:
+        return self._sparse_sizes[dim]
+
+    def sparse_resize(self, sparse_sizes: Tuple[int, int]):
+        """storage.py:281-331: grow/shrink the pointer and count caches."""
+        assert len(sparse_sizes) == 2
+        nnz = self._col.numel()
+
+        def fit(ptr, cnt, diff):
+            if diff > 0:
+                if ptr is not None:
+                    ptr = torch.cat([ptr, ptr.new_full((diff,), nnz)])
+                if cnt is not None:
+                    cnt = torch.cat([cnt, cnt.new_zeros(diff)])
+            elif diff < 0:
+                ptr = ptr[:diff] if ptr is not None else None
+                cnt = cnt[:diff] if cnt is not None else None
+            return ptr, cnt
+
+        rowptr, rowcount = fit(self._rowptr, self._rowcount, sparse_sizes[0] - self._sparse_sizes[0])
+        colptr, colcount = fit(self._colptr, self._colcount, sparse_sizes[1] - self._sparse_sizes[1])
+        return self._replace(rowptr=rowptr, rowcount=rowcount, colptr=colptr,
+                             colcount=colcount, sparse_sizes=tuple(sparse_sizes))
+
+    def sparse_reshape(self, num_rows: int, num_cols: int):
+        """storage.py:333-371: re-split the linear index row*N + col."""
+        assert num_rows > 0 or num_rows == -1
+        assert num_cols > 0 or num_cols == -1
+        assert num_rows > 0 or num_cols > 0
+        total = self._sparse_sizes[0] * self._sparse_sizes[1]
+        if num_rows == -1:
+            num_rows = total // num_cols
+        if num_cols == -1:
+            num_cols = total // num_rows
+        assert num_rows * num_cols == total
+        idx = self._sparse_sizes[1] * self.row() + self._col
+        row = torch.div(idx, num_cols, rounding_mode="floor")
+        col = idx - row * num_cols
+        return SparseStorage(row=row, col=col, value=self._value,
+                             sparse_sizes=(num_rows, num_cols), is_sorted=True, trust_data=True)
+
+    # ---- lazy caches --------------------------------------------------------
+    def has_rowcount(self) -> bool:
+        return self._rowcount is not None
+
+    def rowcount(self) -> torch.Tensor:
+        if self._rowcount is None:
+            p = self.rowptr()
+            self._rowcount = p[1:] - p[:-1]  # storage.py:378-379
+        return self._rowcount
+
+    def has_colptr(self) -> bool:
+        return self._colptr is not None
+
+    def colptr(self) -> torch.Tensor:
+        if self._colptr is None:
+            if self._csr2csc is not None:  # storage.py:391-395
+                self._colptr = ops.ind2ptr(ops.gather_rows(self._col, self._csr2csc),
+                                           self._sparse_sizes[1])
+            else:  # storage.py:397-398
+                self._colptr = ops.count2ptr(self.colcount())
+        return self._colptr
+
+    def has_colcount(self) -> bool:
+        return self._colcount is not None
+
+    def colcount(self) -> torch.Tensor:
+        if self._colcount is None:
+            if self._colptr is not None:
+                self._colcount = self._colptr[1:] - self._colptr[:-1]
+            else:  # storage.py:414-418 scatter_add(ones, col)
+                self._colcount = ops.bincount(self._col, self._sparse_sizes[1])
+        return self._colcount
+
+    def has_csr2csc(self) -> bool:
+        return self._csr2csc is not None
+
+    def csr2csc(self) -> torch.Tensor:
+        if self._csr2csc is None:  # storage.py:430-432: sort by (col, row)
+            M, N = self._sparse_sizes
+            keys, _ = ops.make_keys(self._col, self.row(), M)
+            _, self._csr2csc = index_sort(keys, M * N)
+        return self._csr2csc
+
+    def has_csc2csr(self) -> bool:
+        return self._csc2csr is not None
+
+    def csc2csr(self) -> torch.Tensor:
+        if self._csc2csr is None:
+            # storage.py:444-445 sorts the permutation; its inverse is the
+            # same array and costs one scatter pass.
+            self._csc2csr = ops.invert_permutation(self.csr2csc())
+        return self._csc2csr
+
+    def _row_in_csc_order(self) -> torch.Tensor:
+        """row[csr2csc] (tensor.py:254-257), memoised for repeated backward."""
+        if self._row_csc is None:
+            self._row_csc = ops.gather_rows(self.row(), self.csr2csc())
+        return self._row_csc
+
+    # ---- coalesce -------------------------------------------------------------
+    def is_coalesced(self) -> bool:
+        """storage.py:449-452: keys strictly increasing."""
+        nnz = self._col.numel()
+        if nnz == 0:
+            return True
+        keys, unsorted = ops.make_keys(self.row(), self._col, self._sparse_sizes[1], check_sorted=True)
+        count, _, _, _ = ops.unique_sorted(keys, 1, want_ptr=False, want_rowcol=False)
+        return count == nnz and not int(unsorted.item())
+
+    def coalesce(self, reduce: str = "add"):
+        """storage.py:454-486."""
+        nnz = self._col.numel()
+        if nnz == 0:
+            return self
+        N = self._sparse_sizes[1]
+        keys, _ = ops.make_keys(self.row(), self._col, N)
+        count, ptr, row, col = ops.unique_sorted(keys, N)
+        if count == nnz:  # already coalesced (storage.py:459)
+            return self
+        value = self._value
+        if value is not None:
+            value = ops.segment_csr(value, ptr, reduce)
+        return SparseStorage(row=row, col=col, value=value, sparse_sizes=self._sparse_sizes,
+                             is_sorted=True, trust_data=True)
+
+    def fill_cache_(self):
+        self.row()
+        self.rowptr()
+        self.rowcount()
+        self.colptr()
+        self.colcount()
+        self.csr2csc()
+        self.csc2csr()
+        return self
+
+    def clear_cache_(self):
+        for k in _CACHES:
+            setattr(self, "_" + k, None)
+        self._row_csc = None
+        return self
+
+    def cached_keys(self) -> List[str]:
+        return [k for k in _CACHES if getattr(self, "_" + k) is not None]
+
+    def num_cached_keys(self) -> int:
+        return len(self.cached_keys())
+
+    # ---- copies / moves ----------------------------------------------------------
+    def _replace(self, **kw):
+        """New storage sharing every field not named in kw (no re-sort)."""
+        args = {k: getattr(self, "_" + k) for k in _FIELDS}
+        args["sparse_sizes"] = self._sparse_sizes
+        args.update(kw)
+        return SparseStorage(is_sorted=True, trust_data=True, **args)
+
+    def _map(self, fn: Callable[[torch.Tensor], torch.Tensor]):
+        return self._replace(**{k: (None if getattr(self, "_" + k) is None else fn(getattr(self, "_" + k)))
+                                for k in _FIELDS})
+
+    def copy(self):
+        return self._replace()
+
+    def clone(self):
+        return self._map(lambda t: t.clone())
+
+    def type(self, dtype: torch.dtype, non_blocking: bool = False):
+        value = self._value
+        if value is None or dtype == value.dtype:
+            return self
+        return self.set_value(value.to(dtype=dtype, non_blocking=non_blocking), layout="coo")
+
+    def type_as(self, tensor: torch.Tensor, non_blocking: bool = False):
+        return self.type(dtype=tensor.dtype, non_blocking=non_blocking)
+
+    def to_device(self, device, non_blocking: bool = False):
+        device = torch.device(device)
+        if device == self._col.device:
+            return self
+        return self._map(lambda t: t.to(device, non_blocking=non_blocking))
+
+    def device_as(self, tensor: torch.Tensor, non_blocking: bool = False):
+        return self.to_device(device=tensor.device, non_blocking=non_blocking)
+
+    def cuda(self):
+        if self._col.is_cuda:
+            return self
+        return self._map(lambda t: t.cuda())
+
+    def pin_memory(self):
+        return self._map(lambda t: t.pin_memory())
+
+    def is_pinned(self) -> bool:
+        return all(is_pinned_tensor(getattr(self, "_" + k)) for k in _FIELDS
+                   if getattr(self, "_" + k) is not None)
+
+    def share_memory_(self):
+        for k in _FIELDS:
+            t = getattr(self, "_" + k)
+            if t is not None and not t.is_cuda:
+                t.share_memory_()
+        return self
+
+    def is_shared(self) -> bool:
+        return all(getattr(self, "_" + k).is_shared() for k in _FIELDS
+                   if getattr(self, "_" + k) is not None)

@@ -1,0 +1,45 @@
+"""t() and transpose() — paddle_sparse/transpose.py:9-65."""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from .coalesce import _coalesce_sorted_stream
+from .storage import SparseStorage
+from .tensor import SparseTensor
+
+
+def t(src: SparseTensor) -> SparseTensor:
+    """transpose.py:9-33: permute by csr2csc and swap the row/col caches."""
+    st = src.storage
+    csr2csc = st.csr2csc()
+    row, col, value = src.coo()
+    if value is not None:
+        value = ops.gather_rows(value, csr2csc)
+    M, N = st.sparse_sizes()
+    storage = SparseStorage(
+        row=ops.gather_rows(col, csr2csc),
+        rowptr=st._colptr,
+        col=st._row_in_csc_order(),
+        value=value,
+        sparse_sizes=(N, M),
+        rowcount=st._colcount,
+        colptr=st._rowptr,
+        colcount=st._rowcount,
+        csr2csc=st._csc2csr,
+        csc2csr=csr2csc,
+        is_sorted=True,
+    )
+    return src.from_storage(storage)
+
+
+SparseTensor.t = lambda self: t(self)
+
+
+def transpose(index, value, m, n, coalesced=True):
+    """transpose.py:41-65: swap rows and columns; with coalesced=True the
+    result is sorted and duplicate-free (duplicates added)."""
+    row, col = index[1].contiguous(), index[0].contiguous()
+    if coalesced:
+        row, col, value = _coalesce_sorted_stream(row, col, value, n, m, "add")
+    return torch.stack([row, col], dim=0), value

@@ -28,9 +28,13 @@ def kats():
 @pytest.fixture(scope="session", autouse=True)
 def _built():
     """Make sure the oracle (gcc) and the HIP core (hipcc) are built."""
-    import oracle
-    from paddle_sparse_amd import build as hip_build
+    import importlib.util
 
+    import oracle
+
+    spec = importlib.util.spec_from_file_location("psa_build", ROOT / "paddle_sparse_amd" / "build.py")
+    hip_build = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hip_build)
     oracle.build()
     hip_build.build()
     yield

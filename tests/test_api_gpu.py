@@ -1,0 +1,340 @@
+"""GPU parity of the host mirror (SparseStorage / SparseTensor / coalesce /
+transpose / reduce / spmm) against the reference's own known-answer tests
+(tests/golden/reference_kats.json) and the numpy oracle on seeded inputs.
+Mirrors test/test_storage.py, test_coalesce.py, test_transpose.py,
+test_reduce.py of the reference; dtypes as paddle_sparse/testing.py:12."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import storage_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float16, torch.float32, torch.float64, torch.int32, torch.int64, torch.bfloat16]
+DEV = "cuda"
+
+
+def tensor(x, dtype):
+    return None if x is None else torch.tensor(x, dtype=dtype, device=DEV)
+
+
+def idx(x):
+    return torch.tensor(x, dtype=torch.int64, device=DEV)
+
+
+# ---- test/test_storage.py ---------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_storage(kats, dtype):
+    from paddle_sparse_amd import SparseStorage
+
+    k = kats["storage_sort"]
+    st = SparseStorage(row=idx(k["row"]), col=idx(k["col"]), value=tensor(k["value"], dtype))
+    assert st.row().tolist() == k["out_row"]
+    assert st.col().tolist() == k["out_col"]
+    assert torch.equal(st.value(), tensor(k["out_value"], dtype))
+    assert st.sparse_sizes() == tuple(k["sparse_sizes"])
+
+
+def test_caching(kats):
+    from paddle_sparse_amd import SparseStorage
+
+    k = kats["storage_caching"]
+    row, col = idx(k["row"]), idx(k["col"])
+    st = SparseStorage(row=row, col=col)
+    assert st._row.tolist() == k["row"] and st._col.tolist() == k["col"] and st._value is None
+    assert st._rowcount is None and st._rowptr is None and st._colcount is None
+    assert st._colptr is None and st._csr2csc is None and st.num_cached_keys() == 0
+
+    st.fill_cache_()
+    for name in ("rowcount", "rowptr", "colcount", "colptr", "csr2csc", "csc2csr"):
+        assert getattr(st, "_" + name).tolist() == k[name], name
+    assert st.num_cached_keys() == 5
+
+    st = SparseStorage(row=row, rowptr=st._rowptr, col=col, value=st._value,
+                       sparse_sizes=st._sparse_sizes, rowcount=st._rowcount, colptr=st._colptr,
+                       colcount=st._colcount, csr2csc=st._csr2csc, csc2csr=st._csc2csr)
+    for name in ("rowcount", "rowptr", "colcount", "colptr", "csr2csc", "csc2csr"):
+        assert getattr(st, "_" + name).tolist() == k[name], name
+    assert st.num_cached_keys() == 5
+
+    st.clear_cache_()
+    assert st._rowcount is None and st._rowptr is not None and st._colcount is None
+    assert st._colptr is None and st._csr2csc is None and st.num_cached_keys() == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_utility(kats, dtype):
+    from paddle_sparse_amd import SparseStorage
+
+    k = kats["storage_set_value_csc"]
+    value = tensor(k["value"], dtype)
+    st = SparseStorage(row=idx(k["row"]), col=idx(k["col"]), value=value)
+    assert st.has_value()
+    st.set_value_(value, layout="csc")
+    assert torch.equal(st.value(), tensor(k["csc_value"], dtype))
+    st.set_value_(value, layout="coo")
+    assert torch.equal(st.value(), tensor(k["coo_value"], dtype))
+    st = st.set_value(value, layout="csc")
+    assert torch.equal(st.value(), tensor(k["csc_value"], dtype))
+    st = st.set_value(value, layout="coo")
+    assert torch.equal(st.value(), tensor(k["coo_value"], dtype))
+
+    st = st.sparse_resize((3, 3))
+    assert st.sparse_sizes() == (3, 3)
+    new = st.copy()
+    assert new is not st and new.col().data_ptr() == st.col().data_ptr()
+    new = st.clone()
+    assert new is not st and new.col().data_ptr() != st.col().data_ptr()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_storage_coalesce(kats, dtype):
+    from paddle_sparse_amd import SparseStorage
+
+    k = kats["storage_coalesce"]
+    st = SparseStorage(row=idx(k["row"]), col=idx(k["col"]), value=tensor(k["value"], dtype))
+    assert st.row().tolist() == k["row"] and st.col().tolist() == k["col"]
+    assert not st.is_coalesced()
+    st = st.coalesce()
+    assert st.is_coalesced()
+    assert st.row().tolist() == k["out_row"] and st.col().tolist() == k["out_col"]
+    assert torch.equal(st.value(), tensor(k["out_value"], dtype))
+
+
+def test_sparse_reshape(kats):
+    from paddle_sparse_amd import SparseStorage
+
+    k = kats["storage_reshape"]
+    st = SparseStorage(row=idx(k["row"]), col=idx(k["col"]))
+    for step in k["steps"]:
+        st = st.sparse_reshape(step["num_rows"], step["num_cols"])
+        assert st.sparse_sizes() == tuple(step["sizes"])
+        assert st.row().tolist() == step["row"] and st.col().tolist() == step["col"]
+
+
+def test_resize_keeps_pointer_caches_consistent():
+    from paddle_sparse_amd import SparseStorage
+
+    st = SparseStorage(row=idx([0, 0, 1, 1]), col=idx([0, 1, 0, 1])).fill_cache_()
+    big = st.sparse_resize((4, 3))
+    assert big.rowptr().tolist() == [0, 2, 4, 4, 4] and big.colptr().tolist() == [0, 2, 4, 4]
+    assert big.rowcount().tolist() == [2, 2, 0, 0] and big.colcount().tolist() == [2, 2, 0]
+
+
+# ---- test/test_coalesce.py ----------------------------------------------------
+def test_coalesce(kats):
+    from paddle_sparse_amd import coalesce
+
+    k = kats["coalesce"]
+    index = torch.stack([idx(k["row"]), idx(k["col"])])
+    out_index, _ = coalesce(index, None, m=k["m"], n=k["n"])
+    assert out_index.tolist() == k["out_index"]
+    for dtype in DTYPES:
+        out_index, value = coalesce(index, tensor(k["value"], dtype), m=k["m"], n=k["n"])
+        assert out_index.tolist() == k["out_index"]
+        assert torch.equal(value, tensor(k["out_add"], dtype))
+        out_index, value = coalesce(index, tensor(k["value"], dtype), m=k["m"], n=k["n"], op="max")
+        assert out_index.tolist() == k["out_index"]
+        assert torch.equal(value, tensor(k["out_max"], dtype))
+
+
+@pytest.mark.parametrize("op", ["add", "mean", "min", "max"])
+@pytest.mark.parametrize("shape", [(), (2,)])
+def test_coalesce_config1_vs_oracle(op, shape):
+    """BASELINE config 1: 10k-edge random COO (duplicates), fp32."""
+    from paddle_sparse_amd import coalesce
+
+    rng = np.random.default_rng(0)
+    M = N = 1000
+    row, col = rng.integers(0, M, 10000), rng.integers(0, N, 10000)
+    val = rng.standard_normal((10000,) + shape).astype(np.float32)
+    ref_idx, ref_val = so.coalesce(np.stack([row, col]), val, M, N, op)
+    got_idx, got_val = coalesce(torch.stack([idx(row), idx(col)]), torch.from_numpy(val).cuda(), M, N, op)
+    assert np.array_equal(got_idx.cpu().numpy(), ref_idx)  # bit-exact indices
+    np.testing.assert_allclose(got_val.cpu().numpy(), ref_val, rtol=1e-5, atol=1e-6)
+
+
+def test_coalesce_already_sorted_and_empty():
+    from paddle_sparse_amd import coalesce
+
+    index = torch.stack([idx([0, 0, 1]), idx([0, 2, 1])])
+    value = tensor([1.0, 2.0, 3.0], torch.float32)
+    out_index, out_value = coalesce(index, value, 2, 3)
+    assert out_index.tolist() == [[0, 0, 1], [0, 2, 1]] and out_value.tolist() == [1, 2, 3]
+    empty = torch.empty((2, 0), dtype=torch.int64, device=DEV)
+    out_index, out_value = coalesce(empty, torch.empty(0, device=DEV), 4, 4)
+    assert out_index.shape == (2, 0) and out_value.numel() == 0
+
+
+# ---- test/test_transpose.py -----------------------------------------------------
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_transpose(kats, dtype):
+    from paddle_sparse_amd import transpose
+
+    for name in ("transpose_matrix", "transpose"):
+        k = kats[name]
+        index = torch.stack([idx(k["row"]), idx(k["col"])])
+        out_index, value = transpose(index, tensor(k["value"], dtype), m=k["m"], n=k["n"])
+        assert out_index.tolist() == k["out_index"]
+        assert torch.equal(value, tensor(k["out_value"], dtype))
+
+
+def test_t_matches_oracle_and_swaps_caches():
+    from paddle_sparse_amd import SparseTensor
+
+    rng = np.random.default_rng(3)
+    M, N, nnz = 300, 200, 4000
+    key = np.unique(rng.integers(0, M * N, nnz))
+    row, col = key // N, key % N
+    val = rng.standard_normal(key.size).astype(np.float32)
+    a = SparseTensor(row=idx(row), col=idx(col), value=torch.from_numpy(val).cuda(), sparse_sizes=(M, N))
+    a.fill_cache_()
+    at = a.t()
+    ref = so.t(so.Storage(row, col, val, (M, N)))
+    r, c, v = at.coo()
+    assert np.array_equal(r.cpu().numpy(), ref.row) and np.array_equal(c.cpu().numpy(), ref.col)
+    assert np.array_equal(v.cpu().numpy(), ref.value)
+    assert at.sparse_sizes() == (N, M)
+    assert torch.equal(at.storage.rowptr(), a.storage.colptr())
+    assert torch.equal(at.storage._colptr, a.storage.rowptr())
+    assert torch.equal(at.storage._csr2csc, a.storage.csc2csr())
+    assert torch.equal(at.t().storage.col(), a.storage.col())
+
+
+# ---- test/test_reduce.py (+ dim 0/1, untested upstream) -----------------------------
+def test_reduce_dim_none(kats):
+    from paddle_sparse_amd import SparseTensor
+
+    k = kats["reduce_dim_none"]
+    value = tensor(k["value"], torch.float32)
+    t = SparseTensor(row=idx(k["row"]), col=idx(k["col"]), value=value)
+    assert t.sum() == k["sum"] and t.mean() == k["mean"] and t.max() == k["max"] and t.min() == k["min"]
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max"])
+@pytest.mark.parametrize("npdtype,tdtype", [(np.float32, torch.float32), (np.int64, torch.int64)])
+def test_reduce_dim0_dim1_vs_oracle(reduce, npdtype, tdtype):
+    from paddle_sparse_amd import SparseTensor
+
+    rng = np.random.default_rng(5)
+    M, N, nnz = 500, 400, 6000
+    key = np.unique(rng.integers(0, M * N, nnz))
+    row, col = key // N, key % N
+    val = rng.integers(-9, 9, (key.size, 3)).astype(npdtype)
+    t = SparseTensor(row=idx(row), col=idx(col), value=torch.from_numpy(val).cuda(), sparse_sizes=(M, N))
+    st = so.Storage(row, col, val, (M, N))
+    for dim in (0, 1, -2, -3):
+        got = getattr(t, reduce)(dim).cpu().numpy()
+        ref = so.reduction(st, dim % 3 if dim < 0 else dim, reduce)
+        if npdtype is np.float32 and reduce == "mean":
+            np.testing.assert_allclose(got, ref, rtol=1e-6)
+        else:
+            assert np.array_equal(got, ref), (reduce, dim)
+    # value-less shortcuts (reduce.py:43-58)
+    t0 = SparseTensor(row=idx(row), col=idx(col), sparse_sizes=(M, N))
+    st0 = so.Storage(row, col, None, (M, N))
+    for dim in (None, 0, 1):
+        assert np.array_equal(np.asarray(getattr(t0, reduce)(dim).cpu()), np.asarray(so.reduction(st0, dim, reduce)))
+
+
+# ---- tensor-level pieces on the path ---------------------------------------------------
+def test_to_symmetric_kat():
+    """test/test_tensor.py:75-88."""
+    from paddle_sparse_amd import SparseTensor
+
+    row, col = idx([0, 0, 0, 1, 1]), idx([0, 1, 2, 0, 2])
+    value = torch.arange(1, 6, dtype=torch.float32, device=DEV)
+    mat = SparseTensor(row=row, col=col, value=value)
+    assert not mat.is_symmetric()
+    mat = mat.to_symmetric()
+    assert mat.is_symmetric()
+    assert mat.to_dense().tolist() == [[2, 6, 3], [6, 0, 5], [3, 5, 0]]
+
+
+def test_csr_csc_coo_and_scipy_roundtrip():
+    from paddle_sparse_amd import SparseTensor
+
+    rng = np.random.default_rng(9)
+    M, N = 60, 45
+    key = np.unique(rng.integers(0, M * N, 700))
+    row, col = key // N, key % N
+    val = rng.standard_normal(key.size).astype(np.float32)
+    t = SparseTensor(row=idx(row), col=idx(col), value=torch.from_numpy(val).cuda(), sparse_sizes=(M, N))
+    for layout in ("coo", "csr", "csc"):
+        sp = t.to_scipy(layout)
+        assert np.array_equal(sp.toarray(), t.to_dense().cpu().numpy())
+    back = SparseTensor.from_scipy(t.to_scipy("csc"), device=DEV)
+    assert back == t
+    colptr, r_csc, v_csc = t.csc()
+    ref = so.Storage(row, col, val, (M, N))
+    perm = ref.csr2csc()
+    assert np.array_equal(colptr.cpu().numpy(), ref.colptr())
+    assert np.array_equal(r_csc.cpu().numpy(), row[perm]) and np.array_equal(v_csc.cpu().numpy(), val[perm])
+    dense = SparseTensor.from_dense(t.to_dense())
+    assert dense == t
+
+
+def test_eye_caches():
+    """test/test_eye.py:42-66."""
+    from paddle_sparse_amd import SparseTensor
+
+    for M, N in ((3, 3), (3, 4), (4, 3)):
+        a = SparseTensor.eye(M, N, device=DEV, fill_cache=True)
+        b = SparseTensor.eye(M, N, device=DEV, fill_cache=False).fill_cache_()
+        for name in ("rowcount", "colptr", "colcount", "csr2csc", "csc2csr"):
+            assert getattr(a.storage, "_" + name).tolist() == getattr(b.storage, "_" + name).tolist(), (M, N, name)
+        assert a.storage.rowptr().tolist() == b.storage.rowptr().tolist()
+
+
+# ---- SpMM on the tensor surface ----------------------------------------------------------
+def test_spmm_functional_readme_kat(kats):
+    from paddle_sparse_amd import spmm
+
+    k = kats["spmm"]
+    out = spmm(idx(k["index"]), tensor(k["value"], torch.float32), k["m"], k["n"],
+               tensor(k["matrix"], torch.float32))
+    assert out.tolist() == k["out"]
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max"])
+@pytest.mark.parametrize("has_value", [True, False])
+def test_spmm_autograd_vs_oracle(reduce, has_value):
+    from paddle_sparse_amd import SparseTensor
+
+    rng = np.random.default_rng(21)
+    M, N, K = 400, 300, 32
+    key = np.unique(rng.integers(0, M * N, 5000))
+    row, col = key // N, key % N
+    nnz = key.size
+    val = rng.standard_normal(nnz).astype(np.float32) if has_value else None
+    B = rng.standard_normal((N, K)).astype(np.float32)
+    G = rng.standard_normal((M, K)).astype(np.float32)
+    rowptr = oracle.ind2ptr(row, M)
+
+    v = torch.from_numpy(val).cuda().requires_grad_() if has_value else None
+    Bt = torch.from_numpy(B).cuda().requires_grad_()
+    a = SparseTensor(row=idx(row), col=idx(col), value=v, sparse_sizes=(M, N))
+    out = a.matmul(Bt, reduce) if reduce != "sum" else a @ Bt
+    out.backward(torch.from_numpy(G).cuda())
+
+    ref, arg = oracle.spmm(reduce, rowptr, col, val, B)
+    S = oracle.spmm_abs_sum(rowptr, col, val, B)
+    assert np.all(np.abs(out.detach().cpu().numpy() - ref) <= 1e-5 * S + 1e-30)
+    if reduce in ("sum", "mean"):
+        gB = oracle.spmm_mat_bw(reduce, row, rowptr, col, val, G, N)
+        gV = oracle.spmm_value_bw(reduce, row, rowptr, col, B, G)
+    else:
+        gV, gB = oracle.spmm_minmax_bw(col, val, B, G, arg)
+    np.testing.assert_allclose(Bt.grad.cpu().numpy(), gB, rtol=1e-4, atol=1e-4)
+    if has_value:
+        np.testing.assert_allclose(v.grad.cpu().numpy(), gV, rtol=1e-4, atol=1e-4)
+
+
+def test_cpu_tensors_are_rejected_by_the_hot_path():
+    from paddle_sparse_amd import SparseTensor
+
+    t = SparseTensor(row=torch.tensor([0, 1]), col=torch.tensor([1, 0]), is_sorted=True)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        t.storage.rowptr()

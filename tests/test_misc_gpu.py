@@ -1,0 +1,101 @@
+"""GPU parity of the small index kernels (bincount, count2ptr, scatter) and
+the SpMM backward entry points called directly through the C-ABI."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import storage_oracle as so
+from util import random_csr, skewed_csr
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("n,size,seed", [(0, 5, 0), (1, 1, 1), (1000, 7, 2), (100000, 30000, 3), (3000000, 2000000, 4)])
+def test_bincount_and_count2ptr(n, size, seed):
+    from paddle_sparse_amd import ops
+
+    rng = np.random.default_rng(seed)
+    index = rng.integers(0, size, n, dtype=np.int64)
+    cnt = ops.bincount(dev(index) if n else torch.empty(0, dtype=torch.int64, device="cuda"), size)
+    ref = np.bincount(index, minlength=size).astype(np.int64)
+    assert np.array_equal(cnt.cpu().numpy(), ref)
+    ptr = ops.count2ptr(cnt).cpu().numpy()
+    assert np.array_equal(ptr, np.concatenate([[0], np.cumsum(ref)]))
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max"])
+@pytest.mark.parametrize("npdtype", [np.float32, np.float64, np.int32, np.int64])
+@pytest.mark.parametrize("tail", [(), (3,), (64,)])
+def test_scatter_vs_oracle(reduce, npdtype, tail):
+    from paddle_sparse_amd import ops
+
+    rng = np.random.default_rng(11)
+    n, size = 4000, 300
+    src = rng.integers(-20, 20, (n,) + tail).astype(npdtype)  # exact sums
+    index = rng.integers(0, size - 10, n, dtype=np.int64)      # last rows untouched
+    got = ops.scatter(dev(src), dev(index), size, reduce).cpu().numpy()
+    ref = so.scatter(src, index, size, reduce)
+    if reduce == "mean" and npdtype in (np.float32, np.float64):
+        np.testing.assert_allclose(got, ref, rtol=1e-6)
+    else:
+        assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean"])
+@pytest.mark.parametrize("K", [1, 3, 4, 16, 64, 128, 256, 300, 520])
+def test_spmm_value_bw(reduce, K):
+    from paddle_sparse_amd import ops
+
+    row, rowptr, col, val = skewed_csr(300, 250, seed=K, long_rows=(0, 299), long_deg=200)
+    rng = np.random.default_rng(K)
+    B = rng.standard_normal((250, K)).astype(np.float32)
+    G = rng.standard_normal((300, K)).astype(np.float32)
+    got = ops.spmm_value_bw(dev(row), dev(rowptr), dev(col), dev(B), dev(G), reduce).cpu().numpy()
+    ref = oracle.spmm_value_bw(reduce, row, rowptr, col, B, G)
+    scale = np.abs(B[col] * G[row]).sum(axis=1) + 1e-30
+    deg = np.maximum(rowptr[1:] - rowptr[:-1], 1)[row] if reduce == "mean" else 1
+    assert np.all(np.abs(got - ref) <= 1e-5 * scale / deg)
+
+
+@pytest.mark.parametrize("mean", [False, True])
+@pytest.mark.parametrize("has_value", [False, True])
+def test_transposed_spmm_is_grad_mat(mean, has_value):
+    """gB = A^T gOut evaluated as psa_spmm over the CSC view."""
+    from paddle_sparse_amd import ops
+
+    M, N, K = 500, 350, 64
+    rng = np.random.default_rng(2)
+    key = np.unique(rng.integers(0, M * N, 7000))
+    row, col = key // N, key % N
+    val = rng.standard_normal(key.size).astype(np.float32) if has_value else None
+    G = rng.standard_normal((M, K)).astype(np.float32)
+    rowptr = oracle.ind2ptr(row, M)
+    st = so.Storage(row, col, val, (M, N))
+    perm = st.csr2csc()
+    w = ops.transpose_weights(dev(val), dev(perm), dev(row[perm]), dev(rowptr), mean)
+    gB = ops.spmm_sum(dev(st.colptr()), dev(row[perm]), w, dev(G)).cpu().numpy()
+    ref = oracle.spmm_mat_bw("mean" if mean else "sum", row, rowptr, col, val, G, N)
+    np.testing.assert_allclose(gB, ref, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("reduce", ["min", "max"])
+def test_spmm_minmax_bw(reduce):
+    from paddle_sparse_amd import ops
+
+    row, rowptr, col, val = random_csr(400, 300, 5000, seed=8)
+    rng = np.random.default_rng(1)
+    B = rng.standard_normal((300, 48)).astype(np.float32)
+    G = rng.standard_normal((400, 48)).astype(np.float32)
+    _, arg = oracle.spmm(reduce, rowptr, col, val, B)
+    gv, gm = ops.spmm_minmax_bw(dev(col), dev(val), dev(B), dev(G), dev(arg))
+    rv, rm = oracle.spmm_minmax_bw(col, val, B, G, arg)
+    np.testing.assert_allclose(gv.cpu().numpy(), rv, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gm.cpu().numpy(), rm, rtol=1e-4, atol=1e-5)
+    only_v, none = ops.spmm_minmax_bw(dev(col), dev(val), dev(B), dev(G), dev(arg), want_mat=False)
+    # float atomics: summation order differs between launches
+    assert none is None and torch.allclose(only_v, gv, rtol=1e-4, atol=1e-5)
