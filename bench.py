@@ -8,7 +8,8 @@ dense F = 128 fp32, one `spmm_sum` forward per step, inputs resident in HBM.
 N > 1 (launched by torch.distributed.run, one rank per GPU): the same per-GPU
 rows/edges on every rank (weak scaling, BASELINE config 4's structure): rank r
 owns rows [r*2M, (r+1)*2M) of A (20M edges, columns over all N*2M nodes) and
-the matching 2M-row block of B; a step = RCCL all-gather of B + local SpMM.
+the matching 2M-row block of B; a step = RCCL all-gather of B + local SpMM
+(paddle_sparse_amd.distributed.RowPartitionedSpMM).
 
 Prints ONE JSON line on rank 0 (contract in the task brief): whole-job
 GEdges/s, the roofline object of the dominant kernel (algorithmic bytes /
@@ -103,6 +104,17 @@ def cpu_baseline(rowptr, col, val, B, budget_s: float = 12.0):
     return info, out, sample_rows
 
 
+def event_ms(fn, reps: int) -> float:
+    """Mean device time of fn() over reps launches (HIP events on the current stream)."""
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,30 +140,41 @@ def main() -> None:
 
     from paddle_sparse_amd import ops
 
+    # world == 1 runs without a process group unless a rehearsal asks for one
+    use_dist = world > 1 or os.environ.get("PSA_BENCH_FORCE_DIST") == "1"
     dist = None
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist  # noqa: PLC0415
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     M, nnz, F = M_PER_GPU, NNZ_PER_GPU, FEAT
     N = M * world
+    reduce = args.op.split("_", 1)[1]
     rowptr, col, val = make_workload(M, N, nnz, F, seed=2 + rank, device=device)
     g = torch.Generator(device=device).manual_seed(100 + rank)
     B_local = torch.randn(M, F, generator=g, device=device)
-    B_full = torch.empty(N, F, device=device) if world > 1 else B_local
-    fn = getattr(ops, args.op)
     ops.spmm_set_variant(args.variant)
 
-    def step():
-        if world > 1:
-            dist.all_gather_into_tensor(B_full, B_local)
-        return fn(rowptr, col, val, B_full)
+    if use_dist:
+        from paddle_sparse_amd.distributed import RowPartitionedSpMM, RowShard
+
+        op = RowPartitionedSpMM(RowShard(rowptr, col, val, rank * M, (rank + 1) * M, N), reduce=reduce)
+        step = lambda: op(B_local)  # noqa: E731  all-gather(B) + local HIP SpMM
+        B_full = op.gather(B_local)
+    else:
+        fn = getattr(ops, args.op)
+        B_full = B_local
+        step = lambda: fn(rowptr, col, val, B_full)  # noqa: E731
+
+    def local_kernel():
+        return ops._spmm(reduce, rowptr, col, val, B_full)[0]
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -159,25 +182,22 @@ def main() -> None:
         step()
     sync_all()
 
-    # kernel-only time: HIP events on the launch stream around each launch
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for a, b in ev:
-        if world > 1:
-            dist.all_gather_into_tensor(B_full, B_local)
-        a.record()
-        out = fn(rowptr, col, val, B_full)
-        b.record()
+    for _ in range(args.steps):
+        out = step()
     sync_all()
     elapsed = time.perf_counter() - t0
-    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps
     if isinstance(out, tuple):
         out = out[0]
 
-    t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=device)
-    if world > 1:
+    # dominant kernel alone (HIP events on its launch stream), after the timed region
+    kern_ms = event_ms(local_kernel, args.steps)
+    gather_ms = event_ms(lambda: op.gather(B_local), max(3, args.steps // 5)) if use_dist else 0.0
+
+    t = torch.tensor([elapsed, kern_ms, gather_ms], dtype=torch.float64, device=device)
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, kern_ms = float(t[0]), float(t[1])
+    elapsed, kern_ms, gather_ms = (float(x) for x in t)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -186,7 +206,7 @@ def main() -> None:
         achieved = alg / (kern_ms * 1e-3) / 1e9
         traffic = None
         tfile = ROOT / "profiles" / "traffic.json"
-        if tfile.exists():
+        if tfile.exists() and world == 1:
             traffic = json.loads(tfile.read_text()).get(f"{args.op}_c3", {}).get("hbm_bytes_per_launch")
         line = {
             "metric": f"{args.op}_gedges_per_s",
@@ -204,7 +224,7 @@ def main() -> None:
             "config": {
                 "workload": f"{args.op} fwd, uniform random CSR {M}x{N} per GPU, nnz={nnz} per GPU, "
                             f"dense F={F} fp32 (BASELINE config 3 per GPU)"
-                            + (f"; + RCCL all-gather of B ({N}x{F}) every step" if world > 1 else ""),
+                            + (f"; + RCCL all-gather of B ({N}x{F}) every step" if use_dist else ""),
                 "rows_per_gpu": M, "nnz_per_gpu": nnz, "feat": F, "index_dtype": "int64",
                 "variant": args.variant,
             },
@@ -221,6 +241,14 @@ def main() -> None:
                 "kernel_gedges_per_s": round(nnz / (kern_ms * 1e-3) / 1e9, 4),
             },
         }
+        if use_dist:
+            line["multi_gpu"] = {
+                "allgather_ms": round(gather_ms, 4),
+                "allgather_bytes_received_per_rank": (world - 1) * M * F * 4,
+                "spmm_only_aggregate_gedges_per_s": round(world * nnz / (kern_ms * 1e-3) / 1e9, 4),
+                "note": "value counts the all-gather of B inside every step; spmm_only_* is the "
+                        "local-kernel rate with B already assembled",
+            }
         if not args.no_cpu and args.op == "spmm_sum":
             info, ref, rows = cpu_baseline(rowptr, col, val, B_full)
             got = out[:rows].cpu().numpy()
@@ -229,7 +257,7 @@ def main() -> None:
             line["check_max_abs_err_vs_oracle"] = float(np.abs(got - ref).max() / scale)
         print(json.dumps(line), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
