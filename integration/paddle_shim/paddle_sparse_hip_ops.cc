@@ -1,0 +1,183 @@
+// Paddle custom-op shim over the C-ABI HIP core (include/paddle_sparse_hip.h).
+//
+// NOT compiled in this repository's image (no <paddle/extension.h> on disk);
+// it is the binding a paddle_sparse maintainer adds so that
+// `import paddle_sparse_ops` resolves to the MI355X kernels.  It keeps the
+// reference's registration conventions (csrc/convert.cpp:13-43,46-76,
+// csrc/version.cpp:14-40): one PD_BUILD_OP per op, kernels take
+// paddle::Tensor& and attrs by value, outputs come from paddle::empty, work is
+// enqueued on tensor.stream() and not synchronised, errors become PD_THROW.
+// There is no logic here beyond argument marshalling.
+#include <paddle/extension.h>
+
+#include <vector>
+
+#include "paddle_sparse_hip.h"
+
+#define PSA_CALL(expr)                                  \
+  do {                                                  \
+    if ((expr) != PSA_OK) PD_THROW(psa_last_error());   \
+  } while (0)
+
+#define CHECK_GPU(x) PD_CHECK((x).is_gpu(), #x " must be a GPU tensor (HIP build has no CPU path)")
+#define CHECK_I64(x) PD_CHECK((x).dtype() == paddle::DataType::INT64, #x " must be int64")
+
+namespace {
+inline void* stream_of(const paddle::Tensor& t) { return reinterpret_cast<void*>(t.stream()); }
+inline const int64_t* i64(const paddle::Tensor& t) { return t.data<int64_t>(); }
+inline const float* f32(const paddle::Tensor& t) { return t.data<float>(); }
+}  // namespace
+
+// ---- sparse_cuda_version (csrc/version.cpp:14-40) ---------------------------
+std::vector<paddle::Tensor> sparse_cuda_version() {
+  return {paddle::full({1}, psa_sparse_cuda_version(), paddle::DataType::INT64, paddle::CPUPlace())};
+}
+std::vector<paddle::DataType> sparse_cuda_version_infer_dtype() { return {paddle::DataType::INT64}; }
+std::vector<std::vector<int64_t>> sparse_cuda_version_infer_shape() { return {{1}}; }
+PD_BUILD_OP(sparse_cuda_version)
+    .Inputs({})
+    .Outputs({"out"})
+    .SetKernelFn(PD_KERNEL(sparse_cuda_version))
+    .SetInferShapeFn(PD_INFER_SHAPE(sparse_cuda_version_infer_shape))
+    .SetInferDtypeFn(PD_INFER_DTYPE(sparse_cuda_version_infer_dtype));
+
+// ---- ind2ptr / ptr2ind (csrc/convert.cpp:13-76) --------------------------------
+std::vector<paddle::Tensor> ind2ptr(paddle::Tensor& ind, int64_t M) {
+  CHECK_GPU(ind);
+  CHECK_I64(ind);
+  auto out = paddle::empty({M + 1}, ind.dtype(), ind.place());
+  PSA_CALL(psa_ind2ptr(i64(ind), ind.numel(), M, out.data<int64_t>(), stream_of(ind)));
+  return {out};
+}
+std::vector<paddle::DataType> ind2ptr_infer_dtype(const paddle::DataType d) { return {d}; }
+std::vector<std::vector<int64_t>> ind2ptr_infer_shape(int64_t M) { return {{M + 1}}; }
+PD_BUILD_OP(ind2ptr)
+    .Inputs({"ind"})
+    .Outputs({"out"})
+    .Attrs({"M: int64_t"})
+    .SetKernelFn(PD_KERNEL(ind2ptr))
+    .SetInferShapeFn(PD_INFER_SHAPE(ind2ptr_infer_shape))
+    .SetInferDtypeFn(PD_INFER_DTYPE(ind2ptr_infer_dtype));
+
+std::vector<paddle::Tensor> ptr2ind(paddle::Tensor& ptr, int64_t E) {
+  CHECK_GPU(ptr);
+  CHECK_I64(ptr);
+  auto out = paddle::empty({E}, ptr.dtype(), ptr.place());
+  PSA_CALL(psa_ptr2ind(i64(ptr), ptr.numel() - 1, E, out.data<int64_t>(), stream_of(ptr)));
+  return {out};
+}
+std::vector<paddle::DataType> ptr2ind_infer_dtype(const paddle::DataType d) { return {d}; }
+std::vector<std::vector<int64_t>> ptr2ind_infer_shape(int64_t E) { return {{E}}; }
+PD_BUILD_OP(ptr2ind)
+    .Inputs({"ptr"})
+    .Outputs({"out"})
+    .Attrs({"E: int64_t"})
+    .SetKernelFn(PD_KERNEL(ptr2ind))
+    .SetInferShapeFn(PD_INFER_SHAPE(ptr2ind_infer_shape))
+    .SetInferDtypeFn(PD_INFER_DTYPE(ptr2ind_infer_dtype));
+
+// ---- index_sort (seam: paddle_sparse/utils.py:14-23) ------------------------------
+// returns (sorted, perm); utils.index_sort drops `sorted` unless asked for.
+std::vector<paddle::Tensor> index_sort(paddle::Tensor& keys, int64_t max_value) {
+  CHECK_GPU(keys);
+  CHECK_I64(keys);
+  const int64_t n = keys.numel();
+  auto sorted = paddle::empty({n}, keys.dtype(), keys.place());
+  auto perm = paddle::empty({n}, keys.dtype(), keys.place());
+  const int64_t ws_bytes = static_cast<int64_t>(psa_index_sort_workspace_bytes(n, max_value));
+  auto ws = paddle::empty({ws_bytes > 0 ? ws_bytes : 1}, paddle::DataType::UINT8, keys.place());
+  PSA_CALL(psa_index_sort(i64(keys), n, max_value, sorted.data<int64_t>(), perm.data<int64_t>(),
+                          ws.data<uint8_t>(), static_cast<size_t>(ws_bytes), stream_of(keys)));
+  return {sorted, perm};
+}
+std::vector<paddle::DataType> index_sort_infer_dtype(const paddle::DataType d) { return {d, d}; }
+PD_BUILD_OP(index_sort)
+    .Inputs({"keys"})
+    .Outputs({"sorted", "perm"})
+    .Attrs({"max_value: int64_t"})
+    .SetKernelFn(PD_KERNEL(index_sort))
+    .SetInferDtypeFn(PD_INFER_DTYPE(index_sort_infer_dtype));
+
+// ---- spmm_{sum,mean,min,max}: new ops, same convention -------------------------------
+// `value` is optional in the Python API; Paddle's paddle::optional<Tensor>
+// input (anticipated by PD_DISPATCH_HAS_VALUE, csrc/cpu/utils.h:11-20) maps
+// to a NULL pointer in the C-ABI.
+static std::vector<paddle::Tensor> spmm_impl(int reduce, paddle::Tensor& rowptr, paddle::Tensor& col,
+                                             const paddle::optional<paddle::Tensor>& value,
+                                             paddle::Tensor& mat) {
+  CHECK_GPU(mat);
+  CHECK_I64(rowptr);
+  CHECK_I64(col);
+  PD_CHECK(mat.dtype() == paddle::DataType::FLOAT32, "spmm is fp32 in the HIP build");
+  const int64_t M = rowptr.numel() - 1, N = mat.shape()[0], K = mat.shape()[1], nnz = col.numel();
+  auto out = paddle::empty({M, K}, mat.dtype(), mat.place());
+  const bool minmax = reduce == PSA_MIN || reduce == PSA_MAX;
+  auto arg = minmax ? paddle::empty({M, K}, paddle::DataType::INT64, mat.place())
+                    : paddle::empty({0}, paddle::DataType::INT64, mat.place());
+  PSA_CALL(psa_spmm(reduce, i64(rowptr), i64(col), value ? f32(value.get()) : nullptr, f32(mat), M, N,
+                    K, nnz, out.data<float>(), minmax ? arg.data<int64_t>() : nullptr, stream_of(mat)));
+  return {out, arg};
+}
+#define PSA_SPMM_OP(NAME, RED)                                                                \
+  std::vector<paddle::Tensor> NAME(paddle::Tensor& rowptr, paddle::Tensor& col,                \
+                                   const paddle::optional<paddle::Tensor>& value,             \
+                                   paddle::Tensor& mat) {                                     \
+    return spmm_impl(RED, rowptr, col, value, mat);                                           \
+  }                                                                                           \
+  PD_BUILD_OP(NAME)                                                                           \
+      .Inputs({"rowptr", "col", paddle::Optional("value"), "mat"})                            \
+      .Outputs({"out", "arg_out"})                                                            \
+      .SetKernelFn(PD_KERNEL(NAME));
+PSA_SPMM_OP(spmm_sum, PSA_SUM)
+PSA_SPMM_OP(spmm_mean, PSA_MEAN)
+PSA_SPMM_OP(spmm_min, PSA_MIN)
+PSA_SPMM_OP(spmm_max, PSA_MAX)
+
+// grad wrt the values (upstream spmm_value_bw); grad wrt mat is spmm_sum over
+// the CSC view and is composed in Python (paddle_sparse/matmul.py PyLayer),
+// exactly as paddle_sparse_amd/matmul.py does on torch.
+std::vector<paddle::Tensor> spmm_value_bw(paddle::Tensor& rowptr, paddle::Tensor& col, paddle::Tensor& mat,
+                                          paddle::Tensor& grad, bool mean) {
+  CHECK_GPU(mat);
+  const int64_t M = rowptr.numel() - 1, K = mat.shape()[1], nnz = col.numel();
+  auto out = paddle::empty({nnz}, mat.dtype(), mat.place());
+  PSA_CALL(psa_spmm_value_bw(mean ? PSA_MEAN : PSA_SUM, i64(rowptr), i64(col), f32(mat), f32(grad), M, K,
+                             nnz, out.data<float>(), stream_of(mat)));
+  return {out};
+}
+PD_BUILD_OP(spmm_value_bw)
+    .Inputs({"rowptr", "col", "mat", "grad"})
+    .Outputs({"out"})
+    .Attrs({"mean: bool"})
+    .SetKernelFn(PD_KERNEL(spmm_value_bw));
+
+// ---- segment_csr with an optional gather permutation (storage.py:471) -----------------
+std::vector<paddle::Tensor> segment_csr_perm(paddle::Tensor& src, paddle::Tensor& ptr,
+                                             const paddle::optional<paddle::Tensor>& perm, int64_t reduce) {
+  CHECK_GPU(src);
+  int dtype = -1;
+  switch (src.dtype()) {
+    case paddle::DataType::FLOAT32: dtype = PSA_F32; break;
+    case paddle::DataType::FLOAT64: dtype = PSA_F64; break;
+    case paddle::DataType::INT32: dtype = PSA_I32; break;
+    case paddle::DataType::INT64: dtype = PSA_I64; break;
+    case paddle::DataType::FLOAT16: dtype = PSA_F16; break;
+    case paddle::DataType::BFLOAT16: dtype = PSA_BF16; break;
+    default: PD_THROW("segment_csr: unsupported dtype");
+  }
+  auto shape = src.shape();
+  const int64_t nseg = ptr.numel() - 1;
+  int64_t D = 1;
+  for (size_t i = 1; i < shape.size(); ++i) D *= shape[i];
+  const int64_t n = perm ? perm.get().numel() : shape[0];
+  shape[0] = nseg;
+  auto out = paddle::empty(shape, src.dtype(), src.place());
+  PSA_CALL(psa_segment_reduce(static_cast<int>(reduce), dtype, src.data(), perm ? i64(perm.get()) : nullptr,
+                              i64(ptr), nseg, D, n, out.data(), stream_of(src)));
+  return {out};
+}
+PD_BUILD_OP(segment_csr_perm)
+    .Inputs({"src", "ptr", paddle::Optional("perm")})
+    .Outputs({"out"})
+    .Attrs({"reduce: int64_t"})
+    .SetKernelFn(PD_KERNEL(segment_csr_perm));
