@@ -160,6 +160,13 @@ int psa_index_sort(const int64_t* keys, int64_t n, int64_t max_value,
                    int64_t* sorted_out, int64_t* perm_out, void* workspace,
                    size_t workspace_bytes, psa_stream_t stream);
 
+/* Test/bench hook: scatter kernel variant of psa_index_sort for this process
+ * (0 = production: 8192-key tile reordered in LDS, 1024 threads; 1 = 2048-key
+ * LDS tile; 2 = direct per-lane stores; 3 / 4 = 4096- / 8192-key tile with
+ * separate key and index LDS buffers).  Returns the previous value.  All
+ * variants produce the same bits. */
+int psa_sort_set_variant(int variant);
+
 /* keys[i] = a[i] * mul + b[i]  (storage.py:159-162 key = row*N + col,
  * storage.py:430 key = M*col + row).  If unsorted_flag != NULL, *unsorted_flag
  * (device int32, caller-zeroed) is set to 1 when some keys[i] < keys[i-1]

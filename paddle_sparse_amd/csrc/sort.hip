@@ -8,14 +8,22 @@
 // Per pass (classic histogram / scan / scatter with a fixed grid, no
 // inter-workgroup hand-off inside a launch):
 //   1. radix_hist_kernel    every block counts the digits of its contiguous
-//                           key range (LDS histogram per wave)   -> counts
-//   2. radix_scan_kernel    one wave per digit: exclusive scan of counts in
-//                           (digit, block) order                 -> offsets
-//   3. radix_scatter_kernel every block walks its range tile by tile; ranks
-//                           keys inside the tile with wave-wide digit
-//                           matching (stable), reorders the tile in LDS so
-//                           that global stores are contiguous runs per digit,
-//                           and carries its 256 running offsets in LDS.
+//                           key range (16-B loads, LDS histogram per wave)
+//   2. radix_scan_kernel    one wave per digit: exclusive scan of the counts
+//                           in (digit, block) order
+//   3. radix_scatter_*      every block re-walks its range tile by tile; keys
+//                           get their stable rank inside the tile from
+//                           wave-wide digit matching (8 ballots), the block's
+//                           256 running offsets live in LDS.
+//      wide (default)   : 1024 threads x 8 keys = 8192-key tile, reordered in
+//                         LDS so every store instruction writes contiguous
+//                         runs (32 keys per digit on average); ONE resident
+//                         block per CU, so the 512 open output lines of all
+//                         blocks of an XCD fit its 4 MiB L2 and partial lines
+//                         complete there.  Measured 5.9 ms for 100 M 48-bit
+//                         keys (rocPRIM onesweep via torch.sort: 8.0 ms).
+//      variants 1-4 kept for A/B (tools/sort_bench.py): 256-thread staged
+//      tile 7.6 ms, direct per-lane stores 8.9 ms, 512-thread tile 6.6 ms.
 // HBM traffic per pass: 8n (hist) + 12n read + 12n written (key64 + idx32).
 #include "common.h"
 
@@ -23,13 +31,30 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
-constexpr int kItems = 8;                    // keys per thread per tile
-constexpr int kTile = kThreads * kItems;     // 2048 keys per tile
 constexpr int kRadix = 256;
-constexpr int kMaxBlocks = 1024;
+constexpr int kMaxBlocks = 1024;  // default cap on the fixed grid (tunable, see make_plan)
+constexpr int kTileKeys = 8192;  // granule of the block ranges = production scatter tile
+constexpr int kHistStep = 2048;  // keys per block iteration of the histogram kernel
+
+int g_sort_variant = 0;
 
 __device__ __forceinline__ unsigned digit_of(uint64_t key, int shift) {
   return static_cast<unsigned>(key >> shift) & (kRadix - 1);
+}
+
+// Count one key into the wave's LDS histogram.  A wave whose keys all share
+// the digit (sorted or small keys) would serialise 64 LDS atomics on one
+// address, so that case adds the lane count once.
+__device__ __forceinline__ void hist_add(uint32_t* whist, unsigned d, bool valid, int lane) {
+  const unsigned long long active = __ballot(valid);
+  if (active == 0ull) return;
+  const int first = __ffsll(static_cast<long long>(active)) - 1;
+  const unsigned d0 = __shfl(d, first);
+  if (__ballot(valid && d != d0) == 0ull) {
+    if (lane == first) atomicAdd(whist + d0, static_cast<uint32_t>(__popcll(active)));
+  } else if (valid) {
+    atomicAdd(whist + d, 1u);
+  }
 }
 
 // ---- 1. histogram ---------------------------------------------------------
@@ -40,25 +65,38 @@ radix_hist_kernel(const uint64_t* __restrict__ keys, int64_t n, int shift,
                   uint32_t* __restrict__ digit_total) {
   __shared__ uint32_t hist[kWaves][kRadix];
   const int tid = threadIdx.x;
+  const int lane = tid & 63;
   const int wave = tid >> 6;
-  for (int i = tid; i < kWaves * kRadix; i += kThreads)
-    (&hist[0][0])[i] = 0;
+  for (int i = tid; i < kWaves * kRadix; i += kThreads) (&hist[0][0])[i] = 0;
   __syncthreads();
-  const int64_t begin = static_cast<int64_t>(blockIdx.x) * tiles_per_block * kTile;
-  int64_t end = begin + static_cast<int64_t>(tiles_per_block) * kTile;
+  const int64_t begin = static_cast<int64_t>(blockIdx.x) * tiles_per_block * kTileKeys;
+  int64_t end = begin + static_cast<int64_t>(tiles_per_block) * kTileKeys;
   end = end < n ? end : n;
-  for (int64_t i = begin + tid; i < end; i += kThreads) {
-    const unsigned d = digit_of(keys[i], shift);
-    // Degenerate digits (all keys of the wave equal, e.g. high bytes of small
-    // keys) would serialise 64 LDS atomics on one address.
-    const unsigned d0 = __builtin_amdgcn_readfirstlane(d);
-    const unsigned long long same = __ballot(d == d0);
-    const unsigned long long active = __ballot(1);
-    if (same == active) {
-      if ((tid & 63) == (__ffsll(static_cast<long long>(active)) - 1))
-        atomicAdd(&hist[wave][d0], static_cast<uint32_t>(__popcll(active)));
-    } else {
-      atomicAdd(&hist[wave][d], 1u);
+  uint32_t* whist = hist[wave];
+  const bool vec_ok = (reinterpret_cast<uintptr_t>(keys) & 15) == 0;
+  if (vec_ok) {
+    // 4 x 16-B loads in flight per lane: 2048 keys per block iteration
+    const ulonglong2* kv = reinterpret_cast<const ulonglong2*>(keys);
+    for (int64_t base = begin; base < end; base += kHistStep) {
+      ulonglong2 v[4];
+      int64_t idx[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        idx[j] = base + 2 * (j * kThreads + tid);
+        v[j] = idx[j] + 1 < end ? kv[idx[j] >> 1]
+                                : make_ulonglong2(idx[j] < end ? keys[idx[j]] : 0ull, 0ull);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        hist_add(whist, digit_of(v[j].x, shift), idx[j] < end, lane);
+        hist_add(whist, digit_of(v[j].y, shift), idx[j] + 1 < end, lane);
+      }
+    }
+  } else {
+    for (int64_t base = begin; base < end; base += kThreads) {
+      const int64_t i = base + tid;
+      const bool valid = i < end;
+      hist_add(whist, digit_of(valid ? keys[i] : 0ull, shift), valid, lane);
     }
   }
   __syncthreads();
@@ -103,87 +141,183 @@ radix_scan_kernel(uint32_t* __restrict__ counts,
   }
 }
 
-// ---- 3. scatter ------------------------------------------------------------
+// Stable rank of this lane's key among the wave's keys with the same digit,
+// continuing the wave's running count in wcnt (LDS, 256 counters).
+//
+// Split in two so that the 8 ballot chains of all items (pure VALU/SALU, no
+// memory) can interleave, and only the short counter update is serial:
+//   wave_match : (#peers below this lane) | (#peers << 8), 0xffff.. if invalid
+//   wave_rank  : rank from the packed match word + the LDS running count
+__device__ __forceinline__ uint32_t wave_match(unsigned d, bool valid) {
+  // lanes whose bit b differs from mine = ballot(bit b) ^ (my bit ? ~0 : 0);
+  // OR the 8 difference masks, the complement are my peers.  Written on the
+  // 32-bit halves so it lowers to v_bfe_i32 + v_cmp + 2 v_xor + 2 v_or per bit.
+  const unsigned long long vm = __ballot(valid);
+  uint32_t lo = 0, hi = 0;
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const uint32_t neg = static_cast<uint32_t>(__builtin_amdgcn_sbfe(static_cast<int>(d), b, 1));
+    const unsigned long long m = __ballot(neg != 0u);
+    lo |= static_cast<uint32_t>(m) ^ neg;
+    hi |= static_cast<uint32_t>(m >> 32) ^ neg;
+  }
+  const uint32_t plo = ~lo & static_cast<uint32_t>(vm);
+  const uint32_t phi = ~hi & static_cast<uint32_t>(vm >> 32);
+  const uint32_t below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
+  return below | (static_cast<uint32_t>(__popc(plo) + __popc(phi)) << 8);
+}
+
+__device__ __forceinline__ uint32_t wave_rank(uint32_t* wcnt, unsigned d, bool valid,
+                                              uint32_t match) {
+  const uint32_t below = match & 0xffu;
+  const uint32_t old = wcnt[d];
+  if (valid && below == 0u)  // lowest lane of the peer set publishes the new count
+    wcnt[d] = old + (match >> 8);
+  return old + below;
+}
+
+// ---- 3a. scatter, direct stores ---------------------------------------------
 // PASS0: payload is the element's own index (nothing to read).
 // LAST : payload is written as int64 to perm_out (the API dtype).
+template <bool PASS0, bool LAST, int ITEMS, int THREADS>
+__global__ void __launch_bounds__(THREADS)
+radix_scatter_direct_kernel(const uint64_t* __restrict__ keys_in,
+                            const uint32_t* __restrict__ idx_in,
+                            uint64_t* __restrict__ keys_out,  // may be null if LAST
+                            uint32_t* __restrict__ idx_out,   // !LAST
+                            int64_t* __restrict__ perm_out,   // LAST
+                            int64_t n, int shift, int tiles_per_block,
+                            int num_blocks, const uint32_t* __restrict__ offsets) {
+  constexpr int TILE = THREADS * ITEMS;
+  constexpr int WAVES = THREADS / 64;
+  __shared__ uint32_t wcnt[2][WAVES][kRadix];  // double-buffered per-wave counts
+  __shared__ uint32_t gbase[kRadix];            // running global offset per digit
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+
+  if (tid < kRadix) gbase[tid] = offsets[static_cast<size_t>(tid) * num_blocks + blockIdx.x];
+  for (int i = tid; i < WAVES * kRadix; i += THREADS) (&wcnt[0][0][0])[i] = 0;
+  __syncthreads();
+
+  const int64_t blk_begin = static_cast<int64_t>(blockIdx.x) * tiles_per_block * kTileKeys;
+  int64_t blk_end = blk_begin + static_cast<int64_t>(tiles_per_block) * kTileKeys;
+  blk_end = blk_end < n ? blk_end : n;
+  int buf = 0;
+  for (int64_t tile_begin = blk_begin; tile_begin < blk_end; tile_begin += TILE, buf ^= 1) {
+    const int64_t rem = blk_end - tile_begin;
+    const int tile_n = rem < TILE ? static_cast<int>(rem) : TILE;
+    // wave-striped inside a contiguous chunk per wave: item i of lane l is
+    // tile element  wave*ITEMS*64 + i*64 + l  (index order == (wave, i, lane))
+    uint64_t key[ITEMS];
+    uint32_t idx[ITEMS];
+    uint32_t rank[ITEMS];
+    const int wbase = wave * (ITEMS * 64);
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int p = wbase + i * 64 + lane;
+      const bool valid = p < tile_n;
+      key[i] = valid ? keys_in[tile_begin + p] : ~0ull;
+      if (PASS0) idx[i] = static_cast<uint32_t>(tile_begin + p);
+      else idx[i] = valid ? idx_in[tile_begin + p] : 0u;
+    }
+    uint32_t* mine = wcnt[buf][wave];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const bool valid = wbase + i * 64 + lane < tile_n;
+      const unsigned d = digit_of(key[i], shift);
+      rank[i] = wave_rank(mine, d, valid, wave_match(d, valid));
+    }
+    __syncthreads();
+    if (tid < kRadix) {  // thread d: global start of every wave's run of digit d; advance gbase
+      uint32_t run = gbase[tid];
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) {
+        const uint32_t c = wcnt[buf][w][tid];
+        wcnt[buf][w][tid] = run;
+        run += c;
+        wcnt[buf ^ 1][w][tid] = 0;  // next tile's counters (idle since the last barrier pair)
+      }
+      gbase[tid] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      if (wbase + i * 64 + lane < tile_n) {
+        const int64_t dst = static_cast<int64_t>(mine[digit_of(key[i], shift)]) + rank[i];
+        if (LAST) {
+          if (keys_out) keys_out[dst] = key[i];
+          perm_out[dst] = static_cast<int64_t>(idx[i]);
+        } else {
+          keys_out[dst] = key[i];
+          idx_out[dst] = idx[i];
+        }
+      }
+    }
+  }
+}
+
+// ---- 3b. scatter, tile reordered in LDS first --------------------------------
 template <bool PASS0, bool LAST>
 __global__ void __launch_bounds__(kThreads)
-radix_scatter_kernel(const uint64_t* __restrict__ keys_in,
-                     const uint32_t* __restrict__ idx_in,
-                     uint64_t* __restrict__ keys_out,  // may be null if LAST
-                     uint32_t* __restrict__ idx_out,   // !LAST
-                     int64_t* __restrict__ perm_out,   // LAST
-                     int64_t n, int shift, int tiles_per_block, int num_blocks,
-                     const uint32_t* __restrict__ offsets) {
-  __shared__ uint64_t skey[kTile];
-  __shared__ uint32_t sidx[kTile];
-  __shared__ uint32_t wcnt[kWaves][kRadix];  // per-wave digit counts of a tile
-  __shared__ uint32_t gbase[kRadix];         // running global offset per digit
-  __shared__ int32_t gofs[kRadix];           // gbase - tile_digit_start
+radix_scatter_staged_kernel(const uint64_t* __restrict__ keys_in,
+                            const uint32_t* __restrict__ idx_in,
+                            uint64_t* __restrict__ keys_out,
+                            uint32_t* __restrict__ idx_out,
+                            int64_t* __restrict__ perm_out, int64_t n, int shift,
+                            int tiles_per_block, int num_blocks,
+                            const uint32_t* __restrict__ offsets) {
+  constexpr int ITEMS = 8;
+  constexpr int TILE = kThreads * ITEMS;
+  __shared__ uint64_t skey[TILE];
+  __shared__ uint32_t sidx[TILE];
+  __shared__ uint32_t wcnt[kWaves][kRadix];
+  __shared__ uint32_t gbase[kRadix];
+  __shared__ int32_t gofs[kRadix];  // gbase - tile_digit_start
   __shared__ uint32_t wave_tot[kWaves];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
-
   gbase[tid] = offsets[static_cast<size_t>(tid) * num_blocks + blockIdx.x];
 
-  const int64_t blk_begin = static_cast<int64_t>(blockIdx.x) * tiles_per_block * kTile;
-  for (int t = 0; t < tiles_per_block; ++t) {
-    const int64_t tile_begin = blk_begin + static_cast<int64_t>(t) * kTile;
-    if (tile_begin >= n) break;  // block-uniform
-    const int tile_n = (n - tile_begin) < kTile ? static_cast<int>(n - tile_begin) : kTile;
-
+  const int64_t blk_begin = static_cast<int64_t>(blockIdx.x) * tiles_per_block * kTileKeys;
+  int64_t blk_end = blk_begin + static_cast<int64_t>(tiles_per_block) * kTileKeys;
+  blk_end = blk_end < n ? blk_end : n;
+  for (int64_t tile_begin = blk_begin; tile_begin < blk_end; tile_begin += TILE) {
+    const int tile_n = (blk_end - tile_begin) < TILE ? static_cast<int>(blk_end - tile_begin) : TILE;
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) wcnt[w][tid] = 0;
     __syncthreads();
-
-    // wave-striped inside a contiguous chunk per wave: item i of lane l is
-    // tile element  wave*kItems*64 + i*64 + l  (index order == (wave,i,lane))
-    uint64_t key[kItems];
-    uint32_t idx[kItems];
-    uint32_t rank[kItems];
-    const int wbase = wave * (kItems * 64);
+    uint64_t key[ITEMS];
+    uint32_t idx[ITEMS];
+    uint32_t rank[ITEMS];
+    const int wbase = wave * (ITEMS * 64);
 #pragma unroll
-    for (int i = 0; i < kItems; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
       const int p = wbase + i * 64 + lane;
       const bool valid = p < tile_n;
       key[i] = valid ? keys_in[tile_begin + p] : ~0ull;
-      if (PASS0) {
-        idx[i] = static_cast<uint32_t>(tile_begin + p);
-      } else {
-        idx[i] = valid ? idx_in[tile_begin + p] : 0u;
-      }
+      if (PASS0) idx[i] = static_cast<uint32_t>(tile_begin + p);
+      else idx[i] = valid ? idx_in[tile_begin + p] : 0u;
     }
 #pragma unroll
-    for (int i = 0; i < kItems; ++i) {
-      const int p = wbase + i * 64 + lane;
-      const bool valid = p < tile_n;
+    for (int i = 0; i < ITEMS; ++i) {
+      // match + rank item by item: the 9 ballots of one item die before the
+      // next item's start (all items at once spills SGPRs)
+      const bool valid = wbase + i * 64 + lane < tile_n;
       const unsigned d = digit_of(key[i], shift);
-      // lanes of this wave holding the same digit
-      unsigned long long peers = __ballot(valid);
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        const bool bit = (d >> b) & 1u;
-        const unsigned long long m = __ballot(bit);
-        peers &= bit ? m : ~m;
-      }
-      const uint32_t old = wcnt[wave][d];
-      rank[i] = old + static_cast<uint32_t>(__popcll(peers & lt_mask));
-      if (valid && (peers & lt_mask) == 0ull)  // lowest lane of the peer set
-        wcnt[wave][d] = old + static_cast<uint32_t>(__popcll(peers));
+      rank[i] = wave_rank(wcnt[wave], d, valid, wave_match(d, valid));
     }
     __syncthreads();
-
-    // thread d: offsets of digit d across waves, tile totals, digit scan
     const unsigned d = tid;
     uint32_t c[kWaves];
     uint32_t tot = 0;
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) {
       c[w] = wcnt[w][d];
-      wcnt[w][d] = tot;  // exclusive offset of wave w inside digit d's run
+      wcnt[w][d] = tot;
       tot += c[w];
     }
     uint32_t incl = tot;
@@ -197,32 +331,26 @@ radix_scatter_kernel(const uint64_t* __restrict__ keys_in,
     uint32_t wprefix = 0;
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) wprefix += w < wave ? wave_tot[w] : 0u;
-    const uint32_t dstart = wprefix + incl - tot;  // tile position of digit d's run
+    const uint32_t dstart = wprefix + incl - tot;
     const uint32_t gb = gbase[d];
     gofs[d] = static_cast<int32_t>(gb) - static_cast<int32_t>(dstart);
     gbase[d] = gb + tot;
-    // reuse wcnt[0] slot? no: keep dstart in registers via a second table
-    // (wave offsets already hold per-wave exclusive counts); add dstart now.
 #pragma unroll
     for (int w = 0; w < kWaves; ++w) wcnt[w][d] += dstart;
     __syncthreads();
-
 #pragma unroll
-    for (int i = 0; i < kItems; ++i) {
+    for (int i = 0; i < ITEMS; ++i) {
       const int p = wbase + i * 64 + lane;
       if (p < tile_n) {
-        const unsigned dd = digit_of(key[i], shift);
-        const uint32_t pos = wcnt[wave][dd] + rank[i];
+        const uint32_t pos = wcnt[wave][digit_of(key[i], shift)] + rank[i];
         skey[pos] = key[i];
         sidx[pos] = idx[i];
       }
     }
     __syncthreads();
-
     for (int p = tid; p < tile_n; p += kThreads) {
       const uint64_t k = skey[p];
-      const unsigned dd = digit_of(k, shift);
-      const int64_t dst = static_cast<int64_t>(gofs[dd]) + p;
+      const int64_t dst = static_cast<int64_t>(gofs[digit_of(k, shift)]) + p;
       if (LAST) {
         if (keys_out) keys_out[dst] = k;
         perm_out[dst] = static_cast<int64_t>(sidx[p]);
@@ -232,6 +360,164 @@ radix_scatter_kernel(const uint64_t* __restrict__ keys_in,
       }
     }
     __syncthreads();
+  }
+}
+
+// ---- 3c. staged scatter, wide workgroup (bigger tile, longer store runs) --------
+// Same algorithm as 3b with THREADS x ITEMS keys per tile.  A tile of T keys
+// gives runs of T/256 keys per digit, i.e. T/32 bytes of keys per contiguous
+// store run, and one resident block per CU keeps the 512 open output lines of
+// every block inside the XCD's L2 until the next tile completes them.
+// TWO_ROUND: keys and indices go through ONE LDS buffer one after the other
+// (each thread keeps the destinations of its output slots in registers), which
+// halves... (1/3 less) LDS per key and lets a 16K-key tile fit in 160 KB.
+template <bool PASS0, bool LAST, int THREADS, int ITEMS, bool TWO_ROUND>
+__global__ void __launch_bounds__(THREADS)
+radix_scatter_wide_kernel(const uint64_t* __restrict__ keys_in,
+                          const uint32_t* __restrict__ idx_in,
+                          uint64_t* __restrict__ keys_out,
+                          uint32_t* __restrict__ idx_out,
+                          int64_t* __restrict__ perm_out, int64_t n, int shift,
+                          int tiles_per_block, int num_blocks,
+                          const uint32_t* __restrict__ offsets) {
+  constexpr int WAVES = THREADS / 64;
+  constexpr int TILE = THREADS * ITEMS;
+  __shared__ uint64_t skey[TILE];
+  __shared__ uint32_t sidx_store[TWO_ROUND ? 1 : TILE];
+  __shared__ uint32_t wcnt[WAVES][kRadix];
+  __shared__ uint32_t gbase[kRadix];
+  __shared__ int32_t gofs[kRadix];
+  __shared__ uint32_t wave_tot[4];
+  uint32_t* sidx = TWO_ROUND ? reinterpret_cast<uint32_t*>(skey) : sidx_store;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  if (tid < kRadix) gbase[tid] = offsets[static_cast<size_t>(tid) * num_blocks + blockIdx.x];
+
+  const int64_t blk_begin = static_cast<int64_t>(blockIdx.x) * tiles_per_block * kTileKeys;
+  int64_t blk_end = blk_begin + static_cast<int64_t>(tiles_per_block) * kTileKeys;
+  blk_end = blk_end < n ? blk_end : n;
+  const int wbase = wave * (ITEMS * 64);
+  // The next tile's keys/indices are requested before the current tile's
+  // write-out, so their HBM latency overlaps the stores (one resident block
+  // per CU has no other workgroup to hide it behind).
+  uint64_t nkey[ITEMS];
+  uint32_t nidx[ITEMS];
+  auto request_tile = [&](int64_t tb) {
+    const int64_t r = blk_end - tb;
+    const int tn = r < TILE ? static_cast<int>(r) : TILE;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int p = wbase + i * 64 + lane;
+      const bool valid = p < tn;
+      nkey[i] = valid ? keys_in[tb + p] : ~0ull;
+      if (PASS0) nidx[i] = static_cast<uint32_t>(tb + p);
+      else nidx[i] = valid ? idx_in[tb + p] : 0u;
+    }
+  };
+  if (blk_begin < blk_end) request_tile(blk_begin);
+  for (int64_t tile_begin = blk_begin; tile_begin < blk_end; tile_begin += TILE) {
+    const int64_t rem = blk_end - tile_begin;
+    const int tile_n = rem < TILE ? static_cast<int>(rem) : TILE;
+    for (int i = tid; i < WAVES * kRadix; i += THREADS) (&wcnt[0][0])[i] = 0;
+    __syncthreads();
+    uint64_t key[ITEMS];
+    uint32_t idx[ITEMS];
+    uint32_t rank[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      key[i] = nkey[i];
+      idx[i] = nidx[i];
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      // match + rank item by item: the 9 ballots of one item die before the
+      // next item's start (all items at once spills SGPRs)
+      const bool valid = wbase + i * 64 + lane < tile_n;
+      const unsigned d = digit_of(key[i], shift);
+      rank[i] = wave_rank(wcnt[wave], d, valid, wave_match(d, valid));
+    }
+    __syncthreads();
+    uint32_t tot = 0, incl = 0;
+    if (tid < kRadix) {  // thread d: exclusive wave offsets of digit d, tile total
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) {
+        const uint32_t c = wcnt[w][tid];
+        wcnt[w][tid] = tot;
+        tot += c;
+      }
+      incl = tot;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+      }
+      if (lane == 63) wave_tot[wave] = incl;
+    }
+    __syncthreads();
+    if (tid < kRadix) {
+      uint32_t wprefix = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) wprefix += w < wave ? wave_tot[w] : 0u;
+      const uint32_t dstart = wprefix + incl - tot;
+      const uint32_t gb = gbase[tid];
+      gofs[tid] = static_cast<int32_t>(gb) - static_cast<int32_t>(dstart);
+      gbase[tid] = gb + tot;
+#pragma unroll
+      for (int w = 0; w < WAVES; ++w) wcnt[w][tid] += dstart;
+    }
+    __syncthreads();
+    // tile position of every key (kept in rank[] from here on)
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      if (wbase + i * 64 + lane < tile_n) {
+        rank[i] += wcnt[wave][digit_of(key[i], shift)];
+        skey[rank[i]] = key[i];
+        if (!TWO_ROUND) sidx[rank[i]] = idx[i];
+      }
+    }
+    __syncthreads();
+    if (tile_begin + TILE < blk_end) request_tile(tile_begin + TILE);
+    if (!TWO_ROUND) {
+      for (int p = tid; p < tile_n; p += THREADS) {
+        const uint64_t k = skey[p];
+        const int64_t dst = static_cast<int64_t>(gofs[digit_of(k, shift)]) + p;
+        if (LAST) {
+          if (keys_out) keys_out[dst] = k;
+          perm_out[dst] = static_cast<int64_t>(sidx[p]);
+        } else {
+          keys_out[dst] = k;
+          idx_out[dst] = sidx[p];
+        }
+      }
+      __syncthreads();
+    } else {
+      uint32_t dst[ITEMS];  // global slot of tile position tid + j*THREADS
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) {
+        const int p = tid + j * THREADS;
+        if (p < tile_n) {
+          const uint64_t k = skey[p];
+          dst[j] = static_cast<uint32_t>(gofs[digit_of(k, shift)] + p);
+          if (!LAST || keys_out) keys_out[dst[j]] = k;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < ITEMS; ++i)
+        if (wbase + i * 64 + lane < tile_n) sidx[rank[i]] = idx[i];
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < ITEMS; ++j) {
+        const int p = tid + j * THREADS;
+        if (p < tile_n) {
+          if (LAST) perm_out[dst[j]] = static_cast<int64_t>(sidx[p]);
+          else idx_out[dst[j]] = sidx[p];
+        }
+      }
+      __syncthreads();
+    }
   }
 }
 
@@ -266,8 +552,12 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 SortPlan make_plan(int64_t n, int64_t max_value) {
   SortPlan p;
   p.passes = (bits_for(max_value) + 7) / 8;
-  p.num_tiles = psa::ceil_div(n > 0 ? n : 1, kTile);
-  p.tiles_per_block = static_cast<int>(psa::ceil_div(p.num_tiles, kMaxBlocks));
+  p.num_tiles = psa::ceil_div(n > 0 ? n : 1, kTileKeys);
+  // even tiles_per_block so a 4096-key scatter tile never straddles two blocks
+  // test hook: variant / 16 (if non-zero) overrides the block cap in units of 256
+  const int max_blocks = (g_sort_variant >> 4) > 0 ? (g_sort_variant >> 4) * 256 : kMaxBlocks;
+  p.tiles_per_block = static_cast<int>(psa::ceil_div(p.num_tiles, max_blocks));
+  if (p.tiles_per_block > 1 && (p.tiles_per_block & 1)) ++p.tiles_per_block;
   p.num_blocks = static_cast<int>(psa::ceil_div(p.num_tiles, p.tiles_per_block));
   p.keys_bytes = align_up(sizeof(uint64_t) * static_cast<size_t>(n), 256);
   p.idx_bytes = align_up(sizeof(uint32_t) * static_cast<size_t>(n), 256);
@@ -277,9 +567,33 @@ SortPlan make_plan(int64_t n, int64_t max_value) {
   return p;
 }
 
+template <bool P0, bool L>
+void launch_scatter(int variant, dim3 grid, hipStream_t s, const uint64_t* kin,
+                    const uint32_t* iin, uint64_t* kout, uint32_t* iout,
+                    int64_t* perm_out, int64_t n, int shift, const SortPlan& p,
+                    const uint32_t* counts) {
+#define PSA_SCATTER(KERNEL, THREADS)                                                   \
+  hipLaunchKernelGGL(KERNEL, grid, dim3(THREADS), 0, s, kin, iin, kout, iout, perm_out, \
+                     n, shift, p.tiles_per_block, p.num_blocks, counts)
+  switch (variant) {
+    case 1: PSA_SCATTER((radix_scatter_staged_kernel<P0, L>), kThreads); break;
+    case 2: PSA_SCATTER((radix_scatter_direct_kernel<P0, L, 8, 256>), 256); break;
+    case 3: PSA_SCATTER((radix_scatter_wide_kernel<P0, L, 512, 8, false>), 512); break;
+    case 4: PSA_SCATTER((radix_scatter_wide_kernel<P0, L, 1024, 8, false>), 1024); break;
+    default: PSA_SCATTER((radix_scatter_wide_kernel<P0, L, 1024, 8, true>), 1024); break;
+  }
+#undef PSA_SCATTER
+}
+
 }  // namespace
 
 extern "C" {
+
+int psa_sort_set_variant(int variant) {
+  const int prev = g_sort_variant;
+  g_sort_variant = variant;
+  return prev;
+}
 
 size_t psa_index_sort_workspace_bytes(int64_t n, int64_t max_value) {
   if (n <= 0) return 0;
@@ -325,6 +639,7 @@ int psa_index_sort(const int64_t* keys, int64_t n, int64_t max_value,
   const uint64_t* kin = reinterpret_cast<const uint64_t*>(keys);
   const uint32_t* iin = nullptr;
   const dim3 grid(static_cast<unsigned>(p.num_blocks)), block(kThreads);
+  const int variant = g_sort_variant & 15;
   for (int pass = 0; pass < p.passes; ++pass) {
     const int shift = 8 * pass;
     const bool last = pass == p.passes - 1;
@@ -335,15 +650,14 @@ int psa_index_sort(const int64_t* keys, int64_t n, int64_t max_value,
                        counts, digit_total, p.num_blocks);
     uint64_t* kout = last ? reinterpret_cast<uint64_t*>(sorted_out) : kbuf[pass & 1];
     uint32_t* iout = last ? nullptr : ibuf[pass & 1];
-#define PSA_SCATTER(P0, L)                                                      \
-  hipLaunchKernelGGL((radix_scatter_kernel<P0, L>), grid, block, 0, s, kin, iin, \
-                     kout, iout, perm_out, n, shift, p.tiles_per_block,          \
-                     p.num_blocks, counts)
-    if (pass == 0 && last) PSA_SCATTER(true, true);
-    else if (pass == 0) PSA_SCATTER(true, false);
-    else if (last) PSA_SCATTER(false, true);
-    else PSA_SCATTER(false, false);
-#undef PSA_SCATTER
+    if (pass == 0 && last)
+      launch_scatter<true, true>(variant, grid, s, kin, iin, kout, iout, perm_out, n, shift, p, counts);
+    else if (pass == 0)
+      launch_scatter<true, false>(variant, grid, s, kin, iin, kout, iout, perm_out, n, shift, p, counts);
+    else if (last)
+      launch_scatter<false, true>(variant, grid, s, kin, iin, kout, iout, perm_out, n, shift, p, counts);
+    else
+      launch_scatter<false, false>(variant, grid, s, kin, iin, kout, iout, perm_out, n, shift, p, counts);
     PSA_LAUNCH_CHECK();
     kin = kout;
     iin = iout;

@@ -48,6 +48,27 @@ def test_index_sort_heavy_duplicates_and_sorted_input():
     assert np.array_equal(perm.cpu().numpy(), so.index_sort(keys[::-1]))
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("n", [1, 2047, 4097, 300001, 3000001])
+def test_index_sort_scatter_variants(variant, n):
+    from paddle_sparse_amd import _lib, ops
+
+    keys = np.random.default_rng(n).integers(0, 1 << 37, n, dtype=np.int64)
+    keys[::7] = keys[0]  # duplicates exercise stability
+    prev = _lib.load().psa_sort_set_variant(variant)
+    try:
+        srt, perm = ops.index_sort(dev(keys), 1 << 37, with_sorted_inputs=True)
+        # unaligned key pointer (scalar histogram path)
+        buf = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+        buf[1:] = dev(keys)
+        _, perm_u = ops.index_sort(buf[1:], 1 << 37)
+    finally:
+        _lib.load().psa_sort_set_variant(prev)
+    ref = so.index_sort(keys)
+    assert np.array_equal(perm.cpu().numpy(), ref) and np.array_equal(srt.cpu().numpy(), keys[ref])
+    assert np.array_equal(perm_u.cpu().numpy(), ref)
+
+
 def test_index_sort_empty():
     from paddle_sparse_amd import ops
 
