@@ -104,12 +104,29 @@ spmm_value_bw_kernel(const int64_t* __restrict__ rowptr,
           for (int i = 0; i < VEC; ++i) dot[u] += b[u][i] * gt[i];
         }
       }
+      // Fold the U partial dots of this lane group together: each halving
+      // step sends the half a lane does not keep to its partner (xor bit), so
+      // U-1 + log2(LPR/U) shuffles replace U*log2(LPR).  Lane l ends up with
+      // the full dot of edge slot u = l % U.
+      static_assert((U & (U - 1)) == 0 && U <= LPR, "U must be a power of two <= LPR");
+      {
+        int cnt = U;
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        float p = dot[u];
+        for (int bit = 1; bit < U; bit <<= 1, cnt >>= 1) {
+          const bool up = (l & bit) != 0;
 #pragma unroll
-        for (int off = LPR / 2; off >= 1; off >>= 1) p += __shfl_xor(p, off);
-        if (l == 0 && ok[u]) out[base + j + u * G + g] = p / denom;
+          for (int i = 0; i < cnt / 2; ++i) {
+            const float keep = up ? dot[2 * i + 1] : dot[2 * i];
+            const float send = up ? dot[2 * i] : dot[2 * i + 1];
+            dot[i] = keep + __shfl_xor(send, bit);
+          }
+        }
+#pragma unroll
+        for (int bit = U; bit < LPR; bit <<= 1) dot[0] += __shfl_xor(dot[0], bit);
+      }
+      if (l < U) {
+        const int idx = j + l * G + g;
+        if (idx < n) out[base + idx] = dot[0] / denom;
       }
     }
   }
@@ -149,6 +166,67 @@ spmm_minmax_bw_kernel(const int64_t* __restrict__ col,
   const int64_t c = col[e];
   if (grad_value) atomicAdd(grad_value + e, mat[c * K + k] * g);
   if (grad_mat) atomicAdd(grad_mat + c * K + k, (value ? value[e] : 1.f) * g);
+}
+
+// Row-owned form of the same backward (K <= 64*KT): one wave per output row.
+// Every winning edge of row i belongs to row i only, so grad_value needs no
+// atomics: the wave walks its DISTINCT winners (ballot loop), folds the
+// contributions of the lanes that selected the same edge with shuffles and
+// stores gV[e] once (deterministic).  grad_mat still needs atomics (different
+// rows hit the same column) but now one atomic per (row, k) issued from
+// coalesced reads of arg_out / grad.  grad_value must be zero-filled before.
+template <int KT>
+__global__ void __launch_bounds__(kThreads)
+spmm_minmax_bw_row_kernel(const int64_t* __restrict__ col,
+                          const float* __restrict__ value,
+                          const float* __restrict__ mat,
+                          const float* __restrict__ grad,
+                          const int64_t* __restrict__ arg_out, int64_t M, int64_t K,
+                          int64_t nnz, float* __restrict__ grad_value,
+                          float* __restrict__ grad_mat) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * kWaves + wave;
+  if (row >= M) return;
+  int64_t a[KT];
+  float x[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) {
+    const int64_t k = lane + 64 * t;
+    a[t] = -1;
+    x[t] = 0.f;
+    if (k < K) {
+      const int64_t e = arg_out[row * K + k];
+      if (e != nnz) {
+        const int64_t c = col[e];
+        const float g = grad[row * K + k];
+        a[t] = e;
+        if (grad_value) x[t] = mat[c * K + k] * g;
+        if (grad_mat) atomicAdd(grad_mat + c * K + k, (value ? value[e] : 1.f) * g);
+      }
+    }
+  }
+  if (!grad_value) return;
+  unsigned long long pend[KT];
+#pragma unroll
+  for (int t = 0; t < KT; ++t) pend[t] = __ballot(a[t] >= 0);
+#pragma unroll
+  for (int t0 = 0; t0 < KT; ++t0) {
+    while (pend[t0]) {
+      const int src = __ffsll(static_cast<long long>(pend[t0])) - 1;
+      const int64_t e0 = __shfl(static_cast<long long>(a[t0]), src);
+      float v = 0.f;
+#pragma unroll
+      for (int t = 0; t < KT; ++t) {
+        const bool hit = a[t] == e0;
+        v += hit ? x[t] : 0.f;
+        pend[t] &= ~__ballot(hit);
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+      if (lane == 0) grad_value[e0] = v;
+    }
+  }
 }
 
 template <int VEC, int LPR, int U>
@@ -225,6 +303,20 @@ int psa_spmm_minmax_bw(const int64_t* col, const float* value, const float* mat,
   if (M * K == 0 || nnz == 0 || (!grad_value && !grad_mat)) return PSA_OK;
   PSA_REQUIRE(col && grad && arg_out, "NULL pointer");
   PSA_REQUIRE(!grad_value || mat, "mat needed for grad_value");
+  if (K <= 256) {  // row-owned kernel: no atomics on grad_value
+    const int64_t gx = psa::ceil_div(M, kWaves);
+    PSA_REQUIRE(gx <= 0x7fffffff, "M too large for one launch");
+    const dim3 grid(static_cast<unsigned>(gx)), block(kThreads);
+#define PSA_ROWBW(KT)                                                                  \
+  hipLaunchKernelGGL((spmm_minmax_bw_row_kernel<KT>), grid, block, 0, s, col, value, \
+                     mat, grad, arg_out, M, K, nnz, grad_value, grad_mat)
+    if (K <= 64) PSA_ROWBW(1);
+    else if (K <= 128) PSA_ROWBW(2);
+    else PSA_ROWBW(4);
+#undef PSA_ROWBW
+    PSA_LAUNCH_CHECK();
+    return PSA_OK;
+  }
   const int64_t blocks = psa::ceil_div(M * K, kThreads);
   PSA_REQUIRE(blocks <= 0x7fffffff, "M*K too large for one launch");
   hipLaunchKernelGGL(spmm_minmax_bw_kernel, dim3(static_cast<unsigned>(blocks)),

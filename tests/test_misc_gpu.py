@@ -84,13 +84,14 @@ def test_transposed_spmm_is_grad_mat(mean, has_value):
 
 
 @pytest.mark.parametrize("reduce", ["min", "max"])
-def test_spmm_minmax_bw(reduce):
+@pytest.mark.parametrize("K", [5, 48, 100, 128, 130, 256, 300])
+def test_spmm_minmax_bw(reduce, K):
     from paddle_sparse_amd import ops
 
-    row, rowptr, col, val = random_csr(400, 300, 5000, seed=8)
+    row, rowptr, col, val = skewed_csr(400, 300, seed=8 + K, long_rows=(0, 200), long_deg=300)
     rng = np.random.default_rng(1)
-    B = rng.standard_normal((300, 48)).astype(np.float32)
-    G = rng.standard_normal((400, 48)).astype(np.float32)
+    B = rng.standard_normal((300, K)).astype(np.float32)
+    G = rng.standard_normal((400, K)).astype(np.float32)
     _, arg = oracle.spmm(reduce, rowptr, col, val, B)
     gv, gm = ops.spmm_minmax_bw(dev(col), dev(val), dev(B), dev(G), dev(arg))
     rv, rm = oracle.spmm_minmax_bw(col, val, B, G, arg)
