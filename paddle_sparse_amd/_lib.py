@@ -9,6 +9,12 @@ import ctypes
 from ctypes import c_int, c_int64, c_size_t, c_void_p, c_char_p
 from pathlib import Path
 
+# The framework must bring its HIP runtime into the process FIRST: the core
+# only has a NEEDED entry for libamdhip64.so.7 and binds to the copy that is
+# already loaded.  Loaded the other way round, the process ends up with two
+# HIP runtimes and the core's launches see "no ROCm-capable device".
+import torch  # noqa: F401
+
 LIB_PATH = Path(__file__).resolve().parent / "lib" / "libpaddle_sparse_hip.so"
 
 SUM, MEAN, MIN, MAX = 0, 1, 2, 3
