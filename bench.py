@@ -249,7 +249,7 @@ def main() -> None:
                 "note": "value counts the all-gather of B inside every step; spmm_only_* is the "
                         "local-kernel rate with B already assembled",
             }
-        if not args.no_cpu and args.op == "spmm_sum":
+        if not args.no_cpu and args.op == "spmm_sum" and world == 1:  # CPU leg: N = 1 only
             info, ref, rows = cpu_baseline(rowptr, col, val, B_full)
             got = out[:rows].cpu().numpy()
             scale = np.abs(ref).max()
