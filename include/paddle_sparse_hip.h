@@ -160,6 +160,15 @@ int psa_index_sort(const int64_t* keys, int64_t n, int64_t max_value,
                    int64_t* sorted_out, int64_t* perm_out, void* workspace,
                    size_t workspace_bytes, psa_stream_t stream);
 
+/* Same sort carrying a caller-defined 4-byte payload per key instead of the
+ * permutation: payload_out[i] = payload[perm[i]] (any 4-byte dtype: fp32 /
+ * int32 values of a COO matrix).  Lets coalesce (storage.py:164-169 + :471)
+ * keep `value[perm]` a sequential stream instead of a random gather.
+ * sorted_out is required.  Workspace as psa_index_sort. */
+int psa_sort_pairs_u32(const int64_t* keys, const void* payload, int64_t n,
+                       int64_t max_value, int64_t* sorted_out, void* payload_out,
+                       void* workspace, size_t workspace_bytes, psa_stream_t stream);
+
 /* Test/bench hook: scatter kernel variant of psa_index_sort for this process
  * (0 = production: 8192-key tile reordered in LDS, 1024 threads; 1 = 2048-key
  * LDS tile; 2 = direct per-lane stores; 3 / 4 = 4096- / 8192-key tile with

@@ -25,16 +25,22 @@ def _coalesce_sorted_stream(row, col, value, m: int, n: int, op: str):
         return row, col, value
     keys, unsorted = ops.make_keys(row, col, n, check_sorted=True)
     perm = None
-    if int(unsorted.item()):
-        keys, perm = ops.index_sort(keys, m * n, with_sorted_inputs=True)
+    was_sorted = not int(unsorted.item())
+    if not was_sorted:
+        if value is not None and value.dim() == 1 and value.element_size() == 4:
+            # 4-byte scalar values ride through the sort as the payload: the
+            # reduce below then reads them as a stream, not as value[perm[i]]
+            keys, value = ops.sort_pairs(keys, value, m * n)
+        else:
+            keys, perm = ops.index_sort(keys, m * n, with_sorted_inputs=True)
     count, ptr, new_row, new_col = ops.unique_sorted(keys, n)
-    if count == nnz and perm is None:
+    if count == nnz and was_sorted:
         return row, col, value  # sorted and duplicate-free already
     if value is not None:
-        if count == nnz:
-            value = ops.gather_rows(value, perm)
-        else:
+        if count < nnz:
             value = ops.segment_csr(value, ptr, op, perm=perm)
+        elif perm is not None:
+            value = ops.gather_rows(value, perm)
     return new_row, new_col, value
 
 

@@ -600,30 +600,29 @@ size_t psa_index_sort_workspace_bytes(int64_t n, int64_t max_value) {
   return make_plan(n, max_value).total_bytes;
 }
 
-int psa_index_sort(const int64_t* keys, int64_t n, int64_t max_value,
-                   int64_t* sorted_out, int64_t* perm_out, void* workspace,
-                   size_t workspace_bytes, psa_stream_t stream) {
-  PSA_REQUIRE(n >= 0, "negative size");
-  if (n == 0) return PSA_OK;
-  PSA_REQUIRE(keys != nullptr && perm_out != nullptr, "keys/perm_out is NULL");
-  PSA_REQUIRE(max_value >= 0, "max_value must be >= 0");
-  if (n >= (1ll << 31)) {
-    psa::set_error("psa_index_sort: n >= 2^31 not supported by this build");
-    return PSA_ERR_UNSUPPORTED;
-  }
-  hipStream_t s = psa::as_stream(stream);
+// Shared driver.  perm mode: pay_in == NULL (payload = element index),
+// perm_out int64.  pairs mode: pay_in / pay_out carry a caller-defined 32-bit
+// payload (e.g. the fp32 value of a COO entry) and perm_out is NULL.
+static int sort_impl(const char* who, const int64_t* keys, const uint32_t* pay_in,
+                     int64_t n, int64_t max_value, int64_t* sorted_out,
+                     int64_t* perm_out, uint32_t* pay_out, void* workspace,
+                     size_t workspace_bytes, hipStream_t s) {
   const SortPlan p = make_plan(n, max_value);
-  if (p.passes == 0) {  // all keys equal: the stable permutation is identity
-    hipLaunchKernelGGL(iota_kernel, dim3(static_cast<unsigned>(psa::ceil_div(n, kThreads))),
-                       dim3(kThreads), 0, s, perm_out, n);
-    PSA_LAUNCH_CHECK();
+  if (p.passes == 0) {  // all keys equal: the stable order is the input order
+    if (perm_out) {
+      hipLaunchKernelGGL(iota_kernel, dim3(static_cast<unsigned>(psa::ceil_div(n, kThreads))),
+                         dim3(kThreads), 0, s, perm_out, n);
+      PSA_LAUNCH_CHECK();
+    } else {
+      PSA_HIP(hipMemcpyAsync(pay_out, pay_in, sizeof(uint32_t) * n, hipMemcpyDeviceToDevice, s));
+    }
     if (sorted_out)
       PSA_HIP(hipMemcpyAsync(sorted_out, keys, sizeof(int64_t) * n,
                              hipMemcpyDeviceToDevice, s));
     return PSA_OK;
   }
   if (workspace == nullptr || workspace_bytes < p.total_bytes) {
-    psa::set_error("psa_index_sort: workspace too small (need " +
+    psa::set_error(std::string(who) + ": workspace too small (need " +
                    std::to_string(p.total_bytes) + " bytes)");
     return PSA_ERR_WORKSPACE;
   }
@@ -637,24 +636,26 @@ int psa_index_sort(const int64_t* keys, int64_t n, int64_t max_value,
   uint32_t* digit_total = counts + static_cast<size_t>(kRadix) * p.num_blocks;
 
   const uint64_t* kin = reinterpret_cast<const uint64_t*>(keys);
-  const uint32_t* iin = nullptr;
+  const uint32_t* iin = pay_in;
   const dim3 grid(static_cast<unsigned>(p.num_blocks)), block(kThreads);
   const int variant = g_sort_variant & 15;
   for (int pass = 0; pass < p.passes; ++pass) {
     const int shift = 8 * pass;
     const bool last = pass == p.passes - 1;
+    const bool iota_payload = pass == 0 && pay_in == nullptr;
+    const bool widen = last && perm_out != nullptr;  // int64 permutation output
     PSA_HIP(hipMemsetAsync(digit_total, 0, sizeof(uint32_t) * kRadix, s));
     hipLaunchKernelGGL(radix_hist_kernel, grid, block, 0, s, kin, n, shift,
                        p.tiles_per_block, p.num_blocks, counts, digit_total);
     hipLaunchKernelGGL(radix_scan_kernel, dim3(kRadix / kWaves), block, 0, s,
                        counts, digit_total, p.num_blocks);
     uint64_t* kout = last ? reinterpret_cast<uint64_t*>(sorted_out) : kbuf[pass & 1];
-    uint32_t* iout = last ? nullptr : ibuf[pass & 1];
-    if (pass == 0 && last)
+    uint32_t* iout = last ? pay_out : ibuf[pass & 1];
+    if (iota_payload && widen)
       launch_scatter<true, true>(variant, grid, s, kin, iin, kout, iout, perm_out, n, shift, p, counts);
-    else if (pass == 0)
+    else if (iota_payload)
       launch_scatter<true, false>(variant, grid, s, kin, iin, kout, iout, perm_out, n, shift, p, counts);
-    else if (last)
+    else if (widen)
       launch_scatter<false, true>(variant, grid, s, kin, iin, kout, iout, perm_out, n, shift, p, counts);
     else
       launch_scatter<false, false>(variant, grid, s, kin, iin, kout, iout, perm_out, n, shift, p, counts);
@@ -663,6 +664,38 @@ int psa_index_sort(const int64_t* keys, int64_t n, int64_t max_value,
     iin = iout;
   }
   return PSA_OK;
+}
+
+int psa_index_sort(const int64_t* keys, int64_t n, int64_t max_value,
+                   int64_t* sorted_out, int64_t* perm_out, void* workspace,
+                   size_t workspace_bytes, psa_stream_t stream) {
+  PSA_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return PSA_OK;
+  PSA_REQUIRE(keys != nullptr && perm_out != nullptr, "keys/perm_out is NULL");
+  PSA_REQUIRE(max_value >= 0, "max_value must be >= 0");
+  if (n >= (1ll << 31)) {
+    psa::set_error("psa_index_sort: n >= 2^31 not supported by this build");
+    return PSA_ERR_UNSUPPORTED;
+  }
+  return sort_impl("psa_index_sort", keys, nullptr, n, max_value, sorted_out, perm_out,
+                   nullptr, workspace, workspace_bytes, psa::as_stream(stream));
+}
+
+int psa_sort_pairs_u32(const int64_t* keys, const void* payload, int64_t n,
+                       int64_t max_value, int64_t* sorted_out, void* payload_out,
+                       void* workspace, size_t workspace_bytes, psa_stream_t stream) {
+  PSA_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return PSA_OK;
+  PSA_REQUIRE(keys && payload && sorted_out && payload_out, "NULL pointer");
+  PSA_REQUIRE(max_value >= 0, "max_value must be >= 0");
+  PSA_REQUIRE(psa::aligned(payload, 4) && psa::aligned(payload_out, 4), "payload must be 4-byte aligned");
+  if (n >= (1ll << 31)) {
+    psa::set_error("psa_sort_pairs_u32: n >= 2^31 not supported by this build");
+    return PSA_ERR_UNSUPPORTED;
+  }
+  return sort_impl("psa_sort_pairs_u32", keys, static_cast<const uint32_t*>(payload), n,
+                   max_value, sorted_out, nullptr, static_cast<uint32_t*>(payload_out),
+                   workspace, workspace_bytes, psa::as_stream(stream));
 }
 
 }  // extern "C"

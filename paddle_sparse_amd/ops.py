@@ -165,6 +165,29 @@ def index_sort(keys: torch.Tensor, max_value: Optional[int] = None,
     return out, perm
 
 
+def sort_pairs(keys: torch.Tensor, payload: torch.Tensor, max_value: Optional[int] = None
+               ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Stable sort of (key, 4-byte payload) pairs: returns (sorted_keys,
+    payload[perm]) without ever forming perm.  payload: 1-D, 4-byte dtype."""
+    keys = _index(keys, "keys")
+    _gpu(payload, "payload")
+    if payload.dim() != 1 or payload.element_size() != 4 or payload.numel() != keys.numel():
+        raise ValueError("payload must be 1-D, 4 bytes per element, same length as keys")
+    payload = payload.contiguous()
+    n = keys.numel()
+    if max_value is None:
+        max_value = (int(keys.max()) + 1) if n else 1
+    max_value = max(int(max_value), 1)
+    out_keys = torch.empty_like(keys)
+    out_pay = torch.empty_like(payload)
+    lib = _lib.load()
+    ws = _workspace(lib.psa_index_sort_workspace_bytes(n, max_value), keys.device)
+    with torch.cuda.device(keys.device):
+        check(lib.psa_sort_pairs_u32(_ptr(keys), _ptr(payload), n, max_value, _ptr(out_keys),
+                                     _ptr(out_pay), _ptr(ws), ws.numel(), _stream()))
+    return out_keys, out_pay
+
+
 def make_keys(a: torch.Tensor, b: torch.Tensor, mul: int, check_sorted: bool = False
               ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """keys = a * mul + b  (+ device flag "some key is smaller than its

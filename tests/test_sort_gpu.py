@@ -69,6 +69,20 @@ def test_index_sort_scatter_variants(variant, n):
     assert np.array_equal(perm_u.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("n,max_value", [(1, 5), (5000, 1), (100000, 1 << 20), (2000003, 1 << 44)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.int32])
+def test_sort_pairs_matches_perm_gather(n, max_value, dtype):
+    from paddle_sparse_amd import ops
+
+    rng = np.random.default_rng(n)
+    keys = rng.integers(0, max_value, n, dtype=np.int64)
+    pay = torch.from_numpy(rng.integers(-1000, 1000, n).astype(np.int32)).cuda().to(dtype)
+    skeys, spay = ops.sort_pairs(dev(keys), pay, max_value)
+    ref = so.index_sort(keys)
+    assert np.array_equal(skeys.cpu().numpy(), keys[ref])
+    assert torch.equal(spay.cpu(), pay.cpu()[torch.from_numpy(ref)])
+
+
 def test_index_sort_empty():
     from paddle_sparse_amd import ops
 

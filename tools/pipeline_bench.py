@@ -91,6 +91,10 @@ t_sort, (skeys, perm) = timed(lambda: ops.index_sort(keys, N * N, with_sorted_in
 t_uniq, (cnt, ptr, r2, c2) = timed(lambda: ops.unique_sorted(skeys, N))
 t_seg, _ = timed(lambda: ops.segment_csr(val, ptr, "add", perm=perm))
 t_i2p, _ = timed(lambda: ops.ind2ptr(r2, N))
+t_pairs, (_, sval) = timed(lambda: ops.sort_pairs(keys, val, N * N))
+t_seg2, _ = timed(lambda: ops.segment_csr(sval, ptr, "add"))
+print(f"  (production path for fp32 scalar values: sort_pairs {t_pairs:.3f} ms + segment_csr {t_seg2:.3f} ms; "
+      f"the two lines index_sort / segment_csr(perm) below are the generic-dtype path)")
 passes = (2 * args.scale + 7) // 8
 floor_bytes = n * (8 + 8 + 4) + nnz2 * (8 + 8 + 4) + nnz2 * 8 + (N + 1) * 8
 radix_bytes = n * 24 + n * (32 * passes - 4) + n * 16 + n * (8 + 4 + 64) + nnz2 * 28 + nnz2 * 8 + (N + 1) * 8
