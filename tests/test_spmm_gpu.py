@@ -120,6 +120,22 @@ def test_variants_k128(variant):
         ops.spmm_set_variant(prev)
 
 
+@pytest.mark.parametrize("variant", [0, 1, 7])
+@pytest.mark.parametrize("K", [4, 8, 12, 16, 32, 48, 64, 128, 200, 256])
+def test_multirow_variants_narrow_k(variant, K):
+    from paddle_sparse_amd import ops
+
+    row, rowptr, col, val = skewed_csr(1000, 700, seed=K, long_rows=(0, 500, 999), long_deg=300)
+    B = np.random.default_rng(K).standard_normal((700, K)).astype(np.float32)
+    prev = ops.spmm_set_variant(variant)
+    try:
+        for reduce in ("sum", "mean", "min", "max"):
+            check(reduce, rowptr, col, val, B)
+        check("sum", rowptr, col, None, B)
+    finally:
+        ops.spmm_set_variant(prev)
+
+
 def test_config2_shape_vs_oracle():
     """BASELINE config 2: CSR 100k x 100k, nnz = 1M, F = 64."""
     M = N = 100_000
