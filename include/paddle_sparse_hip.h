@@ -170,10 +170,10 @@ int psa_sort_pairs_u32(const int64_t* keys, const void* payload, int64_t n,
                        void* workspace, size_t workspace_bytes, psa_stream_t stream);
 
 /* Test/bench hook: scatter kernel variant of psa_index_sort for this process
- * (0 = production: 8192-key tile reordered in LDS, 1024 threads; 1 = 2048-key
- * LDS tile; 2 = direct per-lane stores; 3 / 4 = 4096- / 8192-key tile with
- * separate key and index LDS buffers).  Returns the previous value.  All
- * variants produce the same bits. */
+ * (0 = production: single-sweep passes with decoupled look-back, 512 threads x
+ * 16 keys; 5 = the same with 1024 x 8; 1-4, 7 = histogram / scan / scatter
+ * per pass with 2048-key LDS tile, direct per-lane stores, 4096- / 8192-key
+ * tiles).  Returns the previous value.  All variants produce the same bits. */
 int psa_sort_set_variant(int variant);
 
 /* keys[i] = a[i] * mul + b[i]  (storage.py:159-162 key = row*N + col,

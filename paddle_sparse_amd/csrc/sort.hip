@@ -527,12 +527,223 @@ iota_kernel(int64_t* __restrict__ out, int64_t n) {
   if (i < n) out[i] = i;
 }
 
+// ===========================================================================
+// Single-sweep passes (variant 5): the per-pass histogram kernel disappears.
+//   os_hist_kernel   ONE read of the keys builds the 256-bin histograms of all
+//                    passes; os_scan_kernel turns them into digit bases.
+//   os_pass_kernel   tiles are handed out in order by an atomic ticket; a tile
+//                    publishes its 256 digit counts, then walks back over its
+//                    predecessors' published words until it meets an inclusive
+//                    prefix (decoupled look-back).
+// Inter-workgroup words follow the guide's granule rule (MI355X_MICROARCH.md
+// "Valid forms", cdna_hip_programming.md Guideline 16 R2): ONE naturally
+// aligned 8-byte word {pass-tagged flag, value} per (tile, digit), written by
+// one relaxed agent-scope atomic store (sc1) and polled with relaxed
+// agent-scope atomic loads — flag and payload cannot be seen torn or stale
+// apart, so no fence is needed.  Tickets come from an atomic counter, so every
+// predecessor of a running tile is itself running: waits always end.  Spins
+// are bounded anyway (err word) so a bug cannot hang the GPU.
+// ===========================================================================
+constexpr int kOsThreads = 1024;
+constexpr int kOsItems = 8;
+constexpr int kOsTile = kOsThreads * kOsItems;  // 8192 keys
+constexpr int kOsMaxPasses = 8;
+constexpr uint32_t kOsSpinLimit = 1u << 22;
+
+__device__ __forceinline__ uint64_t os_pack(uint32_t flag, uint32_t value) {
+  return (static_cast<uint64_t>(flag) << 32) | value;
+}
+
+__global__ void __launch_bounds__(kThreads)
+os_hist_kernel(const uint64_t* __restrict__ keys, int64_t n, int passes,
+               uint32_t* __restrict__ ghist /*[kOsMaxPasses][256]*/) {
+  __shared__ uint32_t hist[kOsMaxPasses][kRadix];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < kOsMaxPasses * kRadix; i += kThreads) (&hist[0][0])[i] = 0;
+  __syncthreads();
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + tid; i < n; i += stride) {
+    const uint64_t k = keys[i];
+    for (int p = 0; p < passes; ++p) atomicAdd(&hist[p][digit_of(k, 8 * p)], 1u);
+  }
+  __syncthreads();
+  for (int i = tid; i < passes * kRadix; i += kThreads) {
+    const uint32_t c = (&hist[0][0])[i];
+    if (c) atomicAdd(ghist + i, c);
+  }
+}
+
+// one block (256 threads) per pass: exclusive scan of its 256 bins
+__global__ void __launch_bounds__(kThreads)
+os_scan_kernel(const uint32_t* __restrict__ ghist, uint32_t* __restrict__ gbase) {
+  __shared__ uint32_t wtot[kWaves];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint32_t c = ghist[blockIdx.x * kRadix + tid];
+  uint32_t incl = c;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_up(incl, off);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) wtot[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < wave; ++w) base += wtot[w];
+  gbase[blockIdx.x * kRadix + tid] = base + incl - c;
+}
+
+template <bool PASS0, bool LAST, int THREADS, int ITEMS>
+__global__ void __launch_bounds__(THREADS)
+os_pass_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
+               uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
+               int64_t* __restrict__ perm_out, int64_t n, int shift, int pass,
+               const uint32_t* __restrict__ gbase /*this pass: [256]*/,
+               uint64_t* __restrict__ status /*[num_tiles][256]*/,
+               uint32_t* __restrict__ ticket, uint32_t* __restrict__ err) {
+  constexpr int WAVES = THREADS / 64;
+  constexpr int TILE = THREADS * ITEMS;
+  static_assert(TILE == kOsTile, "status words are indexed by 8192-key tiles");
+  __shared__ uint64_t skey[TILE];
+  __shared__ uint32_t wcnt[WAVES][kRadix];
+  __shared__ int32_t gofs[kRadix];
+  __shared__ uint32_t wave_tot[4];
+  __shared__ uint32_t s_tile;
+  uint32_t* sidx = reinterpret_cast<uint32_t*>(skey);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const uint32_t flag_agg = 2u * pass + 1u;   // pass-tagged: words of earlier
+  const uint32_t flag_incl = 2u * pass + 2u;  // passes read as "not ready"
+
+  if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+  for (int i = tid; i < WAVES * kRadix; i += THREADS) (&wcnt[0][0])[i] = 0;
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const int64_t tile_begin = static_cast<int64_t>(tile) * TILE;
+  if (tile_begin >= n) return;  // block-uniform
+  const int tile_n = (n - tile_begin) < TILE ? static_cast<int>(n - tile_begin) : TILE;
+
+  uint64_t key[ITEMS];
+  uint32_t idx[ITEMS];
+  uint32_t rank[ITEMS];
+  const int wbase = wave * (ITEMS * 64);
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int p = wbase + i * 64 + lane;
+    const bool valid = p < tile_n;
+    key[i] = valid ? keys_in[tile_begin + p] : ~0ull;
+    if (PASS0) idx[i] = static_cast<uint32_t>(tile_begin + p);
+    else idx[i] = valid ? idx_in[tile_begin + p] : 0u;
+  }
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const bool valid = wbase + i * 64 + lane < tile_n;
+    const unsigned d = digit_of(key[i], shift);
+    rank[i] = wave_rank(wcnt[wave], d, valid, wave_match(d, valid));
+  }
+  __syncthreads();
+  uint32_t tot = 0, incl = 0;
+  uint64_t* my_status = status + static_cast<size_t>(tile) * kRadix + tid;
+  if (tid < kRadix) {
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+      const uint32_t c = wcnt[w][tid];
+      wcnt[w][tid] = tot;
+      tot += c;
+    }
+    // publish this tile's count of digit `tid` as early as possible
+    __hip_atomic_store(my_status, os_pack(tile == 0 ? flag_incl : flag_agg, tot),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    incl = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+  }
+  __syncthreads();
+  uint32_t dstart = 0;
+  if (tid < kRadix) {
+    uint32_t wprefix = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) wprefix += w < wave ? wave_tot[w] : 0u;
+    dstart = wprefix + incl - tot;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) wcnt[w][tid] += dstart;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    if (wbase + i * 64 + lane < tile_n) {
+      rank[i] += wcnt[wave][digit_of(key[i], shift)];
+      skey[rank[i]] = key[i];
+    }
+  }
+  if (tid < kRadix) {
+    // decoupled look-back: sum predecessors' counts of digit `tid` until one of
+    // them already carries its inclusive prefix
+    uint32_t excl = 0;
+    if (tile > 0) {
+      int64_t t = static_cast<int64_t>(tile) - 1;
+      uint32_t spins = 0;
+      while (t >= 0) {
+        const uint64_t w = __hip_atomic_load(status + static_cast<size_t>(t) * kRadix + tid,
+                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t f = static_cast<uint32_t>(w >> 32);
+        if (f == flag_incl) {
+          excl += static_cast<uint32_t>(w);
+          break;
+        }
+        if (f == flag_agg) {
+          excl += static_cast<uint32_t>(w);
+          --t;
+          continue;
+        }
+        if (++spins > kOsSpinLimit) {  // never expected; keeps a bug from hanging the GPU
+          atomicExch(err, 1u);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      __hip_atomic_store(my_status, os_pack(flag_incl, excl + tot), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    gofs[tid] = static_cast<int32_t>(gbase[tid] + excl) - static_cast<int32_t>(dstart);
+  }
+  __syncthreads();
+  uint32_t dst[ITEMS];
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) {
+    const int p = tid + j * THREADS;
+    if (p < tile_n) {
+      const uint64_t k = skey[p];
+      dst[j] = static_cast<uint32_t>(gofs[digit_of(k, shift)] + p);
+      if (!LAST || keys_out) keys_out[dst[j]] = k;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i)
+    if (wbase + i * 64 + lane < tile_n) sidx[rank[i]] = idx[i];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < ITEMS; ++j) {
+    const int p = tid + j * THREADS;
+    if (p < tile_n) {
+      if (LAST) perm_out[dst[j]] = static_cast<int64_t>(sidx[p]);
+      else idx_out[dst[j]] = sidx[p];
+    }
+  }
+}
+
 struct SortPlan {
   int passes;
   int64_t num_tiles;
   int tiles_per_block;
   int num_blocks;
-  size_t keys_bytes, idx_bytes, counts_bytes, total_bytes;
+  size_t keys_bytes, idx_bytes, counts_bytes, os_bytes, total_bytes;
 };
 
 int bits_for(int64_t max_value) {
@@ -563,7 +774,11 @@ SortPlan make_plan(int64_t n, int64_t max_value) {
   p.idx_bytes = align_up(sizeof(uint32_t) * static_cast<size_t>(n), 256);
   p.counts_bytes =
       align_up(sizeof(uint32_t) * kRadix * (static_cast<size_t>(p.num_blocks) + 8), 256);
-  p.total_bytes = 2 * p.keys_bytes + 2 * p.idx_bytes + p.counts_bytes;
+  // single-sweep area: status words, histograms / bases of all passes, tickets, err
+  const size_t os_tiles = static_cast<size_t>(psa::ceil_div(n > 0 ? n : 1, kOsTile));
+  p.os_bytes = align_up(os_tiles * kRadix * sizeof(uint64_t), 256) +
+               align_up(2 * kOsMaxPasses * kRadix * sizeof(uint32_t), 256) + 256;
+  p.total_bytes = 2 * p.keys_bytes + 2 * p.idx_bytes + p.counts_bytes + p.os_bytes;
   return p;
 }
 
@@ -639,6 +854,55 @@ static int sort_impl(const char* who, const int64_t* keys, const uint32_t* pay_i
   const uint32_t* iin = pay_in;
   const dim3 grid(static_cast<unsigned>(p.num_blocks)), block(kThreads);
   const int variant = g_sort_variant & 15;
+
+  // 0 (production) and 5: single-sweep passes with decoupled look-back
+  // (0: 512 threads x 16 keys, two blocks per CU; 5: 1024 x 8, one block);
+  // 1-4, 7: the three-launch-per-pass family, kept for A/B.
+  if (variant == 0 || variant == 5) {
+    char* os = ws + 2 * p.keys_bytes + 2 * p.idx_bytes + p.counts_bytes;
+    const size_t os_tiles = static_cast<size_t>(psa::ceil_div(n, kOsTile));
+    const size_t status_bytes = align_up(os_tiles * kRadix * sizeof(uint64_t), 256);
+    uint64_t* status = reinterpret_cast<uint64_t*>(os);
+    uint32_t* ghist = reinterpret_cast<uint32_t*>(os + status_bytes);
+    uint32_t* gbase_all = ghist + kOsMaxPasses * kRadix;
+    uint32_t* tickets = gbase_all + kOsMaxPasses * kRadix;  // [kOsMaxPasses] + err word
+    uint32_t* err = tickets + kOsMaxPasses;
+    PSA_HIP(hipMemsetAsync(os, 0, p.os_bytes, s));
+    const int hist_blocks = static_cast<int>(psa::ceil_div(n, kThreads * 16) < 2048
+                                                 ? psa::ceil_div(n, kThreads * 16) : 2048);
+    hipLaunchKernelGGL(os_hist_kernel, dim3(hist_blocks), block, 0, s, kin, n, p.passes, ghist);
+    hipLaunchKernelGGL(os_scan_kernel, dim3(p.passes), block, 0, s, ghist, gbase_all);
+    const bool narrow = variant == 0;  // 512 threads x 16 keys, 2 blocks / CU
+    const dim3 os_grid(static_cast<unsigned>(os_tiles)), os_block(narrow ? 512 : 1024);
+    for (int pass = 0; pass < p.passes; ++pass) {
+      const int shift = 8 * pass;
+      const bool last = pass == p.passes - 1;
+      const bool iota_payload = pass == 0 && pay_in == nullptr;
+      const bool widen = last && perm_out != nullptr;
+      uint64_t* kout = last ? reinterpret_cast<uint64_t*>(sorted_out) : kbuf[pass & 1];
+      uint32_t* iout = last ? pay_out : ibuf[pass & 1];
+#define PSA_OS1(P0, L, T, I)                                                                  \
+  hipLaunchKernelGGL((os_pass_kernel<P0, L, T, I>), os_grid, os_block, 0, s, kin, iin, kout, \
+                     iout, perm_out, n, shift, pass, gbase_all + pass * kRadix, status,      \
+                     tickets + pass, err)
+#define PSA_OS(P0, L)                          \
+  do {                                         \
+    if (narrow) PSA_OS1(P0, L, 512, 16);       \
+    else PSA_OS1(P0, L, 1024, 8);              \
+  } while (0)
+      if (iota_payload && widen) PSA_OS(true, true);
+      else if (iota_payload) PSA_OS(true, false);
+      else if (widen) PSA_OS(false, true);
+      else PSA_OS(false, false);
+#undef PSA_OS
+#undef PSA_OS1
+      PSA_LAUNCH_CHECK();
+      kin = kout;
+      iin = iout;
+    }
+    return PSA_OK;
+  }
+
   for (int pass = 0; pass < p.passes; ++pass) {
     const int shift = 8 * pass;
     const bool last = pass == p.passes - 1;

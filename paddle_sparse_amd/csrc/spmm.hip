@@ -372,6 +372,8 @@ int psa_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
     if (q <= 8) PSA_ROW(4, 8, 1);
     if (q <= 16) PSA_ROW(4, 16, 2);
     if (q <= 32) PSA_ROW(4, 32, 4);
+    if (g_variant == 8) PSA_ROW(4, 64, 16);
+    if (g_variant == 9) PSA_ROW(4, 64, 4);
     PSA_ROW(4, 64, 8);
   }
   if (K <= 4) PSA_ROW(1, 4, 1);

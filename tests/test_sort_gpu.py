@@ -48,7 +48,7 @@ def test_index_sort_heavy_duplicates_and_sorted_input():
     assert np.array_equal(perm.cpu().numpy(), so.index_sort(keys[::-1]))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 7])
 @pytest.mark.parametrize("n", [1, 2047, 4097, 300001, 3000001])
 def test_index_sort_scatter_variants(variant, n):
     from paddle_sparse_amd import _lib, ops
@@ -81,6 +81,37 @@ def test_sort_pairs_matches_perm_gather(n, max_value, dtype):
     ref = so.index_sort(keys)
     assert np.array_equal(skeys.cpu().numpy(), keys[ref])
     assert torch.equal(spay.cpu(), pay.cpu()[torch.from_numpy(ref)])
+
+
+def test_single_sweep_lookback_under_uneven_load():
+    """The production sort hands digit counts between workgroups inside one
+    launch (decoupled look-back).  Exercise it with a second stream keeping the
+    chip busy, odd sizes, sorted and half-constant inputs; every element must
+    match torch.sort(stable=True)."""
+    from paddle_sparse_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(0)
+    M = 200_000
+    row = torch.sort(torch.randint(0, M, (2_000_000,), generator=g, device="cuda"))[0]
+    rowptr = ops.ind2ptr(row, M)
+    col = torch.randint(0, M, (2_000_000,), generator=g, device="cuda")
+    B = torch.randn(M, 64, device="cuda")
+    side = torch.cuda.Stream()
+    for rep in range(3):
+        for n in (8191, 8193, 100_003, 2_500_000, 9_000_001):
+            for bits in (8, 9, 33, 48):
+                keys = torch.randint(0, 1 << bits, (n,), generator=g, device="cuda")
+                if rep == 1:
+                    keys = torch.sort(keys)[0]
+                if rep == 2:
+                    keys[: n // 2] = keys[0]
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        ops.spmm_sum(rowptr, col, None, B)
+                srt, perm = ops.index_sort(keys, 1 << bits, with_sorted_inputs=True)
+                ts, tp = torch.sort(keys, stable=True)
+                assert torch.equal(srt, ts) and torch.equal(perm, tp), (rep, n, bits)
+    torch.cuda.synchronize()
 
 
 def test_index_sort_empty():
