@@ -44,6 +44,19 @@ def _coalesce_sorted_stream(row, col, value, m: int, n: int, op: str):
     return new_row, new_col, value
 
 
+def _stack_index(row: torch.Tensor, col: torch.Tensor) -> torch.Tensor:
+    """stack([row, col]) (coalesce.py:29) without the copy when row and col are
+    already the two rows of one [2, nnz] buffer (ops.unique_sorted writes them
+    that way)."""
+    base = row._base
+    if (base is not None and base is col._base and base.dim() == 2 and base.shape[0] == 2
+            and base.is_contiguous() and row.numel() == base.shape[1]
+            and row.data_ptr() == base.data_ptr()
+            and col.data_ptr() == base.data_ptr() + base.shape[1] * base.element_size()):
+        return base
+    return torch.stack([row, col], dim=0)
+
+
 def coalesce(index: torch.Tensor, value: Optional[torch.Tensor], m: int, n: int,
              op: str = "add") -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """Row-wise sorts `index` and merges duplicate entries with `op`
@@ -53,4 +66,4 @@ def coalesce(index: torch.Tensor, value: Optional[torch.Tensor], m: int, n: int,
     if value is not None:
         assert value.shape[0] == col.numel()
     row, col, value = _coalesce_sorted_stream(row, col, value, m, n, op)
-    return torch.stack([row, col], dim=0), value
+    return _stack_index(row, col), value

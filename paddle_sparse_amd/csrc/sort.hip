@@ -5,8 +5,13 @@
 // key width, so only ceil(log2(max_value)/8) 8-bit passes run: 6 for the
 // 2^24 x 2^24 matrices of BASELINE config 5 instead of 8.
 //
-// Per pass (classic histogram / scan / scatter with a fixed grid, no
-// inter-workgroup hand-off inside a launch):
+// PRODUCTION PATH (variant 0): single-sweep passes, see the block comment above
+// os_hist_kernel — one key read builds every pass's histogram, each pass is one
+// launch with decoupled look-back.  100 M 48-bit keys: 4.1 ms (rocPRIM
+// onesweep through torch.sort: 8.2 ms).
+//
+// A/B FAMILY (variants 1-4, 7), three launches per pass (histogram / scan /
+// scatter with a fixed grid, no inter-workgroup hand-off inside a launch):
 //   1. radix_hist_kernel    every block counts the digits of its contiguous
 //                           key range (16-B loads, LDS histogram per wave)
 //   2. radix_scan_kernel    one wave per digit: exclusive scan of the counts
@@ -15,7 +20,7 @@
 //                           get their stable rank inside the tile from
 //                           wave-wide digit matching (8 ballots), the block's
 //                           256 running offsets live in LDS.
-//      wide (default)   : 1024 threads x 8 keys = 8192-key tile, reordered in
+//      wide (variant 7) : 1024 threads x 8 keys = 8192-key tile, reordered in
 //                         LDS so every store instruction writes contiguous
 //                         runs (32 keys per digit on average); ONE resident
 //                         block per CU, so the 512 open output lines of all

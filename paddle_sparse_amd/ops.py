@@ -267,8 +267,11 @@ def unique_sorted(sorted_keys: torch.Tensor, N: int, want_ptr: bool = True,
         check(lib.psa_unique_count(_ptr(sorted_keys), n, _ptr(ws), ws.numel(), _ptr(count_d), _stream()))
         count = int(count_d.item())
         ptr = torch.empty(count + 1, dtype=torch.int64, device=dev) if want_ptr else None
-        row = torch.empty(count, dtype=torch.int64, device=dev) if want_rowcol else None
-        col = torch.empty(count, dtype=torch.int64, device=dev) if want_rowcol else None
+        # row and col are the two rows of ONE [2, count] buffer, so the
+        # functional API's `stack([row, col])` (coalesce.py:29) is `row._base`
+        index = torch.empty((2, count), dtype=torch.int64, device=dev) if want_rowcol else None
+        row = index[0] if want_rowcol else None
+        col = index[1] if want_rowcol else None
         if n > 0 and (want_ptr or want_rowcol):
             check(lib.psa_unique_write(_ptr(sorted_keys), n, int(N), _ptr(ws), _ptr(count_d),
                                        _ptr(ptr), _ptr(row), _ptr(col), _stream()))

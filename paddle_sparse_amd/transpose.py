@@ -4,7 +4,7 @@ from __future__ import annotations
 import torch
 
 from . import ops
-from .coalesce import _coalesce_sorted_stream
+from .coalesce import _coalesce_sorted_stream, _stack_index
 from .storage import SparseStorage
 from .tensor import SparseTensor
 
@@ -42,4 +42,4 @@ def transpose(index, value, m, n, coalesced=True):
     row, col = index[1].contiguous(), index[0].contiguous()
     if coalesced:
         row, col, value = _coalesce_sorted_stream(row, col, value, n, m, "add")
-    return torch.stack([row, col], dim=0), value
+    return _stack_index(row, col), value
