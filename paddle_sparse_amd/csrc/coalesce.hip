@@ -310,7 +310,7 @@ int psa_unique_count(const int64_t* sorted_keys, int64_t n, void* workspace,
   PSA_REQUIRE(count_out != nullptr, "count_out is NULL");
   hipStream_t s = psa::as_stream(stream);
   if (n == 0) {
-    PSA_HIP(hipMemsetAsync(count_out, 0, sizeof(int64_t), s));
+    PSA_ZERO(count_out, sizeof(int64_t), s);
     return PSA_OK;
   }
   PSA_REQUIRE(sorted_keys != nullptr, "sorted_keys is NULL");

@@ -26,6 +26,12 @@ inline bool aligned(const void* p, size_t a) {
   return (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0;
 }
 
+// Zero-fill by a kernel of the core (4-byte aligned pointer and size).  Used
+// instead of hipMemsetAsync everywhere: memset NODES of a captured HIP graph
+// replay wrongly from the second launch on with the ROCm runtime torch 2.10
+// ships (tools/graph_debug.py), kernels replay fine.
+int zero_async(void* p, size_t bytes, hipStream_t s);
+
 }  // namespace psa
 
 #define PSA_REQUIRE(cond, msg)                                        \
@@ -44,6 +50,12 @@ inline bool aligned(const void* p, size_t a) {
                      hipGetErrorString(_e));                          \
       return PSA_ERR_HIP;                                             \
     }                                                                 \
+  } while (0)
+
+#define PSA_ZERO(ptr, bytes, stream)                                  \
+  do {                                                                \
+    const int _z = psa::zero_async((ptr), (bytes), (stream));         \
+    if (_z != PSA_OK) return _z;                                      \
   } while (0)
 
 // Launch errors (bad configuration) surface through hipGetLastError.

@@ -91,7 +91,7 @@ int psa_ind2ptr(const int64_t* ind, int64_t numel, int64_t M, int64_t* out,
   PSA_REQUIRE(numel == 0 || ind != nullptr, "ind is NULL");
   hipStream_t s = psa::as_stream(stream);
   if (numel == 0) {  // csrc/cpu/convert_cpu.cpp:9-11
-    PSA_HIP(hipMemsetAsync(out, 0, sizeof(int64_t) * (M + 1), s));
+    PSA_ZERO(out, sizeof(int64_t) * (M + 1), s);
     return PSA_OK;
   }
   const int64_t blocks = psa::ceil_div(numel + 1, kThreads);

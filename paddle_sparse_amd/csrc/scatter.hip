@@ -150,7 +150,7 @@ int psa_scatter_reduce(int reduce, int dtype, const void* src,
       return PSA_ERR_WORKSPACE;
     }
     count = static_cast<unsigned int*>(workspace);
-    PSA_HIP(hipMemsetAsync(count, 0, sizeof(unsigned int) * dim_size, s));
+    PSA_ZERO(count, sizeof(unsigned int) * dim_size, s);
   }
   switch (dtype) {
     case PSA_F32: return dispatch<float>(reduce, src, index, n, D, dim_size, out, count, s);

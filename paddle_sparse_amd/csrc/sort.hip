@@ -872,7 +872,7 @@ static int sort_impl(const char* who, const int64_t* keys, const uint32_t* pay_i
     uint32_t* gbase_all = ghist + kOsMaxPasses * kRadix;
     uint32_t* tickets = gbase_all + kOsMaxPasses * kRadix;  // [kOsMaxPasses] + err word
     uint32_t* err = tickets + kOsMaxPasses;
-    PSA_HIP(hipMemsetAsync(os, 0, p.os_bytes, s));
+    PSA_ZERO(os, p.os_bytes, s);
     const int hist_blocks = static_cast<int>(psa::ceil_div(n, kThreads * 16) < 2048
                                                  ? psa::ceil_div(n, kThreads * 16) : 2048);
     hipLaunchKernelGGL(os_hist_kernel, dim3(hist_blocks), block, 0, s, kin, n, p.passes, ghist);
@@ -913,7 +913,7 @@ static int sort_impl(const char* who, const int64_t* keys, const uint32_t* pay_i
     const bool last = pass == p.passes - 1;
     const bool iota_payload = pass == 0 && pay_in == nullptr;
     const bool widen = last && perm_out != nullptr;  // int64 permutation output
-    PSA_HIP(hipMemsetAsync(digit_total, 0, sizeof(uint32_t) * kRadix, s));
+    PSA_ZERO(digit_total, sizeof(uint32_t) * kRadix, s);
     hipLaunchKernelGGL(radix_hist_kernel, grid, block, 0, s, kin, n, shift,
                        p.tiles_per_block, p.num_blocks, counts, digit_total);
     hipLaunchKernelGGL(radix_scan_kernel, dim3(kRadix / kWaves), block, 0, s,

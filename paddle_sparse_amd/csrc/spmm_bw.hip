@@ -255,7 +255,7 @@ int psa_spmm_value_bw(int reduce, const int64_t* rowptr, const int64_t* col,
   PSA_REQUIRE(out != nullptr, "out is NULL");
   hipStream_t s = psa::as_stream(stream);
   if (M == 0 || K == 0) {
-    PSA_HIP(hipMemsetAsync(out, 0, sizeof(float) * nnz, s));
+    PSA_ZERO(out, sizeof(float) * nnz, s);
     return PSA_OK;
   }
   PSA_REQUIRE(rowptr && col && mat && grad, "NULL pointer");
@@ -298,8 +298,8 @@ int psa_spmm_minmax_bw(const int64_t* col, const float* value, const float* mat,
                        float* grad_mat, psa_stream_t stream) {
   PSA_REQUIRE(M >= 0 && N >= 0 && K >= 0 && nnz >= 0, "negative size");
   hipStream_t s = psa::as_stream(stream);
-  if (grad_value && nnz) PSA_HIP(hipMemsetAsync(grad_value, 0, sizeof(float) * nnz, s));
-  if (grad_mat && N * K) PSA_HIP(hipMemsetAsync(grad_mat, 0, sizeof(float) * N * K, s));
+  if (grad_value && nnz) PSA_ZERO(grad_value, sizeof(float) * nnz, s);
+  if (grad_mat && N * K) PSA_ZERO(grad_mat, sizeof(float) * N * K, s);
   if (M * K == 0 || nnz == 0 || (!grad_value && !grad_mat)) return PSA_OK;
   PSA_REQUIRE(col && grad && arg_out, "NULL pointer");
   PSA_REQUIRE(!grad_value || mat, "mat needed for grad_value");

@@ -193,7 +193,7 @@ int psa_bincount(const int64_t* index, int64_t n, int64_t size, int64_t* out,
   hipStream_t s = psa::as_stream(stream);
   if (size > 0) {
     PSA_REQUIRE(out != nullptr, "out is NULL");
-    PSA_HIP(hipMemsetAsync(out, 0, sizeof(int64_t) * size, s));
+    PSA_ZERO(out, sizeof(int64_t) * size, s);
   }
   if (n == 0 || size == 0) return PSA_OK;
   PSA_REQUIRE(index != nullptr, "index is NULL");
@@ -216,7 +216,7 @@ int psa_count2ptr(const int64_t* counts, int64_t n, int64_t* ptr_out,
   PSA_REQUIRE(ptr_out != nullptr, "ptr_out is NULL");
   hipStream_t s = psa::as_stream(stream);
   if (n == 0) {
-    PSA_HIP(hipMemsetAsync(ptr_out, 0, sizeof(int64_t), s));
+    PSA_ZERO(ptr_out, sizeof(int64_t), s);
     return PSA_OK;
   }
   PSA_REQUIRE(counts != nullptr, "counts is NULL");

@@ -1,0 +1,51 @@
+"""GPU: the C-ABI calls are stream-ordered and allocation-free (caller owns
+outputs and workspaces), so a framework can capture them into a HIP graph
+(cdna_hip_programming.md Guideline 9).  Capture SpMM forward/backward pieces
+and the sort, replay on new data, compare with eager results."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_spmm_and_sort_replay_from_a_hip_graph():
+    from paddle_sparse_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(0)
+    M, nnz, K = 20_000, 200_000, 128
+    row = torch.sort(torch.randint(0, M, (nnz,), generator=g, device="cuda"))[0]
+    col = torch.randint(0, M, (nnz,), generator=g, device="cuda")
+    val = torch.randn(nnz, generator=g, device="cuda")
+    rowptr = ops.ind2ptr(row, M)
+    B = torch.randn(M, K, generator=g, device="cuda")
+    G = torch.randn(M, K, generator=g, device="cuda")
+    keys = torch.randint(0, 1 << 40, (300_000,), generator=g, device="cuda")
+
+    # warm up on a side stream (required before capture), then capture
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ops.spmm_sum(rowptr, col, val, B)
+        ops.spmm_value_bw(None, rowptr, col, B, G)
+        ops.index_sort(keys, 1 << 40, with_sorted_inputs=True)
+    torch.cuda.current_stream().wait_stream(s)
+
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = ops.spmm_sum(rowptr, col, val, B)
+        out_max, arg = ops.spmm_max(rowptr, col, val, B)
+        gv = ops.spmm_value_bw(None, rowptr, col, B, G)
+        srt, perm = ops.index_sort(keys, 1 << 40, with_sorted_inputs=True)
+
+    for trial in range(3):  # new data in the captured input buffers, replay
+        B.copy_(torch.randn(M, K, generator=g, device="cuda"))
+        G.copy_(torch.randn(M, K, generator=g, device="cuda"))
+        keys.copy_(torch.randint(0, 1 << 40, (300_000,), generator=g, device="cuda"))
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ops.spmm_sum(rowptr, col, val, B))
+        e_max, e_arg = ops.spmm_max(rowptr, col, val, B)
+        assert torch.equal(out_max, e_max) and torch.equal(arg, e_arg)
+        assert torch.equal(gv, ops.spmm_value_bw(None, rowptr, col, B, G))
+        ts, tp = torch.sort(keys, stable=True)
+        assert torch.equal(srt, ts) and torch.equal(perm, tp)
