@@ -23,6 +23,8 @@ assert cuda_version == -1
 
 from .storage import SparseStorage  # noqa: E402,F401
 from .tensor import SparseTensor  # noqa: E402,F401
+from .add import add, add_, add_nnz, add_nnz_  # noqa: E402,F401
+from .mul import mul, mul_, mul_nnz, mul_nnz_  # noqa: E402,F401
 from .reduce import sum, mean, min, max  # noqa: E402,F401,A004
 from .convert import to_torch_sparse, from_torch_sparse  # noqa: E402,F401
 from .convert import to_scipy, from_scipy  # noqa: E402,F401
@@ -33,6 +35,14 @@ from .matmul import spmm, matmul  # noqa: E402,F401
 __all__ = [
     "SparseStorage",
     "SparseTensor",
+    "add",
+    "add_",
+    "add_nnz",
+    "add_nnz_",
+    "mul",
+    "mul_",
+    "mul_nnz",
+    "mul_nnz_",
     "sum",
     "mean",
     "min",

@@ -1,0 +1,105 @@
+"""GPU: add / mul on the SparseTensor surface against the
+reference's known answers (test/test_add.py, test/test_mul.py) and scipy on
+seeded inputs."""
+import numpy as np
+import pytest
+import scipy.sparse
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float16, torch.float32, torch.float64, torch.int32, torch.int64, torch.bfloat16]
+
+
+def idx(x):
+    return torch.tensor(x, dtype=torch.int64, device="cuda")
+
+
+def make(k, which, dtype):
+    from paddle_sparse_amd import SparseTensor
+
+    return SparseTensor(row=idx(k["row" + which]), col=idx(k["col" + which]),
+                        value=torch.tensor(k["value" + which], dtype=dtype, device="cuda"))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_add_kat(kats, dtype):
+    k = kats["add_mul_sparse_sparse"]
+    C = make(k, "A", dtype) + make(k, "B", dtype)
+    row, col, value = C.coo()
+    assert row.tolist() == k["add_row"] and col.tolist() == k["add_col"]
+    assert torch.equal(value, torch.tensor(k["add_value"], dtype=dtype, device="cuda"))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_sparse_sparse_mul_kat(kats, dtype):
+    k = kats["add_mul_sparse_sparse"]
+    C = make(k, "A", dtype) * make(k, "B", dtype)
+    row, col, value = C.coo()
+    assert row.tolist() == k["mul_row"] and col.tolist() == k["mul_col"]
+    assert torch.equal(value, torch.tensor(k["mul_value"], dtype=dtype, device="cuda"))
+    e = k["mul_empty"]
+    C = make(e, "A", dtype) * make(e, "B", dtype)
+    row, col, value = C.coo()
+    assert row.tolist() == [] and col.tolist() == [] and value.tolist() == []
+
+
+def _random(M, N, nnz, seed):
+    from paddle_sparse_amd import SparseTensor
+
+    rng = np.random.default_rng(seed)
+    key = np.unique(rng.integers(0, M * N, nnz))
+    row, col = key // N, key % N
+    val = rng.integers(-5, 6, key.size).astype(np.float32)
+    val[val == 0] = 1
+    t = SparseTensor(row=idx(row), col=idx(col), value=torch.from_numpy(val).cuda(), sparse_sizes=(M, N))
+    return t, scipy.sparse.csr_matrix((val, (row, col)), (M, N))
+
+
+def test_add_mul_random_vs_scipy():
+    A, sa = _random(300, 200, 5000, 1)
+    B, sb = _random(300, 200, 4000, 2)
+    assert np.array_equal((A + B).to_dense().cpu().numpy(), (sa + sb).toarray())
+    C = A * B
+    assert np.array_equal(C.to_dense().cpu().numpy(), sa.multiply(sb).toarray())
+    assert C.nnz() == sa.multiply(sb).nnz
+    # operands of different shapes (add.py:41-43: sizes are the elementwise max)
+    D, sd = _random(350, 150, 3000, 3)
+    S = A + D
+    assert S.sparse_sizes() == (350, 200)
+    ref = np.zeros((350, 200), np.float32)
+    ref[:300, :200] += sa.toarray()
+    ref[:350, :150] += sd.toarray()
+    assert np.array_equal(S.to_dense().cpu().numpy(), ref)
+
+
+def test_dense_broadcast_add_mul():
+    A, sa = _random(60, 40, 500, 4)
+    dense = sa.toarray()
+    mask = dense != 0
+    r = torch.arange(60, dtype=torch.float32, device="cuda").view(-1, 1)
+    c = torch.arange(40, dtype=torch.float32, device="cuda").view(1, -1)
+    for op, npop in (("add", np.add), ("mul", np.multiply)):
+        got = getattr(A, op)(r).to_dense().cpu().numpy()
+        assert np.array_equal(got, np.where(mask, npop(dense, r.cpu().numpy()), 0))
+        got = getattr(A, op)(c).to_dense().cpu().numpy()
+        assert np.array_equal(got, np.where(mask, npop(dense, c.cpu().numpy()), 0))
+    with pytest.raises(ValueError, match="Size mismatch"):
+        A + torch.ones(3, 3, device="cuda")
+    # nnz-wise and in-place forms
+    v = torch.full((A.nnz(),), 2.0, device="cuda")
+    assert np.array_equal(A.mul_nnz(v, layout="coo").to_dense().cpu().numpy(), dense * 2)
+    assert np.array_equal(A.add_nnz(v, layout="coo").to_dense().cpu().numpy(), np.where(mask, dense + 2, 0))
+    B = A.copy()
+    B.storage._value = A.storage.value().clone()
+    B *= c
+    assert np.array_equal(B.to_dense().cpu().numpy(), np.where(mask, dense * c.cpu().numpy(), 0))
+
+
+def test_mul_requires_coalesced_operands():
+    from paddle_sparse_amd import SparseTensor
+
+    dup = SparseTensor(row=idx([0, 0]), col=idx([1, 1]), value=torch.ones(2, device="cuda"))
+    ok = SparseTensor(row=idx([0]), col=idx([1]), value=torch.ones(1, device="cuda"))
+    with pytest.raises(ValueError, match="not coalesced"):
+        dup * ok
