@@ -23,6 +23,8 @@ assert cuda_version == -1
 
 from .storage import SparseStorage  # noqa: E402,F401
 from .tensor import SparseTensor  # noqa: E402,F401
+from .slicing import narrow, select, index_select, index_select_nnz  # noqa: E402,F401
+from .slicing import masked_select, masked_select_nnz  # noqa: E402,F401
 from .add import add, add_, add_nnz, add_nnz_  # noqa: E402,F401
 from .mul import mul, mul_, mul_nnz, mul_nnz_  # noqa: E402,F401
 from .reduce import sum, mean, min, max  # noqa: E402,F401,A004
@@ -35,6 +37,12 @@ from .matmul import spmm, matmul  # noqa: E402,F401
 __all__ = [
     "SparseStorage",
     "SparseTensor",
+    "narrow",
+    "select",
+    "index_select",
+    "index_select_nnz",
+    "masked_select",
+    "masked_select_nnz",
     "add",
     "add_",
     "add_nnz",

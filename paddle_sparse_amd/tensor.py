@@ -3,8 +3,9 @@
 Same public surface as the reference class for the parts that sit on the hot
 path (constructors, coo/csr/csc, value handling, coalesce, caches, size/stat
 helpers, to_symmetric, dense / scipy / torch.sparse conversions).  Slicing
-(`__getitem__` -> narrow/select/index_select/masked_select) is outside this
-round's scope and raises NotImplementedError.
+(`__getitem__`, narrow/select/index_select/masked_select) is attached by
+slicing.py, add/mul by add.py/mul.py, reductions by reduce.py, SpMM by
+matmul.py — the reference monkey-patches its methods the same way.
 """
 from __future__ import annotations
 
@@ -429,11 +430,6 @@ class SparseTensor(object):
         colptr, row, value = self.csc()
         data = host(value) if value is not None else ones
         return scipy.sparse.csc_matrix((data, host(row), host(colptr)), self.sizes())
-
-    def __getitem__(self, index: Any):
-        raise NotImplementedError(
-            "SparseTensor slicing (narrow/select/index_select/masked_select) is not part of "
-            "the MI355X hot-path build yet (SURVEY.md §8(f) f-3)")
 
     def __repr__(self) -> str:
         i = " " * 6
