@@ -104,11 +104,18 @@ int psa_ptr2ind(const int64_t* ptr, int64_t M, int64_t E, int64_t* out,
  * rowptr int64[M+1], col int64[nnz] (values in [0, N)), value f32[nnz] or
  * NULL, mat f32[N,K] row-major, out f32[M,K], arg_out int64[M,K] (required
  * for MIN/MAX, ignored otherwise; may be NULL for SUM/MEAN).
- * nnz is passed explicitly because rowptr lives on the device. */
+ * nnz is passed explicitly because rowptr lives on the device.
+ *
+ * workspace (psa_spmm_workspace_bytes(reduce, K, nnz) bytes, 16-byte aligned)
+ * enables the long-row path: rows with more than 128 edges are split into
+ * 128-edge chunks reduced by separate wavefronts and folded in chunk order
+ * (deterministic).  workspace == NULL keeps every row on one wavefront — same
+ * results, but a power-law graph then waits for its longest row. */
+size_t psa_spmm_workspace_bytes(int reduce, int64_t K, int64_t nnz);
 int psa_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
              const float* value, const float* mat, int64_t M, int64_t N,
              int64_t K, int64_t nnz, float* out, int64_t* arg_out,
-             psa_stream_t stream);
+             void* workspace, size_t workspace_bytes, psa_stream_t stream);
 
 /* ---- SpMM backward (fp32) ------------------------------------------------ */
 

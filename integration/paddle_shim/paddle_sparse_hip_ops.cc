@@ -114,8 +114,13 @@ static std::vector<paddle::Tensor> spmm_impl(int reduce, paddle::Tensor& rowptr,
   const bool minmax = reduce == PSA_MIN || reduce == PSA_MAX;
   auto arg = minmax ? paddle::empty({M, K}, paddle::DataType::INT64, mat.place())
                     : paddle::empty({0}, paddle::DataType::INT64, mat.place());
+  // scratch of the long-row path (rows > 128 edges are reduced chunk-wise)
+  const int64_t ws_bytes = static_cast<int64_t>(psa_spmm_workspace_bytes(reduce, K, nnz));
+  auto ws = paddle::empty({ws_bytes > 0 ? ws_bytes : 1}, paddle::DataType::UINT8, mat.place());
   PSA_CALL(psa_spmm(reduce, i64(rowptr), i64(col), value ? f32(value.get()) : nullptr, f32(mat), M, N,
-                    K, nnz, out.data<float>(), minmax ? arg.data<int64_t>() : nullptr, stream_of(mat)));
+                    K, nnz, out.data<float>(), minmax ? arg.data<int64_t>() : nullptr,
+                    ws_bytes > 0 ? ws.data<uint8_t>() : nullptr, static_cast<size_t>(ws_bytes),
+                    stream_of(mat)));
   return {out, arg};
 }
 #define PSA_SPMM_OP(NAME, RED)                                                                \

@@ -28,8 +28,10 @@ SIGNATURES = {
     "psa_sparse_cuda_version": (c_int64, []),
     "psa_ind2ptr": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "psa_ptr2ind": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "psa_spmm_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64]),
     "psa_spmm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
-                         c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+                         c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                         c_size_t, c_void_p]),
     "psa_spmm_set_variant": (c_int, [c_int]),
     "psa_spmm_value_bw": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                   c_int64, c_int64, c_void_p, c_void_p]),

@@ -61,42 +61,45 @@ __device__ __forceinline__ int64_t shfl_i64(int64_t x, int src) {
 }
 
 // ---------------------------------------------------------------------------
-// Variant A: one wavefront per CSR row.
-//   LPR lanes x VEC floats cover one K-tile (blockIdx.y selects the tile);
-//   G = 64/LPR edge slots work on G edges of the row per step; U steps are
-//   issued before any is consumed (G*U gathers in flight per wave).
+// Long rows (power-law graphs).  One wave pulls only a few GB/s (8 gathers in
+// flight), so a 40 000-edge row would keep its wave busy for milliseconds
+// while the rest of the chip idles (R-MAT scale 21: 9.5 ms against 1.8 ms for
+// a uniform graph of the same size).  Rows longer than kLongRow are therefore
+// NOT reduced by their row wave: it records (row, first chunk) in a work list
+// with ONE 64-bit atomic {rows << 32 | chunks} (so list order == chunk order),
+// a second launch reduces every kLongChunk-edge chunk with its own wave into a
+// partials buffer, and a third folds each row's partials IN CHUNK ORDER
+// (deterministic, no float atomics; min/max keep the first winner).
+// R-MAT scale 21, 19.5 M edges, K=128: 5.8 -> 2.5 ms; the chunk launch itself
+// runs at 5.7 TB/s (11.7 M edges in 1.05 ms).  Cost when no row is long: three
+// near-empty launches, ~5 us (visible only on sub-100-us problems).
 // ---------------------------------------------------------------------------
+constexpr int kLongRow = 128;    // rows with more edges take the chunked path
+constexpr int kLongChunk = 128;  // edges per chunk wave
+constexpr int kLongBlocks = 2048;
+
+struct LongEntry {
+  int64_t row;
+  uint32_t first_chunk;
+  uint32_t num_chunks;
+};
+
+// Reduce edges [s, e) of one row into acc/arg: LPR lanes x VEC floats cover the
+// K tile at k0, the G = 64/LPR lane groups take different edges of a step, U
+// steps are issued before any is consumed; the groups are folded at the end.
 template <int VEC, int LPR, int RED, int U>
-__global__ void __launch_bounds__(kThreads)
-spmm_row_kernel(const int64_t* __restrict__ rowptr,
-                const int64_t* __restrict__ col,
-                const float* __restrict__ val, const float* __restrict__ mat,
-                float* __restrict__ out, int64_t* __restrict__ arg_out,
-                int64_t M, int64_t K, int64_t nnz, int mean) {
+__device__ __forceinline__ void reduce_edge_range(
+    const int64_t* __restrict__ col, const float* __restrict__ val,
+    const float* __restrict__ matk, int64_t K, bool kact, int64_t s, int64_t e,
+    int64_t nnz, int lane, float (&acc)[VEC], int64_t (&arg)[VEC]) {
   constexpr int G = 64 / LPR;
   static_assert(64 % (G * U) == 0, "edge batch must divide the wave");
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t row = static_cast<int64_t>(blockIdx.x) * kWaves + wave;
-  if (row >= M) return;
   const int g = lane / LPR;
-  const int l = lane % LPR;
-  const int64_t k0 = static_cast<int64_t>(blockIdx.y) * (LPR * VEC) + l * VEC;
-  const bool kact = k0 < K;  // K % VEC == 0 (dispatch guarantees it)
-  const float* matk = mat + k0;
-
-  const int64_t s = rowptr[row];
-  const int64_t e = rowptr[row + 1];
-
-  float acc[VEC];
-  int64_t arg[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
-    acc[i] = RED == R_SUM ? 0.f
-                          : (RED == R_MAX ? -__FLT_MAX__ : __FLT_MAX__);
+    acc[i] = RED == R_SUM ? 0.f : (RED == R_MAX ? -__FLT_MAX__ : __FLT_MAX__);
     arg[i] = nnz;
   }
-
   for (int64_t base = s; base < e; base += 64) {
     const int n = (e - base) < 64 ? static_cast<int>(e - base) : 64;
     int64_t c_l = 0;
@@ -139,7 +142,6 @@ spmm_row_kernel(const int64_t* __restrict__ rowptr,
       }
     }
   }
-
   // Fold the G edge slots.
 #pragma unroll
   for (int off = LPR; off < 64; off <<= 1) {
@@ -159,6 +161,54 @@ spmm_row_kernel(const int64_t* __restrict__ rowptr,
       }
     }
   }
+}
+
+// Lane 0 of a row wave hands a long row to the chunk kernels.
+__device__ __forceinline__ void push_long_row(unsigned long long* ctr, LongEntry* list,
+                                              int64_t row, int64_t deg) {
+  const uint32_t chunks = static_cast<uint32_t>((deg + kLongChunk - 1) / kLongChunk);
+  const unsigned long long old = atomicAdd(ctr, (1ull << 32) | chunks);
+  LongEntry e;
+  e.row = row;
+  e.first_chunk = static_cast<uint32_t>(old & 0xffffffffull);
+  e.num_chunks = chunks;
+  list[old >> 32] = e;
+}
+
+// ---------------------------------------------------------------------------
+// Variant A: one wavefront per CSR row.
+//   LPR lanes x VEC floats cover one K-tile (blockIdx.y selects the tile);
+//   G = 64/LPR edge slots work on G edges of the row per step; U steps are
+//   issued before any is consumed (G*U gathers in flight per wave).
+// ---------------------------------------------------------------------------
+template <int VEC, int LPR, int RED, int U>
+__global__ void __launch_bounds__(kThreads)
+spmm_row_kernel(const int64_t* __restrict__ rowptr,
+                const int64_t* __restrict__ col,
+                const float* __restrict__ val, const float* __restrict__ mat,
+                float* __restrict__ out, int64_t* __restrict__ arg_out,
+                int64_t M, int64_t K, int64_t nnz, int mean,
+                unsigned long long* __restrict__ long_ctr,
+                LongEntry* __restrict__ long_list) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * kWaves + wave;
+  if (row >= M) return;
+  const int g = lane / LPR;
+  const int l = lane % LPR;
+  const int64_t k0 = static_cast<int64_t>(blockIdx.y) * (LPR * VEC) + l * VEC;
+  const bool kact = k0 < K;  // K % VEC == 0 (dispatch guarantees it)
+
+  const int64_t s = rowptr[row];
+  const int64_t e = rowptr[row + 1];
+  if (long_list && e - s > kLongRow) {  // wave-uniform
+    if (lane == 0 && blockIdx.y == 0) push_long_row(long_ctr, long_list, row, e - s);
+    return;
+  }
+
+  float acc[VEC];
+  int64_t arg[VEC];
+  reduce_edge_range<VEC, LPR, RED, U>(col, val, mat + k0, K, kact, s, e, nnz, lane, acc, arg);
 
   if (g == 0 && kact) {
     const int64_t deg = e - s;
@@ -181,6 +231,235 @@ spmm_row_kernel(const int64_t* __restrict__ rowptr,
 }
 
 // ---------------------------------------------------------------------------
+// Variant A2: one wavefront per R consecutive CSR rows.  The R+1 row pointers
+// come from one coalesced load and the first 64 col/value entries of the
+// wave's whole edge range from another, so rows that lie inside that window
+// (short and empty rows: most rows of a power-law graph) pay neither their own
+// pointer latency nor their own index load before their gathers can issue.
+// ---------------------------------------------------------------------------
+template <int VEC, int LPR, int RED, int U, int R>
+__global__ void __launch_bounds__(kThreads)
+spmm_rows_kernel(const int64_t* __restrict__ rowptr,
+                 const int64_t* __restrict__ col,
+                 const float* __restrict__ val, const float* __restrict__ mat,
+                 float* __restrict__ out, int64_t* __restrict__ arg_out,
+                 int64_t M, int64_t K, int64_t nnz, int mean,
+                 unsigned long long* __restrict__ long_ctr,
+                 LongEntry* __restrict__ long_list) {
+  constexpr int G = 64 / LPR;
+  static_assert(64 % (G * U) == 0, "edge batch must divide the wave");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t row0 = (static_cast<int64_t>(blockIdx.x) * kWaves + wave) * R;
+  if (row0 >= M) return;
+  const int nrows = (M - row0) < R ? static_cast<int>(M - row0) : R;
+  const int g = lane / LPR;
+  const int l = lane % LPR;
+  const int64_t k0 = static_cast<int64_t>(blockIdx.y) * (LPR * VEC) + l * VEC;
+  const bool kact = k0 < K;
+  const float* matk = mat + k0;
+
+  const int64_t p = rowptr[row0 + (lane < nrows ? lane : nrows)];
+  const int64_t win_s = shfl_i64(p, 0);
+  const int64_t win_e_all = shfl_i64(p, nrows);
+  int64_t c_w = 0;
+  float v_w = 0.f;
+  if (win_s + lane < win_e_all) {  // first 64 edges of the wave's range
+    c_w = col[win_s + lane];
+    v_w = val ? val[win_s + lane] : 1.f;
+  }
+  for (int rr = 0; rr < nrows; ++rr) {
+    const int64_t row = row0 + rr;
+    const int64_t s = shfl_i64(p, rr);
+    const int64_t e = shfl_i64(p, rr + 1);
+    if (long_list && e - s > kLongRow) {  // wave-uniform
+      if (lane == 0 && blockIdx.y == 0) push_long_row(long_ctr, long_list, row, e - s);
+      continue;
+    }
+    float acc[VEC];
+    int64_t arg[VEC];
+    if (e <= win_s + 64) {
+      // the row lies inside the preloaded window: gather straight from it
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        acc[i] = RED == R_SUM ? 0.f : (RED == R_MAX ? -__FLT_MAX__ : __FLT_MAX__);
+        arg[i] = nnz;
+      }
+      const int off = static_cast<int>(s - win_s);
+      const int n = static_cast<int>(e - s);
+      for (int j = 0; j < n; j += G * U) {
+        float b[U][VEC];
+        float w[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int idx = j + u * G + g;
+          const int64_t c = shfl_i64(c_w, (off + idx) & 63);
+          w[u] = __shfl(v_w, (off + idx) & 63);
+          ok[u] = (idx < n) && kact;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) b[u][i] = 0.f;
+          if (ok[u]) load_vec<VEC>(matk + c * K, b[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          if (RED == R_SUM) {
+            if (ok[u]) {
+#pragma unroll
+              for (int i = 0; i < VEC; ++i) acc[i] += w[u] * b[u][i];
+            }
+          } else if (ok[u]) {
+            const int64_t eid = s + j + u * G + g;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+              const float x = w[u] * b[u][i];
+              const bool better = RED == R_MAX ? (x > acc[i]) : (x < acc[i]);
+              if (better) {
+                acc[i] = x;
+                arg[i] = eid;
+              }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int off2 = LPR; off2 < 64; off2 <<= 1) {
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const float o = __shfl_xor(acc[i], off2);
+          if (RED == R_SUM) {
+            acc[i] += o;
+          } else {
+            const int64_t oa = shfl_i64(arg[i], lane ^ off2);
+            const bool better = RED == R_MAX ? (o > acc[i]) : (o < acc[i]);
+            if (better || (o == acc[i] && oa < arg[i])) {
+              acc[i] = o;
+              arg[i] = oa;
+            }
+          }
+        }
+      }
+    } else {
+      reduce_edge_range<VEC, LPR, RED, U>(col, val, matk, K, kact, s, e, nnz, lane, acc, arg);
+    }
+    if (g == 0 && kact) {
+      const int64_t deg = e - s;
+      if (RED == R_SUM) {
+        if (mean && deg > 1) {
+          const float d = static_cast<float>(deg);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] = acc[i] / d;
+        }
+      } else {
+        if (deg == 0) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) arg_out[row * K + k0 + i] = arg[i];
+      }
+      store_vec<VEC>(out + row * K + k0, acc);
+    }
+  }
+}
+
+// One wave per kLongChunk-edge chunk of a long row (grid-stride over the chunk list):
+// partial[chunk, :] (and the winning edge ids for min/max).
+template <int VEC, int LPR, int RED, int U>
+__global__ void __launch_bounds__(kThreads)
+spmm_long_chunk_kernel(const int64_t* __restrict__ rowptr,
+                       const int64_t* __restrict__ col,
+                       const float* __restrict__ val, const float* __restrict__ mat,
+                       int64_t K, int64_t nnz,
+                       const unsigned long long* __restrict__ long_ctr,
+                       const LongEntry* __restrict__ long_list,
+                       float* __restrict__ part_val, int64_t* __restrict__ part_arg) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long ctr = *long_ctr;
+  const uint32_t total = static_cast<uint32_t>(ctr & 0xffffffffull);
+  const int nrows = static_cast<int>(ctr >> 32);
+  const int g = lane / LPR;
+  const int l = lane % LPR;
+  const int ktiles = static_cast<int>((K + LPR * VEC - 1) / (LPR * VEC));
+  const uint32_t wave_id = blockIdx.x * kWaves + (threadIdx.x >> 6);
+  const uint32_t num_waves = gridDim.x * kWaves;
+  for (uint32_t c = wave_id; c < total; c += num_waves) {
+    // largest slot with first_chunk <= c (the list is ordered by first_chunk)
+    int lo = 0, hi = nrows - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (long_list[mid].first_chunk <= c) lo = mid;
+      else hi = mid - 1;
+    }
+    const LongEntry ent = long_list[lo];
+    const int64_t rs = rowptr[ent.row], re = rowptr[ent.row + 1];
+    const int64_t s = rs + static_cast<int64_t>(c - ent.first_chunk) * kLongChunk;
+    const int64_t e = s + kLongChunk < re ? s + kLongChunk : re;
+    for (int t = 0; t < ktiles; ++t) {
+      const int64_t k0 = static_cast<int64_t>(t) * (LPR * VEC) + l * VEC;
+      const bool kact = k0 < K;
+      float acc[VEC];
+      int64_t arg[VEC];
+      reduce_edge_range<VEC, LPR, RED, U>(col, val, mat + k0, K, kact, s, e, nnz, lane, acc, arg);
+      if (g == 0 && kact) {
+        store_vec<VEC>(part_val + static_cast<int64_t>(c) * K + k0, acc);
+        if (RED != R_SUM) {
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) part_arg[static_cast<int64_t>(c) * K + k0 + i] = arg[i];
+        }
+      }
+    }
+  }
+}
+
+// One wave per long row: fold its chunks' partials in chunk order.
+template <int RED>
+__global__ void __launch_bounds__(kThreads)
+spmm_long_combine_kernel(const int64_t* __restrict__ rowptr, int64_t K, int mean,
+                         const unsigned long long* __restrict__ long_ctr,
+                         const LongEntry* __restrict__ long_list,
+                         const float* __restrict__ part_val,
+                         const int64_t* __restrict__ part_arg,
+                         float* __restrict__ out, int64_t* __restrict__ arg_out) {
+  const int lane = threadIdx.x & 63;
+  const int nrows = static_cast<int>(*long_ctr >> 32);
+  const int num_waves = gridDim.x * kWaves;
+  for (int r = blockIdx.x * kWaves + (threadIdx.x >> 6); r < nrows; r += num_waves) {
+    const LongEntry ent = long_list[r];
+    const int64_t deg = rowptr[ent.row + 1] - rowptr[ent.row];
+    for (int64_t k = lane; k < K; k += 64) {
+      const int64_t p0 = static_cast<int64_t>(ent.first_chunk) * K + k;
+      float acc = part_val[p0];
+      int64_t arg = RED == R_SUM ? 0 : part_arg[p0];
+      // 8 partials requested per step (a 40 000-edge row has > 300 chunks; one
+      // dependent load per chunk made this kernel 0.3 ms), folded in chunk order
+      for (uint32_t c = 1; c < ent.num_chunks; c += 8) {
+        float x[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          x[i] = c + i < ent.num_chunks ? part_val[p0 + static_cast<int64_t>(c + i) * K] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          if (c + i >= ent.num_chunks) break;
+          if (RED == R_SUM) {
+            acc += x[i];
+          } else if (RED == R_MAX ? (x[i] > acc) : (x[i] < acc)) {
+            acc = x[i];
+            arg = part_arg[p0 + static_cast<int64_t>(c + i) * K];
+          }
+        }
+      }
+      if (RED == R_SUM) {
+        if (mean) acc = acc / static_cast<float>(deg);
+      } else {
+        arg_out[ent.row * K + k] = arg;
+      }
+      out[ent.row * K + k] = acc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Variant B (narrow K, K <= LPR*VEC <= 64 floats): G = 64/LPR ROWS per wave.
 // A dense row is only LPR*16 bytes, so one row per wave leaves most lanes in
 // the cross-group fold and the per-row prologue dominates.  Here every lane
@@ -194,7 +473,9 @@ spmm_multirow_kernel(const int64_t* __restrict__ rowptr,
                      const int64_t* __restrict__ col,
                      const float* __restrict__ val, const float* __restrict__ mat,
                      float* __restrict__ out, int64_t* __restrict__ arg_out,
-                     int64_t M, int64_t K, int64_t nnz, int mean) {
+                     int64_t M, int64_t K, int64_t nnz, int mean,
+                     unsigned long long* __restrict__ long_ctr,
+                     LongEntry* __restrict__ long_list) {
   constexpr int G = 64 / LPR;
   const int lane = threadIdx.x & 63;
   const int g = lane / LPR;
@@ -206,6 +487,10 @@ spmm_multirow_kernel(const int64_t* __restrict__ rowptr,
   const float* matk = mat + k0;
   const int64_t s = rowptr[row];
   const int64_t e = rowptr[row + 1];
+  if (long_list && e - s > kLongRow) {  // the whole lane group leaves together
+    if (l == 0) push_long_row(long_ctr, long_list, row, e - s);
+    return;
+  }
   float acc[VEC];
   int64_t arg[VEC];
 #pragma unroll
@@ -265,25 +550,82 @@ spmm_multirow_kernel(const int64_t* __restrict__ rowptr,
 
 int g_variant = 0;
 
+// Device scratch of the long-row path (carved out of the caller's workspace).
+struct LongScratch {
+  unsigned long long* ctr = nullptr;  // {rows << 32 | chunks}, zeroed every call
+  LongEntry* list = nullptr;
+  float* part_val = nullptr;
+  int64_t* part_arg = nullptr;
+};
+
+size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+int64_t max_long_rows(int64_t nnz) { return nnz / (kLongRow + 1) + 1; }
+int64_t max_long_chunks(int64_t nnz) { return nnz / kLongChunk + max_long_rows(nnz) + 1; }
+
+size_t long_workspace_bytes(bool minmax, int64_t K, int64_t nnz) {
+  const size_t chunks = static_cast<size_t>(max_long_chunks(nnz));
+  return 256 + align256(sizeof(LongEntry) * static_cast<size_t>(max_long_rows(nnz))) +
+         align256(chunks * K * sizeof(float)) +
+         (minmax ? align256(chunks * K * sizeof(int64_t)) : 0);
+}
+
+LongScratch carve(void* workspace, bool minmax, int64_t K, int64_t nnz) {
+  LongScratch w;
+  char* p = static_cast<char*>(workspace);
+  w.ctr = reinterpret_cast<unsigned long long*>(p);
+  p += 256;
+  w.list = reinterpret_cast<LongEntry*>(p);
+  p += align256(sizeof(LongEntry) * static_cast<size_t>(max_long_rows(nnz)));
+  w.part_val = reinterpret_cast<float*>(p);
+  p += align256(static_cast<size_t>(max_long_chunks(nnz)) * K * sizeof(float));
+  if (minmax) w.part_arg = reinterpret_cast<int64_t*>(p);
+  return w;
+}
+
+// Second and third launch of the long-row path (no-ops when the list is empty).
+template <int VEC, int LPR, int U>
+int launch_long(int red, const int64_t* rowptr, const int64_t* col, const float* val,
+                const float* mat, float* out, int64_t* arg_out, int64_t K, int64_t nnz,
+                int mean, const LongScratch& w, hipStream_t s) {
+  const dim3 grid(kLongBlocks), block(kThreads);
+#define PSA_LONG(R)                                                                        \
+  do {                                                                                     \
+    hipLaunchKernelGGL((spmm_long_chunk_kernel<VEC, LPR, R, U>), grid, block, 0, s, rowptr, \
+                       col, val, mat, K, nnz, w.ctr, w.list, w.part_val, w.part_arg);      \
+    hipLaunchKernelGGL((spmm_long_combine_kernel<R>), grid, block, 0, s, rowptr, K,         \
+                       mean, w.ctr, w.list, w.part_val, w.part_arg, out, arg_out);         \
+  } while (0)
+  if (red == R_SUM) PSA_LONG(R_SUM);
+  else if (red == R_MIN) PSA_LONG(R_MIN);
+  else PSA_LONG(R_MAX);
+#undef PSA_LONG
+  PSA_LAUNCH_CHECK();
+  return PSA_OK;
+}
+
 template <int VEC, int LPR, int U>
 int launch_multirow(int red, const int64_t* rowptr, const int64_t* col,
                     const float* val, const float* mat, float* out,
                     int64_t* arg_out, int64_t M, int64_t K, int64_t nnz, int mean,
-                    hipStream_t s) {
+                    const LongScratch& w, hipStream_t s) {
   const int64_t gx = psa::ceil_div(M, static_cast<int64_t>(kWaves) * (64 / LPR));
   PSA_REQUIRE(gx <= 0x7fffffff, "M too large for one launch");
   const dim3 grid(static_cast<unsigned>(gx)), block(kThreads);
   if (red == R_SUM) {
     hipLaunchKernelGGL((spmm_multirow_kernel<VEC, LPR, R_SUM, U>), grid, block, 0, s,
-                       rowptr, col, val, mat, out, arg_out, M, K, nnz, mean);
+                       rowptr, col, val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list);
   } else if (red == R_MIN) {
     hipLaunchKernelGGL((spmm_multirow_kernel<VEC, LPR, R_MIN, U>), grid, block, 0, s,
-                       rowptr, col, val, mat, out, arg_out, M, K, nnz, mean);
+                       rowptr, col, val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list);
   } else {
     hipLaunchKernelGGL((spmm_multirow_kernel<VEC, LPR, R_MAX, U>), grid, block, 0, s,
-                       rowptr, col, val, mat, out, arg_out, M, K, nnz, mean);
+                       rowptr, col, val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list);
   }
   PSA_LAUNCH_CHECK();
+  // chunk waves split a row's edges over the 64/LPR lane groups: 8 edges per step
+  constexpr int UL = (64 / LPR) >= 8 ? 1 : 8 / (64 / LPR);
+  if (w.list) return launch_long<VEC, LPR, UL>(red, rowptr, col, val, mat, out, arg_out, K, nnz, mean, w, s);
   return PSA_OK;
 }
 
@@ -291,7 +633,7 @@ template <int VEC, int LPR, int U>
 int launch_row(int red, const int64_t* rowptr, const int64_t* col,
                const float* val, const float* mat, float* out,
                int64_t* arg_out, int64_t M, int64_t K, int64_t nnz, int mean,
-               hipStream_t s) {
+               const LongScratch& w, hipStream_t s) {
   const int64_t gx = psa::ceil_div(M, kWaves);
   const int64_t gy = psa::ceil_div(K, static_cast<int64_t>(LPR) * VEC);
   PSA_REQUIRE(gx <= 0x7fffffff, "M too large for one launch");
@@ -299,19 +641,43 @@ int launch_row(int red, const int64_t* rowptr, const int64_t* col,
   const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(gy));
   const dim3 block(kThreads);
   if (red == R_SUM) {
-    hipLaunchKernelGGL((spmm_row_kernel<VEC, LPR, R_SUM, U>), grid, block, 0,
-                       s, rowptr, col, val, mat, out, arg_out, M, K, nnz,
-                       mean);
+    hipLaunchKernelGGL((spmm_row_kernel<VEC, LPR, R_SUM, U>), grid, block, 0, s, rowptr, col,
+                       val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list);
   } else if (red == R_MIN) {
-    hipLaunchKernelGGL((spmm_row_kernel<VEC, LPR, R_MIN, U>), grid, block, 0,
-                       s, rowptr, col, val, mat, out, arg_out, M, K, nnz,
-                       mean);
+    hipLaunchKernelGGL((spmm_row_kernel<VEC, LPR, R_MIN, U>), grid, block, 0, s, rowptr, col,
+                       val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list);
   } else {
-    hipLaunchKernelGGL((spmm_row_kernel<VEC, LPR, R_MAX, U>), grid, block, 0,
-                       s, rowptr, col, val, mat, out, arg_out, M, K, nnz,
-                       mean);
+    hipLaunchKernelGGL((spmm_row_kernel<VEC, LPR, R_MAX, U>), grid, block, 0, s, rowptr, col,
+                       val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list);
   }
   PSA_LAUNCH_CHECK();
+  if (w.list) return launch_long<VEC, LPR, U>(red, rowptr, col, val, mat, out, arg_out, K, nnz, mean, w, s);
+  return PSA_OK;
+}
+
+template <int VEC, int LPR, int U, int R>
+int launch_rows(int red, const int64_t* rowptr, const int64_t* col,
+                const float* val, const float* mat, float* out,
+                int64_t* arg_out, int64_t M, int64_t K, int64_t nnz, int mean,
+                const LongScratch& w, hipStream_t s) {
+  const int64_t gx = psa::ceil_div(M, static_cast<int64_t>(kWaves) * R);
+  const int64_t gy = psa::ceil_div(K, static_cast<int64_t>(LPR) * VEC);
+  PSA_REQUIRE(gx <= 0x7fffffff, "M too large for one launch");
+  PSA_REQUIRE(gy <= 65535, "K too large for one launch");
+  const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(gy));
+  const dim3 block(kThreads);
+  if (red == R_SUM) {
+    hipLaunchKernelGGL((spmm_rows_kernel<VEC, LPR, R_SUM, U, R>), grid, block, 0, s, rowptr,
+                       col, val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list);
+  } else if (red == R_MIN) {
+    hipLaunchKernelGGL((spmm_rows_kernel<VEC, LPR, R_MIN, U, R>), grid, block, 0, s, rowptr,
+                       col, val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list);
+  } else {
+    hipLaunchKernelGGL((spmm_rows_kernel<VEC, LPR, R_MAX, U, R>), grid, block, 0, s, rowptr,
+                       col, val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list);
+  }
+  PSA_LAUNCH_CHECK();
+  if (w.list) return launch_long<VEC, LPR, U>(red, rowptr, col, val, mat, out, arg_out, K, nnz, mean, w, s);
   return PSA_OK;
 }
 
@@ -325,10 +691,15 @@ int psa_spmm_set_variant(int variant) {
   return prev;
 }
 
+size_t psa_spmm_workspace_bytes(int reduce, int64_t K, int64_t nnz) {
+  if (K <= 0 || nnz <= kLongRow) return 0;  // no row can be long
+  return long_workspace_bytes(reduce == PSA_MIN || reduce == PSA_MAX, K, nnz);
+}
+
 int psa_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
              const float* value, const float* mat, int64_t M, int64_t N,
              int64_t K, int64_t nnz, float* out, int64_t* arg_out,
-             psa_stream_t stream) {
+             void* workspace, size_t workspace_bytes, psa_stream_t stream) {
   PSA_REQUIRE(reduce >= PSA_SUM && reduce <= PSA_MAX, "bad reduce");
   PSA_REQUIRE(M >= 0 && N >= 0 && K >= 0 && nnz >= 0, "negative size");
   if (M == 0 || K == 0) return PSA_OK;
@@ -342,9 +713,23 @@ int psa_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
   const int red = reduce == PSA_MIN ? R_MIN : (reduce == PSA_MAX ? R_MAX : R_SUM);
   const int mean = reduce == PSA_MEAN;
 
+  // Long-row path: on when the caller brings a workspace (NULL keeps every row
+  // on its own wave: same results, slow on power-law graphs).
+  LongScratch w;
+  if (workspace != nullptr && nnz > kLongRow && g_variant != 10) {
+    if (workspace_bytes < long_workspace_bytes(minmax, K, nnz)) {
+      psa::set_error("psa_spmm: workspace too small");
+      return PSA_ERR_WORKSPACE;
+    }
+    PSA_REQUIRE(psa::aligned(workspace, 16), "workspace must be 16-byte aligned");
+    PSA_REQUIRE(max_long_chunks(nnz) < (1ll << 32), "too many chunks");
+    w = carve(workspace, minmax, K, nnz);
+    PSA_ZERO(w.ctr, 8, s);
+  }
+
 #define PSA_ROW(VEC, LPR, U)                                                 \
   return launch_row<VEC, LPR, U>(red, rowptr, col, value, mat, out, arg_out, \
-                                 M, K, nnz, mean, s)
+                                 M, K, nnz, mean, w, s)
 
   const bool v4 = (K % 4 == 0) && psa::aligned(mat, 16) && psa::aligned(out, 16);
   if (v4) {
@@ -354,7 +739,7 @@ int psa_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
     if (g_variant == 4 && K % 128 == 0) PSA_ROW(2, 64, 16);
 #define PSA_MULTI(VEC, LPR, U)                                                     \
   return launch_multirow<VEC, LPR, U>(red, rowptr, col, value, mat, out, arg_out, \
-                                      M, K, nnz, mean, s)
+                                      M, K, nnz, mean, w, s)
     // K <= 64: several rows per wave (multirow, 8 gathers in flight per row)
     // measured at 2M rows / 20M edges: K=16 0.58 -> 0.41 ms, K=32 0.69 -> 0.45,
     // K=64 1.01 -> 0.88 (variant 1 forces the one-row-per-wave kernel back)
@@ -371,6 +756,13 @@ int psa_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
     if (q <= 4) PSA_ROW(4, 4, 1);
     if (q <= 8) PSA_ROW(4, 8, 1);
     if (q <= 16) PSA_ROW(4, 16, 2);
+#define PSA_ROWS(VEC, LPR, U, R)                                                   \
+  return launch_rows<VEC, LPR, U, R>(red, rowptr, col, value, mat, out, arg_out, \
+                                     M, K, nnz, mean, w, s)
+    if (g_variant == 11) { if (q <= 32) PSA_ROWS(4, 32, 4, 4); PSA_ROWS(4, 64, 8, 4); }
+    if (g_variant == 12) { if (q <= 32) PSA_ROWS(4, 32, 4, 8); PSA_ROWS(4, 64, 8, 8); }
+    if (g_variant == 13) { if (q <= 32) PSA_ROWS(4, 32, 4, 2); PSA_ROWS(4, 64, 8, 2); }
+#undef PSA_ROWS
     if (q <= 32) PSA_ROW(4, 32, 4);
     if (g_variant == 8) PSA_ROW(4, 64, 16);
     if (g_variant == 9) PSA_ROW(4, 64, 4);

@@ -96,9 +96,12 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
     arg = None
     if rid in (_lib.MIN, _lib.MAX):
         arg = torch.empty((M, K), dtype=torch.int64, device=mat.device)
+    lib = _lib.load()
+    ws_bytes = lib.psa_spmm_workspace_bytes(rid, K, nnz)  # long-row scratch (0 if no row can be long)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=mat.device) if ws_bytes else None
     with torch.cuda.device(mat.device):
-        check(_lib.load().psa_spmm(rid, _ptr(rowptr), _ptr(col), _ptr(value), _ptr(mat),
-                                   M, N, K, nnz, _ptr(out), _ptr(arg), _stream()))
+        check(lib.psa_spmm(rid, _ptr(rowptr), _ptr(col), _ptr(value), _ptr(mat),
+                           M, N, K, nnz, _ptr(out), _ptr(arg), _ptr(ws), ws_bytes, _stream()))
     return out, arg
 
 

@@ -120,7 +120,7 @@ def test_variants_k128(variant):
         ops.spmm_set_variant(prev)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 7])
+@pytest.mark.parametrize("variant", [0, 1, 7, 11, 12, 13])
 @pytest.mark.parametrize("K", [4, 8, 12, 16, 32, 48, 64, 128, 200, 256])
 def test_multirow_variants_narrow_k(variant, K):
     from paddle_sparse_amd import ops
@@ -134,6 +134,43 @@ def test_multirow_variants_narrow_k(variant, K):
         check("sum", rowptr, col, None, B)
     finally:
         ops.spmm_set_variant(prev)
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max"])
+@pytest.mark.parametrize("K", [4, 32, 64, 100, 128, 256, 300])
+def test_long_rows_take_the_chunked_path(reduce, K):
+    """Rows above 512 edges are split into 256-edge chunks reduced by separate
+    waves and folded in chunk order; results must match the single-wave path
+    (variant 10 switches the chunked path off) and the oracle."""
+    from paddle_sparse_amd import ops
+
+    row, rowptr, col, val = skewed_csr(600, 500, seed=K, long_rows=(0, 1, 300, 599), long_deg=5000)
+    deg = rowptr[1:] - rowptr[:-1]
+    assert (deg > 512).sum() == 4 and (deg == 0).sum() > 0
+    B = np.random.default_rng(K + 3).standard_normal((500, K)).astype(np.float32)
+    out = check(reduce, rowptr, col, val, B)
+    prev = ops.spmm_set_variant(10)
+    try:
+        ref_out, ref_arg = run_gpu(reduce, rowptr, col, val, B)
+    finally:
+        ops.spmm_set_variant(prev)
+    S = oracle.spmm_abs_sum(rowptr, col, val, B)
+    assert np.all(np.abs(out - ref_out) <= RTOL * S + 1e-30)
+    if reduce in ("min", "max"):
+        assert np.array_equal(run_gpu(reduce, rowptr, col, val, B)[1], ref_arg)
+
+
+def test_one_row_holds_everything():
+    from paddle_sparse_amd import ops
+
+    nnz, N, K = 300_000, 4000, 64
+    rng = np.random.default_rng(0)
+    rowptr = np.array([0, 0, nnz, nnz], np.int64)
+    col = rng.integers(0, N, nnz, dtype=np.int64)
+    val = rng.standard_normal(nnz).astype(np.float32)
+    B = rng.standard_normal((N, K)).astype(np.float32)
+    for reduce in ("sum", "mean", "max"):
+        check(reduce, rowptr, col, val, B)
 
 
 def test_config2_shape_vs_oracle():
