@@ -122,10 +122,14 @@ int psa_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
 /* grad wrt the sparse values for sum/mean (upstream spmm_value_bw):
  * out[e] = sum_k mat[col[e],k] * grad[row(e),k], divided by max(deg(row(e)),1)
  * for PSA_MEAN.  row(e) is implied by rowptr (one wave per CSR row), so the
- * upstream `row` argument is not needed.  out: f32[nnz]. */
+ * upstream `row` argument is not needed.  out: f32[nnz].  workspace
+ * (psa_spmm_value_bw_workspace_bytes(nnz) bytes, or NULL) holds the work list
+ * of the long-row path, as for psa_spmm. */
+size_t psa_spmm_value_bw_workspace_bytes(int64_t nnz);
 int psa_spmm_value_bw(int reduce, const int64_t* rowptr, const int64_t* col,
                       const float* mat, const float* grad, int64_t M, int64_t K,
-                      int64_t nnz, float* out, psa_stream_t stream);
+                      int64_t nnz, float* out, void* workspace,
+                      size_t workspace_bytes, psa_stream_t stream);
 
 /* CSC-ordered edge weights for grad wrt the dense operand (sum/mean):
  * out[j] = (value ? value[csr2csc[j]] : 1) / (mean ? max(deg(row_csc[j]),1) : 1)

@@ -146,8 +146,11 @@ std::vector<paddle::Tensor> spmm_value_bw(paddle::Tensor& rowptr, paddle::Tensor
   CHECK_GPU(mat);
   const int64_t M = rowptr.numel() - 1, K = mat.shape()[1], nnz = col.numel();
   auto out = paddle::empty({nnz}, mat.dtype(), mat.place());
+  const int64_t ws_bytes = static_cast<int64_t>(psa_spmm_value_bw_workspace_bytes(nnz));
+  auto ws = paddle::empty({ws_bytes > 0 ? ws_bytes : 1}, paddle::DataType::UINT8, mat.place());
   PSA_CALL(psa_spmm_value_bw(mean ? PSA_MEAN : PSA_SUM, i64(rowptr), i64(col), f32(mat), f32(grad), M, K,
-                             nnz, out.data<float>(), stream_of(mat)));
+                             nnz, out.data<float>(), ws_bytes > 0 ? ws.data<uint8_t>() : nullptr,
+                             static_cast<size_t>(ws_bytes), stream_of(mat)));
   return {out};
 }
 PD_BUILD_OP(spmm_value_bw)

@@ -33,8 +33,9 @@ SIGNATURES = {
                          c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                          c_size_t, c_void_p]),
     "psa_spmm_set_variant": (c_int, [c_int]),
+    "psa_spmm_value_bw_workspace_bytes": (c_size_t, [c_int64]),
     "psa_spmm_value_bw": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
-                                  c_int64, c_int64, c_void_p, c_void_p]),
+                                  c_int64, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "psa_transpose_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                       c_int, c_void_p, c_void_p]),
     "psa_spmm_minmax_bw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,

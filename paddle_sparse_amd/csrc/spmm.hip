@@ -14,6 +14,7 @@
 //     instruction), several of them in flight before the first use;
 //   * partial sums of the 64/LPR edge slots are folded with wave shuffles.
 #include "common.h"
+#include "long_rows.h"
 
 namespace {
 
@@ -74,15 +75,14 @@ __device__ __forceinline__ int64_t shfl_i64(int64_t x, int src) {
 // runs at 5.7 TB/s (11.7 M edges in 1.05 ms).  Cost when no row is long: three
 // near-empty launches, ~5 us (visible only on sub-100-us problems).
 // ---------------------------------------------------------------------------
-constexpr int kLongRow = 128;    // rows with more edges take the chunked path
-constexpr int kLongChunk = 128;  // edges per chunk wave
-constexpr int kLongBlocks = 2048;
-
-struct LongEntry {
-  int64_t row;
-  uint32_t first_chunk;
-  uint32_t num_chunks;
-};
+using psa::find_long_entry;
+using psa::kLongBlocks;
+using psa::kLongChunk;
+using psa::kLongRow;
+using psa::LongEntry;
+using psa::max_long_chunks;
+using psa::max_long_rows;
+using psa::push_long_row;
 
 // Reduce edges [s, e) of one row into acc/arg: LPR lanes x VEC floats cover the
 // K tile at k0, the G = 64/LPR lane groups take different edges of a step, U
@@ -161,18 +161,6 @@ __device__ __forceinline__ void reduce_edge_range(
       }
     }
   }
-}
-
-// Lane 0 of a row wave hands a long row to the chunk kernels.
-__device__ __forceinline__ void push_long_row(unsigned long long* ctr, LongEntry* list,
-                                              int64_t row, int64_t deg) {
-  const uint32_t chunks = static_cast<uint32_t>((deg + kLongChunk - 1) / kLongChunk);
-  const unsigned long long old = atomicAdd(ctr, (1ull << 32) | chunks);
-  LongEntry e;
-  e.row = row;
-  e.first_chunk = static_cast<uint32_t>(old & 0xffffffffull);
-  e.num_chunks = chunks;
-  list[old >> 32] = e;
 }
 
 // ---------------------------------------------------------------------------
@@ -384,14 +372,7 @@ spmm_long_chunk_kernel(const int64_t* __restrict__ rowptr,
   const uint32_t wave_id = blockIdx.x * kWaves + (threadIdx.x >> 6);
   const uint32_t num_waves = gridDim.x * kWaves;
   for (uint32_t c = wave_id; c < total; c += num_waves) {
-    // largest slot with first_chunk <= c (the list is ordered by first_chunk)
-    int lo = 0, hi = nrows - 1;
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (long_list[mid].first_chunk <= c) lo = mid;
-      else hi = mid - 1;
-    }
-    const LongEntry ent = long_list[lo];
+    const LongEntry ent = find_long_entry(long_list, nrows, c);
     const int64_t rs = rowptr[ent.row], re = rowptr[ent.row + 1];
     const int64_t s = rs + static_cast<int64_t>(c - ent.first_chunk) * kLongChunk;
     const int64_t e = s + kLongChunk < re ? s + kLongChunk : re;
@@ -558,15 +539,11 @@ struct LongScratch {
   int64_t* part_arg = nullptr;
 };
 
-size_t align256(size_t x) { return (x + 255) / 256 * 256; }
-
-int64_t max_long_rows(int64_t nnz) { return nnz / (kLongRow + 1) + 1; }
-int64_t max_long_chunks(int64_t nnz) { return nnz / kLongChunk + max_long_rows(nnz) + 1; }
+using psa::align256;
 
 size_t long_workspace_bytes(bool minmax, int64_t K, int64_t nnz) {
   const size_t chunks = static_cast<size_t>(max_long_chunks(nnz));
-  return 256 + align256(sizeof(LongEntry) * static_cast<size_t>(max_long_rows(nnz))) +
-         align256(chunks * K * sizeof(float)) +
+  return psa::long_list_bytes(nnz) + align256(chunks * K * sizeof(float)) +
          (minmax ? align256(chunks * K * sizeof(int64_t)) : 0);
 }
 

@@ -12,6 +12,7 @@
 //                          plain psa_spmm over (colptr, row[csr2csc], w').
 //   psa_spmm_minmax_bw     scatter through arg_out with float atomics.
 #include "common.h"
+#include "long_rows.h"
 
 namespace {
 
@@ -38,27 +39,21 @@ __device__ __forceinline__ void load_vec(const float* p, float (&dst)[VEC]) {
   for (int i = 0; i < VEC; ++i) dst[i] = f[i];
 }
 
+// out[e] = <mat[col[e], :], grow[:]> / denom for the edges [s, e) of ONE row
+// (grow = that row of gOut).  Called by the row wave for ordinary rows and by a
+// chunk wave for a 128-edge piece of a long row.
 template <int VEC, int LPR, int U>
-__global__ void __launch_bounds__(kThreads)
-spmm_value_bw_kernel(const int64_t* __restrict__ rowptr,
-                     const int64_t* __restrict__ col,
-                     const float* __restrict__ mat,
-                     const float* __restrict__ grad, float* __restrict__ out,
-                     int64_t M, int64_t K, int mean) {
+__device__ __forceinline__ void value_bw_range(const int64_t* __restrict__ col,
+                                               const float* __restrict__ mat,
+                                               const float* __restrict__ grow,
+                                               float* __restrict__ out, int64_t K,
+                                               int64_t s, int64_t e, float denom, int lane) {
   constexpr int G = 64 / LPR;
   constexpr int TILE = LPR * VEC;
   static_assert(64 % (G * U) == 0, "edge batch must divide the wave");
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t row = static_cast<int64_t>(blockIdx.x) * kWaves + wave;
-  if (row >= M) return;
   const int g = lane / LPR;
   const int l = lane % LPR;
-  const int64_t s = rowptr[row];
-  const int64_t e = rowptr[row + 1];
-  const float denom = (mean && e - s > 1) ? static_cast<float>(e - s) : 1.0f;
   const int64_t ntiles = (K + TILE - 1) / TILE;
-  const float* grow = grad + row * K;
 
   float gr[VEC];
 #pragma unroll
@@ -129,6 +124,55 @@ spmm_value_bw_kernel(const int64_t* __restrict__ rowptr,
         if (idx < n) out[base + idx] = dot[0] / denom;
       }
     }
+  }
+}
+
+template <int VEC, int LPR, int U>
+__global__ void __launch_bounds__(kThreads)
+spmm_value_bw_kernel(const int64_t* __restrict__ rowptr,
+                     const int64_t* __restrict__ col,
+                     const float* __restrict__ mat,
+                     const float* __restrict__ grad, float* __restrict__ out,
+                     int64_t M, int64_t K, int mean,
+                     unsigned long long* __restrict__ long_ctr,
+                     psa::LongEntry* __restrict__ long_list) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * kWaves + wave;
+  if (row >= M) return;
+  const int64_t s = rowptr[row];
+  const int64_t e = rowptr[row + 1];
+  if (long_list && e - s > psa::kLongRow) {  // wave-uniform: hand the row to chunk waves
+    if (lane == 0) psa::push_long_row(long_ctr, long_list, row, e - s);
+    return;
+  }
+  const float denom = (mean && e - s > 1) ? static_cast<float>(e - s) : 1.0f;
+  value_bw_range<VEC, LPR, U>(col, mat, grad + row * K, out, K, s, e, denom, lane);
+}
+
+// One wave per 128-edge chunk of a long row; chunks write disjoint out[e], so
+// no combine step is needed.
+template <int VEC, int LPR, int U>
+__global__ void __launch_bounds__(kThreads)
+spmm_value_bw_long_kernel(const int64_t* __restrict__ rowptr,
+                          const int64_t* __restrict__ col,
+                          const float* __restrict__ mat,
+                          const float* __restrict__ grad, float* __restrict__ out,
+                          int64_t K, int mean,
+                          const unsigned long long* __restrict__ long_ctr,
+                          const psa::LongEntry* __restrict__ long_list) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long ctr = *long_ctr;
+  const uint32_t total = static_cast<uint32_t>(ctr & 0xffffffffull);
+  const int nrows = static_cast<int>(ctr >> 32);
+  const uint32_t num_waves = gridDim.x * kWaves;
+  for (uint32_t c = blockIdx.x * kWaves + (threadIdx.x >> 6); c < total; c += num_waves) {
+    const psa::LongEntry ent = psa::find_long_entry(long_list, nrows, c);
+    const int64_t rs = rowptr[ent.row], re = rowptr[ent.row + 1];
+    const int64_t s = rs + static_cast<int64_t>(c - ent.first_chunk) * psa::kLongChunk;
+    const int64_t e = s + psa::kLongChunk < re ? s + psa::kLongChunk : re;
+    const float denom = mean ? static_cast<float>(re - rs) : 1.0f;
+    value_bw_range<VEC, LPR, U>(col, mat, grad + ent.row * K, out, K, s, e, denom, lane);
   }
 }
 
@@ -232,12 +276,17 @@ spmm_minmax_bw_row_kernel(const int64_t* __restrict__ col,
 template <int VEC, int LPR, int U>
 int launch_value_bw(const int64_t* rowptr, const int64_t* col, const float* mat,
                     const float* grad, float* out, int64_t M, int64_t K,
-                    int mean, hipStream_t s) {
+                    int mean, unsigned long long* ctr, psa::LongEntry* list,
+                    hipStream_t s) {
   const int64_t gx = psa::ceil_div(M, kWaves);
   PSA_REQUIRE(gx <= 0x7fffffff, "M too large for one launch");
   hipLaunchKernelGGL((spmm_value_bw_kernel<VEC, LPR, U>),
                      dim3(static_cast<unsigned>(gx)), dim3(kThreads), 0, s,
-                     rowptr, col, mat, grad, out, M, K, mean);
+                     rowptr, col, mat, grad, out, M, K, mean, ctr, list);
+  if (list) {
+    hipLaunchKernelGGL((spmm_value_bw_long_kernel<VEC, LPR, U>), dim3(psa::kLongBlocks),
+                       dim3(kThreads), 0, s, rowptr, col, mat, grad, out, K, mean, ctr, list);
+  }
   PSA_LAUNCH_CHECK();
   return PSA_OK;
 }
@@ -246,9 +295,14 @@ int launch_value_bw(const int64_t* rowptr, const int64_t* col, const float* mat,
 
 extern "C" {
 
+size_t psa_spmm_value_bw_workspace_bytes(int64_t nnz) {
+  return nnz > psa::kLongRow ? psa::long_list_bytes(nnz) : 0;
+}
+
 int psa_spmm_value_bw(int reduce, const int64_t* rowptr, const int64_t* col,
                       const float* mat, const float* grad, int64_t M, int64_t K,
-                      int64_t nnz, float* out, psa_stream_t stream) {
+                      int64_t nnz, float* out, void* workspace,
+                      size_t workspace_bytes, psa_stream_t stream) {
   PSA_REQUIRE(reduce == PSA_SUM || reduce == PSA_MEAN, "reduce must be sum or mean");
   PSA_REQUIRE(M >= 0 && K >= 0 && nnz >= 0, "negative size");
   if (nnz == 0) return PSA_OK;
@@ -260,18 +314,34 @@ int psa_spmm_value_bw(int reduce, const int64_t* rowptr, const int64_t* col,
   }
   PSA_REQUIRE(rowptr && col && mat && grad, "NULL pointer");
   const int mean = reduce == PSA_MEAN;
+  // long rows: handed to chunk waves when the caller brings the work list
+  unsigned long long* ctr = nullptr;
+  psa::LongEntry* list = nullptr;
+  if (workspace != nullptr && nnz > psa::kLongRow) {
+    if (workspace_bytes < psa::long_list_bytes(nnz)) {
+      psa::set_error("psa_spmm_value_bw: workspace too small");
+      return PSA_ERR_WORKSPACE;
+    }
+    PSA_REQUIRE(psa::aligned(workspace, 16), "workspace must be 16-byte aligned");
+    ctr = static_cast<unsigned long long*>(workspace);
+    list = reinterpret_cast<psa::LongEntry*>(static_cast<char*>(workspace) + 256);
+    PSA_ZERO(ctr, 8, s);
+  }
+#define PSA_VBW(VEC, LPR, U) \
+  return launch_value_bw<VEC, LPR, U>(rowptr, col, mat, grad, out, M, K, mean, ctr, list, s)
   const bool v4 = (K % 4 == 0) && psa::aligned(mat, 16) && psa::aligned(grad, 16);
   if (v4) {
     const int64_t q = K / 4;
-    if (q <= 4) return launch_value_bw<4, 4, 1>(rowptr, col, mat, grad, out, M, K, mean, s);
-    if (q <= 8) return launch_value_bw<4, 8, 1>(rowptr, col, mat, grad, out, M, K, mean, s);
-    if (q <= 16) return launch_value_bw<4, 16, 2>(rowptr, col, mat, grad, out, M, K, mean, s);
-    if (q <= 32) return launch_value_bw<4, 32, 4>(rowptr, col, mat, grad, out, M, K, mean, s);
-    return launch_value_bw<4, 64, 8>(rowptr, col, mat, grad, out, M, K, mean, s);
+    if (q <= 4) PSA_VBW(4, 4, 1);
+    if (q <= 8) PSA_VBW(4, 8, 1);
+    if (q <= 16) PSA_VBW(4, 16, 2);
+    if (q <= 32) PSA_VBW(4, 32, 4);
+    PSA_VBW(4, 64, 8);
   }
-  if (K <= 4) return launch_value_bw<1, 4, 1>(rowptr, col, mat, grad, out, M, K, mean, s);
-  if (K <= 16) return launch_value_bw<1, 16, 2>(rowptr, col, mat, grad, out, M, K, mean, s);
-  return launch_value_bw<1, 64, 8>(rowptr, col, mat, grad, out, M, K, mean, s);
+  if (K <= 4) PSA_VBW(1, 4, 1);
+  if (K <= 16) PSA_VBW(1, 16, 2);
+  PSA_VBW(1, 64, 8);
+#undef PSA_VBW
 }
 
 int psa_transpose_weights(const float* value, const int64_t* csr2csc,

@@ -306,9 +306,12 @@ def spmm_value_bw(row, rowptr, col, mat, grad, reduce: str = "sum") -> torch.Ten
     if grad.shape != (M, K):
         raise ValueError("grad must be [M, K]")
     out = torch.empty(nnz, dtype=torch.float32, device=mat.device)
+    lib = _lib.load()
+    ws_bytes = lib.psa_spmm_value_bw_workspace_bytes(nnz)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=mat.device) if ws_bytes else None
     with torch.cuda.device(mat.device):
-        check(_lib.load().psa_spmm_value_bw(REDUCE_ID[reduce], _ptr(rowptr), _ptr(col), _ptr(mat),
-                                            _ptr(grad), M, K, nnz, _ptr(out), _stream()))
+        check(lib.psa_spmm_value_bw(REDUCE_ID[reduce], _ptr(rowptr), _ptr(col), _ptr(mat),
+                                    _ptr(grad), M, K, nnz, _ptr(out), _ptr(ws), ws_bytes, _stream()))
     return out
 
 

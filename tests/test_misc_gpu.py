@@ -62,6 +62,23 @@ def test_spmm_value_bw(reduce, K):
     assert np.all(np.abs(got - ref) <= 1e-5 * scale / deg)
 
 
+@pytest.mark.parametrize("reduce", ["sum", "mean"])
+@pytest.mark.parametrize("K", [8, 64, 128, 300])
+def test_spmm_value_bw_long_rows(reduce, K):
+    """Rows above 128 edges go to chunk waves (disjoint out[e] ranges)."""
+    from paddle_sparse_amd import ops
+
+    row, rowptr, col, val = skewed_csr(500, 400, seed=K, long_rows=(0, 250, 499), long_deg=4000)
+    rng = np.random.default_rng(K)
+    B = rng.standard_normal((400, K)).astype(np.float32)
+    G = rng.standard_normal((500, K)).astype(np.float32)
+    got = ops.spmm_value_bw(None, dev(rowptr), dev(col), dev(B), dev(G), reduce).cpu().numpy()
+    ref = oracle.spmm_value_bw(reduce, row, rowptr, col, B, G)
+    scale = np.abs(B[col] * G[row]).sum(axis=1) + 1e-30
+    deg = np.maximum(rowptr[1:] - rowptr[:-1], 1)[row] if reduce == "mean" else 1
+    assert np.all(np.abs(got - ref) <= 1e-5 * scale / deg)
+
+
 @pytest.mark.parametrize("mean", [False, True])
 @pytest.mark.parametrize("has_value", [False, True])
 def test_transposed_spmm_is_grad_mat(mean, has_value):
