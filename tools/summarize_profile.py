@@ -29,9 +29,9 @@ def short(name: str) -> str:
 
 
 # kernel stats
-stats = glob.glob(str(src / "stats" / "*" / "*_kernel_stats.csv"))
+stats = sorted(glob.glob(str(src / "stats" / "*" / "*_kernel_stats.csv")), key=lambda f: Path(f).stat().st_mtime)
 if stats:
-    rows = list(csv.DictReader(open(stats[0])))
+    rows = list(csv.DictReader(open(stats[-1])))  # newest run
     with open(dst / f"{rnd}_kernel_stats.csv", "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
@@ -42,7 +42,9 @@ if stats:
 
 def pmc(dirname: str, match: str):
     out = collections.defaultdict(list)
-    for f in glob.glob(str(src / dirname / "*" / "*_counter_collection.csv")):
+    files = sorted(glob.glob(str(src / dirname / "*" / "*_counter_collection.csv")),
+                   key=lambda f: Path(f).stat().st_mtime)
+    for f in files[-1:]:  # newest run only
         for r in csv.DictReader(open(f)):
             if match in r["Kernel_Name"]:
                 out[r["Counter_Name"]].append(float(r["Counter_Value"]))
