@@ -17,7 +17,11 @@ namespace psa {
 
 constexpr int kLongRow = 128;    // rows with more edges take the chunked path
 constexpr int kLongChunk = 128;  // edges per chunk wave
-constexpr int kLongBlocks = 2048;
+// chunk / combine launches: few, fat workgroups (512 x 1024 threads = 8192
+// waves, the whole chip) — when no row is long these launches are pure
+// dispatch overhead, which grows with the number of workgroups, not threads
+constexpr int kLongBlocks = 512;
+constexpr int kLongThreads = 1024;
 
 struct LongEntry {
   int64_t row;

@@ -354,7 +354,7 @@ spmm_rows_kernel(const int64_t* __restrict__ rowptr,
 // One wave per kLongChunk-edge chunk of a long row (grid-stride over the chunk list):
 // partial[chunk, :] (and the winning edge ids for min/max).
 template <int VEC, int LPR, int RED, int U>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(psa::kLongThreads)
 spmm_long_chunk_kernel(const int64_t* __restrict__ rowptr,
                        const int64_t* __restrict__ col,
                        const float* __restrict__ val, const float* __restrict__ mat,
@@ -369,8 +369,8 @@ spmm_long_chunk_kernel(const int64_t* __restrict__ rowptr,
   const int g = lane / LPR;
   const int l = lane % LPR;
   const int ktiles = static_cast<int>((K + LPR * VEC - 1) / (LPR * VEC));
-  const uint32_t wave_id = blockIdx.x * kWaves + (threadIdx.x >> 6);
-  const uint32_t num_waves = gridDim.x * kWaves;
+  const uint32_t wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint32_t num_waves = gridDim.x * (blockDim.x >> 6);
   for (uint32_t c = wave_id; c < total; c += num_waves) {
     const LongEntry ent = find_long_entry(long_list, nrows, c);
     const int64_t rs = rowptr[ent.row], re = rowptr[ent.row + 1];
@@ -395,7 +395,7 @@ spmm_long_chunk_kernel(const int64_t* __restrict__ rowptr,
 
 // One wave per long row: fold its chunks' partials in chunk order.
 template <int RED>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(psa::kLongThreads)
 spmm_long_combine_kernel(const int64_t* __restrict__ rowptr, int64_t K, int mean,
                          const unsigned long long* __restrict__ long_ctr,
                          const LongEntry* __restrict__ long_list,
@@ -404,8 +404,8 @@ spmm_long_combine_kernel(const int64_t* __restrict__ rowptr, int64_t K, int mean
                          float* __restrict__ out, int64_t* __restrict__ arg_out) {
   const int lane = threadIdx.x & 63;
   const int nrows = static_cast<int>(*long_ctr >> 32);
-  const int num_waves = gridDim.x * kWaves;
-  for (int r = blockIdx.x * kWaves + (threadIdx.x >> 6); r < nrows; r += num_waves) {
+  const int num_waves = gridDim.x * (blockDim.x >> 6);
+  for (int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < nrows; r += num_waves) {
     const LongEntry ent = long_list[r];
     const int64_t deg = rowptr[ent.row + 1] - rowptr[ent.row];
     for (int64_t k = lane; k < K; k += 64) {
@@ -565,7 +565,7 @@ template <int VEC, int LPR, int U>
 int launch_long(int red, const int64_t* rowptr, const int64_t* col, const float* val,
                 const float* mat, float* out, int64_t* arg_out, int64_t K, int64_t nnz,
                 int mean, const LongScratch& w, hipStream_t s) {
-  const dim3 grid(kLongBlocks), block(kThreads);
+  const dim3 grid(kLongBlocks), block(psa::kLongThreads);
 #define PSA_LONG(R)                                                                        \
   do {                                                                                     \
     hipLaunchKernelGGL((spmm_long_chunk_kernel<VEC, LPR, R, U>), grid, block, 0, s, rowptr, \

@@ -153,7 +153,7 @@ spmm_value_bw_kernel(const int64_t* __restrict__ rowptr,
 // One wave per 128-edge chunk of a long row; chunks write disjoint out[e], so
 // no combine step is needed.
 template <int VEC, int LPR, int U>
-__global__ void __launch_bounds__(kThreads)
+__global__ void __launch_bounds__(psa::kLongThreads)
 spmm_value_bw_long_kernel(const int64_t* __restrict__ rowptr,
                           const int64_t* __restrict__ col,
                           const float* __restrict__ mat,
@@ -165,8 +165,8 @@ spmm_value_bw_long_kernel(const int64_t* __restrict__ rowptr,
   const unsigned long long ctr = *long_ctr;
   const uint32_t total = static_cast<uint32_t>(ctr & 0xffffffffull);
   const int nrows = static_cast<int>(ctr >> 32);
-  const uint32_t num_waves = gridDim.x * kWaves;
-  for (uint32_t c = blockIdx.x * kWaves + (threadIdx.x >> 6); c < total; c += num_waves) {
+  const uint32_t num_waves = gridDim.x * (blockDim.x >> 6);
+  for (uint32_t c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); c < total; c += num_waves) {
     const psa::LongEntry ent = psa::find_long_entry(long_list, nrows, c);
     const int64_t rs = rowptr[ent.row], re = rowptr[ent.row + 1];
     const int64_t s = rs + static_cast<int64_t>(c - ent.first_chunk) * psa::kLongChunk;
@@ -285,7 +285,7 @@ int launch_value_bw(const int64_t* rowptr, const int64_t* col, const float* mat,
                      rowptr, col, mat, grad, out, M, K, mean, ctr, list);
   if (list) {
     hipLaunchKernelGGL((spmm_value_bw_long_kernel<VEC, LPR, U>), dim3(psa::kLongBlocks),
-                       dim3(kThreads), 0, s, rowptr, col, mat, grad, out, K, mean, ctr, list);
+                       dim3(psa::kLongThreads), 0, s, rowptr, col, mat, grad, out, K, mean, ctr, list);
   }
   PSA_LAUNCH_CHECK();
   return PSA_OK;
