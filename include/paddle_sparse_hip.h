@@ -171,6 +171,13 @@ int psa_index_sort(const int64_t* keys, int64_t n, int64_t max_value,
                    int64_t* sorted_out, int64_t* perm_out, void* workspace,
                    size_t workspace_bytes, psa_stream_t stream);
 
+/* Diagnostic (synchronises the stream): 0 if the last psa_index_sort /
+ * psa_sort_pairs_u32 that used `workspace` (same n, max_value) finished every
+ * inter-workgroup wait normally, 1 if a bounded spin of the look-back gave up
+ * (never expected; results are then invalid), -1 if the flag could not be read. */
+int psa_index_sort_status(const void* workspace, int64_t n, int64_t max_value,
+                          psa_stream_t stream);
+
 /* Same sort carrying a caller-defined 4-byte payload per key instead of the
  * permutation: payload_out[i] = payload[perm[i]] (any 4-byte dtype: fp32 /
  * int32 values of a COO matrix).  Lets coalesce (storage.py:164-169 + :471)

@@ -43,6 +43,7 @@ SIGNATURES = {
     "psa_index_sort_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "psa_index_sort": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p,
                                c_void_p, c_size_t, c_void_p]),
+    "psa_index_sort_status": (c_int, [c_void_p, c_int64, c_int64, c_void_p]),
     "psa_sort_pairs_u32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
                                    c_void_p, c_size_t, c_void_p]),
     "psa_sort_set_variant": (c_int, [c_int]),

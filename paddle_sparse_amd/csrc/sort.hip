@@ -950,6 +950,27 @@ int psa_index_sort(const int64_t* keys, int64_t n, int64_t max_value,
                    nullptr, workspace, workspace_bytes, psa::as_stream(stream));
 }
 
+int psa_index_sort_status(const void* workspace, int64_t n, int64_t max_value,
+                          psa_stream_t stream) {
+  if (n <= 0 || workspace == nullptr) return 0;
+  const SortPlan p = make_plan(n, max_value);
+  if (p.passes == 0) return 0;
+  const char* os = static_cast<const char*>(workspace) + 2 * p.keys_bytes + 2 * p.idx_bytes +
+                   p.counts_bytes;
+  const size_t status_bytes =
+      align_up(static_cast<size_t>(psa::ceil_div(n, kOsTile)) * kRadix * sizeof(uint64_t), 256);
+  const uint32_t* err = reinterpret_cast<const uint32_t*>(os + status_bytes) +
+                        2 * kOsMaxPasses * kRadix + kOsMaxPasses;
+  uint32_t host = 0;
+  hipStream_t s = psa::as_stream(stream);
+  if (hipMemcpyAsync(&host, err, sizeof(host), hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipStreamSynchronize(s) != hipSuccess) {
+    psa::set_error("psa_index_sort_status: copy failed");
+    return -1;
+  }
+  return static_cast<int>(host);
+}
+
 int psa_sort_pairs_u32(const int64_t* keys, const void* payload, int64_t n,
                        int64_t max_value, int64_t* sorted_out, void* payload_out,
                        void* workspace, size_t workspace_bytes, psa_stream_t stream) {

@@ -168,6 +168,24 @@ def index_sort(keys: torch.Tensor, max_value: Optional[int] = None,
     return out, perm
 
 
+def index_sort_checked(keys: torch.Tensor, max_value: int):
+    """index_sort plus the look-back diagnostic word (tests): returns
+    (sorted, perm, status) with status 0 when every inter-workgroup wait of the
+    single-sweep passes ended normally.  Synchronises."""
+    keys = _index(keys, "keys")
+    n = keys.numel()
+    max_value = max(int(max_value), 1)
+    perm = torch.empty(n, dtype=torch.int64, device=keys.device)
+    out = torch.empty(n, dtype=torch.int64, device=keys.device)
+    lib = _lib.load()
+    ws = _workspace(lib.psa_index_sort_workspace_bytes(n, max_value), keys.device)
+    with torch.cuda.device(keys.device):
+        check(lib.psa_index_sort(_ptr(keys), n, max_value, _ptr(out), _ptr(perm),
+                                 _ptr(ws), ws.numel(), _stream()))
+        status = lib.psa_index_sort_status(_ptr(ws), n, max_value, _stream())
+    return out, perm, status
+
+
 def sort_pairs(keys: torch.Tensor, payload: torch.Tensor, max_value: Optional[int] = None
                ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Stable sort of (key, 4-byte payload) pairs: returns (sorted_keys,

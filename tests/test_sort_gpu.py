@@ -108,8 +108,9 @@ def test_single_sweep_lookback_under_uneven_load():
                 with torch.cuda.stream(side):
                     for _ in range(2):
                         ops.spmm_sum(rowptr, col, None, B)
-                srt, perm = ops.index_sort(keys, 1 << bits, with_sorted_inputs=True)
+                srt, perm, status = ops.index_sort_checked(keys, 1 << bits)
                 ts, tp = torch.sort(keys, stable=True)
+                assert status == 0, "a bounded look-back spin gave up"
                 assert torch.equal(srt, ts) and torch.equal(perm, tp), (rep, n, bits)
     torch.cuda.synchronize()
 
