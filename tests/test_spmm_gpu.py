@@ -181,6 +181,32 @@ def test_config2_shape_vs_oracle():
     check("sum", rowptr, col, val, B)
 
 
+def test_config4_per_gpu_shape():
+    """BASELINE config 4, one rank's share: 2M rows x 16M columns, nnz 20M,
+    F = 256 (B is 16.4 GB: exercises 64-bit addressing of the gather).  A
+    sample of rows is recomputed in float64 with torch ops."""
+    from paddle_sparse_amd import ops
+
+    M, N, nnz, K = 2_000_000, 16_000_000, 20_000_000, 256
+    g = torch.Generator(device="cuda").manual_seed(3)
+    row = torch.sort(torch.randint(0, M, (nnz,), generator=g, device="cuda"))[0]
+    col = torch.randint(0, N, (nnz,), generator=g, device="cuda")
+    col[-1] = N - 1  # touch the last row of B
+    val = torch.randn(nnz, generator=g, device="cuda")
+    rowptr = ops.ind2ptr(row, M)
+    B = torch.randn(N, K, generator=g, device="cuda")
+    out = ops.spmm_sum(rowptr, col, val, B)
+    sample = torch.cat([torch.arange(0, 500, device="cuda"), torch.arange(M - 500, M, device="cuda")])
+    e0 = int(rowptr[500])
+    e1 = int(rowptr[M - 500])
+    for lo, hi, rows in ((0, e0, sample[:500]), (e1, nnz, sample[500:])):
+        contrib = val[lo:hi, None].double() * B[col[lo:hi]].double()
+        acc = torch.zeros(500, K, dtype=torch.float64, device="cuda")
+        acc.index_add_(0, row[lo:hi] - rows[0], contrib)
+        scale = torch.zeros(500, K, dtype=torch.float64, device="cuda").index_add_(0, row[lo:hi] - rows[0], contrib.abs())
+        assert bool(((out[rows].double() - acc).abs() <= 1e-5 * scale + 1e-30).all())
+
+
 def test_linearity_full_size():
     """BASELINE config 3 size (2M x 2M, nnz 20M, F=128): size-independent
     properties instead of the oracle — linearity in B, and A @ ones == row sums."""
