@@ -123,6 +123,9 @@ def main() -> None:
     ap.add_argument("--op", default="spmm_sum", choices=["spmm_sum", "spmm_mean", "spmm_max", "spmm_min"])
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--feature-chunks", type=int, default=1,
+                    help="N > 1: all-gather B in this many column slices and run the SpMM of a "
+                         "slice under the exchange of the next ones (default 1: one all-gather)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -162,7 +165,7 @@ def main() -> None:
         from paddle_sparse_amd.distributed import RowPartitionedSpMM, RowShard
 
         op = RowPartitionedSpMM(RowShard(rowptr, col, val, rank * M, (rank + 1) * M, N), reduce=reduce)
-        step = lambda: op(B_local)  # noqa: E731  all-gather(B) + local HIP SpMM
+        step = lambda: op(B_local, feature_chunks=args.feature_chunks)  # noqa: E731  all-gather(B) + local HIP SpMM
         B_full = op.gather(B_local)
     else:
         fn = getattr(ops, args.op)
@@ -244,6 +247,7 @@ def main() -> None:
         if use_dist:
             line["multi_gpu"] = {
                 "allgather_ms": round(gather_ms, 4),
+                "feature_chunks": args.feature_chunks,
                 "allgather_bytes_received_per_rank": (world - 1) * M * F * 4,
                 "spmm_only_aggregate_gedges_per_s": round(world * nnz / (kern_ms * 1e-3) / 1e9, 4),
                 "note": "value counts the all-gather of B inside every step; spmm_only_* is the "

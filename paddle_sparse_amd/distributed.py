@@ -157,10 +157,32 @@ class RowPartitionedSpMM:
             buf = self._gather_buf = torch.empty(shape, dtype=b_local.dtype, device=b_local.device)
         return all_gather_dense(b_local, self.shard.num_cols, self.group, out=buf)
 
-    def __call__(self, b_local: torch.Tensor) -> torch.Tensor:
-        b_full = self.gather(b_local)
+    def __call__(self, b_local: torch.Tensor, feature_chunks: int = 1) -> torch.Tensor:
+        """out_local [m_local, F].  feature_chunks = 1: one all-gather of B, then
+        the local SpMM.  feature_chunks = C > 1 (opt-in): B is cut into C column
+        slices; all C all-gathers are queued at once on the collective's own
+        stream and the SpMM of slice c starts as soon as slice c has landed, so
+        the kernel runs under the exchange of the later slices (every reduce
+        is element-wise over columns, so slices are independent; the K <= 64
+        kernels are as efficient per byte as the K = 128 one)."""
         s = self.shard
-        return self._local_spmm(self.reduce, s.rowptr, s.col, s.value, b_full)
+        if feature_chunks <= 1:
+            return self._local_spmm(self.reduce, s.rowptr, s.col, s.value, self.gather(b_local))
+        F = b_local.shape[1]
+        bounds = [(F * c) // feature_chunks for c in range(feature_chunks + 1)]
+        works, bufs = [], []
+        for c in range(feature_chunks):
+            part = b_local[:, bounds[c]:bounds[c + 1]].contiguous()
+            buf = torch.empty((self.world * self.block_rows, part.shape[1]), dtype=part.dtype,
+                              device=part.device)
+            works.append(dist.all_gather_into_tensor(buf, part, group=self.group, async_op=True))
+            bufs.append(buf)
+        outs = []
+        for c in range(feature_chunks):
+            works[c].wait()  # the compute stream waits for slice c only
+            outs.append(self._local_spmm(self.reduce, s.rowptr, s.col, s.value,
+                                         bufs[c][:s.num_cols]))
+        return torch.cat(outs, dim=1)
 
     def spmm_only(self, b_full: torch.Tensor) -> torch.Tensor:
         """Local kernel on an already-assembled B (B replicated / reused)."""

@@ -66,6 +66,9 @@ def _worker(rank, world, port, M, N, nnz, F, reduce, balance, result_path):
         out_local = op(b_local)
         ref, _ = oracle.spmm(reduce, rowptr, col, val, B)
         assert np.array_equal(out_local.numpy(), ref[s.row_begin:s.row_end])
+        # column-sliced form (all-gathers queued up front, SpMM per slice)
+        out_sliced = op(b_local, feature_chunks=5)
+        assert np.array_equal(out_sliced.numpy(), out_local.numpy())
         full = pd.gather_rows_to_root(out_local, bounds)
         if rank == 0:
             assert np.array_equal(full.numpy(), ref)

@@ -31,7 +31,8 @@ print(f"R-MAT scale {scale}: nnz={nnz}, max deg={int(deg.max())}, rows with deg>
 B = torch.randn(N, F, device=dev)
 c = index[1].contiguous()
 for variant, label in ((10, "one wave per row, any length"), (0, "long rows chunked (production)"),
-                       (13, "2 rows per wave"), (11, "4 rows per wave"), (12, "8 rows per wave")):
+                       (13, "2 rows per wave"), (11, "4 rows per wave"), (12, "8 rows per wave"),
+                       (7, "multirow: 2 lane groups, a row each")):
     ops.spmm_set_variant(variant)
     for op in ("spmm_sum", "spmm_max"):
         fn = getattr(ops, op)
