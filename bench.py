@@ -233,7 +233,7 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "spmm_row_kernel",
+                "kernel": "spmm_fused_kernel",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -149,6 +149,12 @@ def test_long_rows_take_the_chunked_path(reduce, K):
     assert (deg > 512).sum() == 4 and (deg == 0).sum() > 0
     B = np.random.default_rng(K + 3).standard_normal((500, K)).astype(np.float32)
     out = check(reduce, rowptr, col, val, B)
+    prev = ops.spmm_set_variant(15)  # chunk and row launches back to back (0 fuses them for 64 < K <= 256)
+    try:
+        separate = check(reduce, rowptr, col, val, B)
+    finally:
+        ops.spmm_set_variant(prev)
+    assert np.array_equal(separate, out)  # same chunking, same fold order
     prev = ops.spmm_set_variant(10)
     try:
         ref_out, ref_arg = run_gpu(reduce, rowptr, col, val, B)

@@ -30,9 +30,10 @@ print(f"R-MAT scale {scale}: nnz={nnz}, max deg={int(deg.max())}, rows with deg>
       f"empty rows: {int((deg == 0).sum())}")
 B = torch.randn(N, F, device=dev)
 c = index[1].contiguous()
-for variant, label in ((10, "one wave per row, any length"), (0, "long rows chunked (production)"),
+for variant, label in ((10, "one wave per row, any length"), (15, "long rows chunked, separate launches"),
+                       (0, "production: long rows chunked, roles fused"),
                        (13, "2 rows per wave"), (11, "4 rows per wave"), (12, "8 rows per wave"),
-                       (7, "multirow: 2 lane groups, a row each")):
+                       (14, "fused roles: chunks + rows in one launch")):
     ops.spmm_set_variant(variant)
     for op in ("spmm_sum", "spmm_max"):
         fn = getattr(ops, op)

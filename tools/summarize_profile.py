@@ -53,7 +53,7 @@ def pmc(dirname: str, match: str):
 
 M = N = 2_000_000
 F = 128
-KERNEL = sys.argv[2] if len(sys.argv) > 2 else "spmm_"
+KERNEL = sys.argv[2] if len(sys.argv) > 2 else "spmm_fused_kernel"
 res = {"units": "FETCH_SIZE/WRITE_SIZE in KiB per launch (mean over launches)", "kernel_match": KERNEL}
 cal_f, _ = pmc("pmc_fetch_calib", KERNEL)
 cal_w, _ = pmc("pmc_write_calib", KERNEL)
