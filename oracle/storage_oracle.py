@@ -14,6 +14,8 @@ on Paddle ops + paddle_scatter, neither importable here):
   coalesce() ........... /root/reference/paddle_sparse/coalesce.py:25-29
   t() / transpose() .... /root/reference/paddle_sparse/transpose.py:9-33,41-65
   reduction() .......... /root/reference/paddle_sparse/reduce.py:12-71
+  to_symmetric() ....... /root/reference/paddle_sparse/tensor.py:415-451
+  add() / mul() ........ /root/reference/paddle_sparse/add.py:30-47, mul.py:35-73
 
 Third-party arithmetic that is not under /root/reference:
   paddle_scatter.segment_csr / scatter / scatter_add (unpinned HEAD,
@@ -27,6 +29,7 @@ Third-party arithmetic that is not under /root/reference:
 
 Pinned by the reference's known answers (tests/golden/reference_kats.json,
 from test/test_storage.py, test/test_coalesce.py, test/test_transpose.py,
+test/test_tensor.py, test/test_eye.py, test/test_add.py, test/test_mul.py,
 README.md:204-264).  reduce(dim=0/1), mean/min coalesce: "parity unpinned"
 (test/test_reduce.py only covers dim=None).
 """
@@ -208,6 +211,43 @@ def t(st: Storage) -> Storage:
     perm = st.csr2csc()
     value = None if st.value is None else st.value[perm]
     return Storage(st.col[perm], st.row[perm], value, (st.N, st.M), is_sorted=True)
+
+
+def to_symmetric(st: Storage, reduce="sum") -> Storage:
+    """tensor.py:415-451: entries of A and A^T together, duplicates reduced."""
+    N = max(st.M, st.N)
+    row = np.concatenate([st.row, st.col])
+    col = np.concatenate([st.col, st.row])
+    value = None if st.value is None else np.concatenate([st.value, st.value])
+    return Storage(row, col, value, (N, N), is_sorted=False).coalesce(reduce)
+
+
+def add(a: Storage, b: Storage) -> Storage:
+    """add.py:30-47: concatenate both operands, coalesce with "sum"."""
+    M, N = max(a.M, b.M), max(a.N, b.N)
+    value = None
+    if a.value is not None and b.value is not None:
+        value = np.concatenate([a.value, b.value])
+    return Storage(np.concatenate([a.row, b.row]), np.concatenate([a.col, b.col]), value,
+                   (M, N), is_sorted=False).coalesce("sum")
+
+
+def mul(a: Storage, b: Storage) -> Storage:
+    """mul.py:35-73: entries present in BOTH (coalesced) operands, values multiplied."""
+    M, N = max(a.M, b.M), max(a.N, b.N)
+    key = np.concatenate([a.row * N + a.col, b.row * N + b.col])
+    value = np.concatenate([a.value, b.value])
+    perm = index_sort(key)
+    key, value = key[perm], value[perm]
+    hit = np.nonzero(key[1:] == key[:-1])[0]
+    return Storage(key[hit] // N, key[hit] % N, value[hit] * value[hit + 1], (M, N), is_sorted=True)
+
+
+def dense(st: Storage) -> np.ndarray:
+    out = np.zeros((st.M, st.N) + (() if st.value is None else st.value.shape[1:]),
+                   dtype=np.float64 if st.value is None else st.value.dtype)
+    out[st.row, st.col] = 1 if st.value is None else st.value
+    return out
 
 
 def reduction(st: Storage, dim, reduce="sum", dtype=np.float32):

@@ -73,6 +73,40 @@ def test_add_mul_random_vs_scipy():
     assert np.array_equal(S.to_dense().cpu().numpy(), ref)
 
 
+def test_add_mul_symmetric_vs_oracle():
+    """Bit-exact (row, col, value) against oracle.storage_oracle on seeded inputs."""
+    from oracle import storage_oracle as so
+
+    def to_oracle(t):
+        row, col, value = t.coo()
+        return so.Storage(row.cpu().numpy(), col.cpu().numpy(), value.cpu().numpy(),
+                          t.sparse_sizes(), is_sorted=True)
+
+    def same(t, o):
+        row, col, value = t.coo()
+        assert np.array_equal(row.cpu().numpy(), o.row) and np.array_equal(col.cpu().numpy(), o.col)
+        assert np.array_equal(value.cpu().numpy(), o.value)
+        assert t.sparse_sizes() == (o.M, o.N)
+
+    A, _ = _random(2000, 1500, 60000, 11)
+    B, _ = _random(2000, 1500, 50000, 12)
+    same(A + B, so.add(to_oracle(A), to_oracle(B)))
+    same(A * B, so.mul(to_oracle(A), to_oracle(B)))
+    for reduce in ("sum", "max", "min"):
+        same(A.to_symmetric(reduce), so.to_symmetric(to_oracle(A), reduce))
+
+
+def test_to_symmetric_kat(kats):
+    from paddle_sparse_amd import SparseTensor
+
+    k = kats["to_symmetric"]
+    for dtype in DTYPES:
+        t = SparseTensor(row=idx(k["row"]), col=idx(k["col"]),
+                         value=torch.tensor(k["value"], dtype=dtype, device="cuda")).to_symmetric()
+        assert t.to_dense().cpu().to(torch.int64).tolist() == k["dense"]
+        assert t.is_symmetric()
+
+
 def test_dense_broadcast_add_mul():
     A, sa = _random(60, 40, 500, 4)
     dense = sa.toarray()

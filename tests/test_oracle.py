@@ -95,6 +95,38 @@ def test_reduce_dim_none_kat(kats):
         assert so.reduction(st, None, r) == k[r]
 
 
+def test_to_symmetric_kat(kats):
+    k = kats["to_symmetric"]
+    st = so.to_symmetric(so.Storage(k["row"], k["col"], np.array(k["value"], np.int64)))
+    assert so.dense(st).tolist() == k["dense"]
+    assert np.array_equal(so.dense(st), so.dense(st).T)
+
+
+def test_add_mul_kats(kats):
+    k = kats["add_mul_sparse_sparse"]
+    A = so.Storage(k["rowA"], k["colA"], np.array(k["valueA"], np.float32))
+    B = so.Storage(k["rowB"], k["colB"], np.array(k["valueB"], np.float32))
+    C = so.add(A, B)
+    assert C.row.tolist() == k["add_row"] and C.col.tolist() == k["add_col"]
+    assert C.value.tolist() == k["add_value"]
+    C = so.mul(A, B)
+    assert C.row.tolist() == k["mul_row"] and C.col.tolist() == k["mul_col"]
+    assert C.value.tolist() == k["mul_value"]
+    e = k["mul_empty"]
+    C = so.mul(so.Storage(e["rowA"], e["colA"], np.array(e["valueA"], np.float32)),
+               so.Storage(e["rowB"], e["colB"], np.array(e["valueB"], np.float32)))
+    assert C.row.size == 0 and C.col.size == 0 and C.value.size == 0
+
+
+def test_eye_caches_kat(kats):
+    """test/test_eye.py:42-66: the caches an identity must carry equal the ones
+    the generic cache fill computes from its (row, col)."""
+    for c in kats["eye_caches"]["cases"]:
+        st = so.Storage(c["row"], c["col"], None, (c["M"], c["N"]), is_sorted=True)
+        for name in ("rowptr", "rowcount", "colptr", "colcount", "csr2csc", "csc2csr"):
+            assert getattr(st, name)().tolist() == c[name], (c["M"], c["N"], name)
+
+
 def test_segment_csr_fast_matches_loop():
     rng = np.random.default_rng(0)
     src = rng.integers(-50, 50, (300, 3)).astype(np.int64)
