@@ -201,6 +201,14 @@ int psa_sort_set_variant(int variant);
 int psa_make_keys(const int64_t* a, const int64_t* b, int64_t mul, int64_t n,
                   int64_t* keys, int32_t* unsorted_flag, psa_stream_t stream);
 
+/* The inverse of psa_make_keys on a (sorted) key stream: hi[i] = keys[i] / div,
+ * lo[i] = keys[i] % div; either output may be NULL.  Replaces the row[perm] /
+ * col[perm] gathers after a sort (storage.py:166-168, tensor.py:254-257,
+ * transpose.py:14-16) with one sequential pass: the sorted keys already hold
+ * both indices. */
+int psa_split_keys(const int64_t* keys, int64_t n, int64_t div, int64_t* hi,
+                   int64_t* lo, psa_stream_t stream);
+
 /* out[i, :] = src[perm[i], :] for rows of row_bytes bytes (any dtype):
  * the `x[perm]` gathers of storage.py:166-169, transpose.py:14-22,
  * tensor.py:252-257. */

@@ -9,7 +9,9 @@ Contents
   spmm_oracle.c      SpMM fwd/bwd (upstream pytorch_sparse algorithm; the
                      reference tree has no SpMM)
   storage_oracle.py  numpy restatement of storage.py / coalesce.py /
-                     transpose.py / reduce.py
+                     transpose.py / reduce.py / add.py / mul.py
+  coalesce_oracle.c  C form of the sort + coalesce path (the timed CPU
+                     baseline of those rows; checked against storage_oracle)
 
 oracle/_ref (a build of the reference's own C++): NOT buildable in this
 image — csrc/*.cpp include <paddle/extension.h> (no Paddle headers on disk)
@@ -20,7 +22,6 @@ known-answer tests only (tests/golden/reference_kats.json).
 from __future__ import annotations
 
 import ctypes
-import os
 import shutil
 import subprocess
 from pathlib import Path
@@ -30,7 +31,7 @@ import numpy as np
 HERE = Path(__file__).resolve().parent
 BUILD_DIR = HERE / "_build"
 LIB_PATH = BUILD_DIR / "liboracle.so"
-SOURCES = [HERE / "convert_oracle.c", HERE / "spmm_oracle.c"]
+SOURCES = [HERE / "convert_oracle.c", HERE / "spmm_oracle.c", HERE / "coalesce_oracle.c"]
 
 SUM, MEAN, MIN, MAX = 0, 1, 2, 3
 REDUCE_ID = {"sum": SUM, "add": SUM, "mean": MEAN, "min": MIN, "max": MAX}
@@ -92,6 +93,36 @@ def ptr2ind(ptr, E: int) -> np.ndarray:
     return out
 
 
+def index_sort_c(keys, max_value: int, threads: int = 1):
+    """(sorted keys, stable permutation) — coalesce_oracle.c."""
+    keys = _i64(keys)
+    out, perm = np.empty_like(keys), np.empty_like(keys)
+    lib().oracle_index_sort(_p(keys, ctypes.c_int64), ctypes.c_int64(keys.size),
+                            ctypes.c_int64(max_value), _p(out, ctypes.c_int64),
+                            _p(perm, ctypes.c_int64), ctypes.c_int(threads))
+    return out, perm
+
+
+def coalesce_c(row, col, value, M: int, N: int, reduce: str = "add", threads: int = 1):
+    """coalesce.py:25-29 on fp32 values [nnz] or [nnz, D] (or None) — coalesce_oracle.c.
+    Returns (index[2, nnz'], value')."""
+    row, col, value = _i64(row), _i64(col), _f32(value)
+    nnz = row.size
+    D = 0 if value is None else int(np.prod(value.shape[1:], dtype=np.int64))
+    out_row, out_col = np.empty(nnz, np.int64), np.empty(nnz, np.int64)
+    out_val = None if value is None else np.empty((nnz, D), np.float32)
+    fn = lib().oracle_coalesce_f32
+    fn.restype = ctypes.c_int64
+    cnt = fn(_p(row, ctypes.c_int64), _p(col, ctypes.c_int64), _p(value, ctypes.c_float),
+             ctypes.c_int64(D), ctypes.c_int64(nnz), ctypes.c_int64(M), ctypes.c_int64(N),
+             ctypes.c_int(REDUCE_ID[reduce]), _p(out_row, ctypes.c_int64), _p(out_col, ctypes.c_int64),
+             _p(out_val, ctypes.c_float), ctypes.c_int(threads))
+    index = np.stack([out_row[:cnt], out_col[:cnt]])
+    if value is None:
+        return index, None
+    return index, out_val[:cnt].reshape((cnt,) + value.shape[1:])
+
+
 def spmm(reduce: str, rowptr, col, value, mat, threads: int = 1):
     """Returns (out, arg_out or None).  threads > 1 uses the OpenMP entry."""
     rowptr, col = _i64(rowptr), _i64(col)
@@ -101,8 +132,8 @@ def spmm(reduce: str, rowptr, col, value, mat, threads: int = 1):
     out = np.empty((M, K), dtype=np.float32)
     arg = np.empty((M, K), dtype=np.int64) if rid in (MIN, MAX) else None
     fn = lib().oracle_spmm if threads <= 1 else lib().oracle_spmm_omp
-    if threads > 1:
-        os.environ.setdefault("OMP_NUM_THREADS", str(threads))
+    if threads > 1:  # libgomp (a dependency of liboracle.so) resolves through the same handle
+        lib().omp_set_num_threads(ctypes.c_int(threads))
     fn(ctypes.c_int(rid), _p(rowptr, ctypes.c_int64), _p(col, ctypes.c_int64),
        _p(value, ctypes.c_float), _p(mat, ctypes.c_float), ctypes.c_int64(M),
        ctypes.c_int64(K), ctypes.c_int64(col.size), _p(out, ctypes.c_float),

@@ -49,6 +49,7 @@ SIGNATURES = {
     "psa_sort_set_variant": (c_int, [c_int]),
     "psa_make_keys": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p,
                               c_void_p, c_void_p]),
+    "psa_split_keys": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "psa_gather_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "psa_invert_permutation": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "psa_bincount": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),

@@ -25,6 +25,26 @@ make_keys_kernel(const int64_t* __restrict__ a, const int64_t* __restrict__ b,
   }
 }
 
+// hi[i] = keys[i] / div, lo[i] = keys[i] % div: a sorted key stream already
+// holds both indices, so no permutation gather is needed to recover them.
+// Keys and divisors below 2^32 take the 32-bit division; the generic 64-bit
+// one (a few dozen instructions, still far under the memory time) is the rest.
+__global__ void __launch_bounds__(kThreads)
+split_keys_kernel(const int64_t* __restrict__ keys, int64_t n, int64_t div,
+                  int64_t* __restrict__ hi, int64_t* __restrict__ lo) {
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (i >= n) return;
+  const int64_t k = keys[i];
+  int64_t q;
+  if ((static_cast<uint64_t>(div) >> 32) == 0 && (static_cast<uint64_t>(k) >> 32) == 0) {
+    q = static_cast<uint32_t>(k) / static_cast<uint32_t>(div);
+  } else {
+    q = k / div;
+  }
+  if (hi) hi[i] = q;
+  if (lo) lo[i] = k - q * div;
+}
+
 // out[i, :] = src[perm[i], :], rows of `chunks` pieces of sizeof(T) bytes.
 template <typename T>
 __global__ void __launch_bounds__(kThreads)
@@ -166,6 +186,20 @@ int psa_make_keys(const int64_t* a, const int64_t* b, int64_t mul, int64_t n,
   hipLaunchKernelGGL(make_keys_kernel, dim3(static_cast<unsigned>(blocks)),
                      dim3(kThreads), 0, psa::as_stream(stream), a, b, mul, n,
                      keys, unsorted_flag);
+  PSA_LAUNCH_CHECK();
+  return PSA_OK;
+}
+
+int psa_split_keys(const int64_t* keys, int64_t n, int64_t div, int64_t* hi,
+                   int64_t* lo, psa_stream_t stream) {
+  PSA_REQUIRE(n >= 0, "negative size");
+  PSA_REQUIRE(div > 0, "div must be positive");
+  if (n == 0 || (hi == nullptr && lo == nullptr)) return PSA_OK;
+  PSA_REQUIRE(keys != nullptr, "keys is NULL");
+  const int64_t blocks = psa::ceil_div(n, kThreads);
+  PSA_REQUIRE(blocks <= 0x7fffffff, "n too large for one launch");
+  hipLaunchKernelGGL(split_keys_kernel, dim3(static_cast<unsigned>(blocks)),
+                     dim3(kThreads), 0, psa::as_stream(stream), keys, n, div, hi, lo);
   PSA_LAUNCH_CHECK();
   return PSA_OK;
 }

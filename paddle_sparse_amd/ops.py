@@ -224,6 +224,19 @@ def make_keys(a: torch.Tensor, b: torch.Tensor, mul: int, check_sorted: bool = F
     return keys, flag
 
 
+def split_keys(keys: torch.Tensor, div: int, want_hi: bool = True, want_lo: bool = True
+               ) -> Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]:
+    """(keys // div, keys % div): the two indices a key stream was built from,
+    without a permutation gather."""
+    keys = _index(keys, "keys")
+    hi = torch.empty_like(keys) if want_hi else None
+    lo = torch.empty_like(keys) if want_lo else None
+    with torch.cuda.device(keys.device):
+        check(_lib.load().psa_split_keys(_ptr(keys), keys.numel(), int(div), _ptr(hi), _ptr(lo),
+                                         _stream()))
+    return hi, lo
+
+
 def gather_rows(src: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
     """src[perm] along dim 0 for any dtype / trailing shape."""
     _gpu(src, "src")

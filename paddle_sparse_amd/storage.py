@@ -120,11 +120,15 @@ class SparseStorage(object):
         if not is_sorted and nnz > 0:
             keys, unsorted = ops.make_keys(self.row(), self._col, N, check_sorted=True)
             if int(unsorted.item()):
-                _, perm = index_sort(keys, M * N)
-                self._row = ops.gather_rows(self.row(), perm)
-                self._col = ops.gather_rows(self._col, perm)
-                if value is not None:
-                    self._value = ops.gather_rows(value, perm)
+                # row[perm] / col[perm] (storage.py:166-167) are read back
+                # from the sorted keys; a 4-byte scalar value rides the sort.
+                if value is not None and value.dim() == 1 and value.element_size() == 4:
+                    keys, self._value = ops.sort_pairs(keys, value, M * N)
+                else:
+                    keys, perm = index_sort(keys, M * N, with_sorted_inputs=True)
+                    if value is not None:
+                        self._value = ops.gather_rows(value, perm)
+                self._row, self._col = ops.split_keys(keys, N)
                 self._csr2csc = None
                 self._csc2csr = None
 
@@ -263,7 +267,15 @@ class SparseStorage(object):
         if self._csr2csc is None:  # storage.py:430-432: sort by (col, row)
             M, N = self._sparse_sizes
             keys, _ = ops.make_keys(self._col, self.row(), M)
-            _, self._csr2csc = index_sort(keys, M * N)
+            keys, self._csr2csc = index_sort(keys, M * N, with_sorted_inputs=True)
+            # The sorted keys are the (col, row) pairs in CSC order: what csc(),
+            # t() and the SpMM backward ask for next (row[csr2csc], and colptr
+            # = ind2ptr(col[csr2csc]), storage.py:391-395) is read off them
+            # sequentially instead of through two permutation gathers.
+            if keys.numel() > 0:
+                col_csc, self._row_csc = ops.split_keys(keys, M)
+                if self._colptr is None:
+                    self._colptr = ops.ind2ptr(col_csc, N)
         return self._csr2csc
 
     def has_csc2csr(self) -> bool:

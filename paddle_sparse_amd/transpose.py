@@ -17,8 +17,11 @@ def t(src: SparseTensor) -> SparseTensor:
     if value is not None:
         value = ops.gather_rows(value, csr2csc)
     M, N = st.sparse_sizes()
+    # The transposed row index is col[csr2csc] = the sorted column index.  With
+    # colptr cached (csr2csc() leaves it behind) it stays implicit: row() of the
+    # result expands it from rowptr on first use, as for any CSR-built storage.
     storage = SparseStorage(
-        row=ops.gather_rows(col, csr2csc),
+        row=ops.gather_rows(col, csr2csc) if st._colptr is None else None,
         rowptr=st._colptr,
         col=st._row_in_csc_order(),
         value=value,
@@ -29,6 +32,7 @@ def t(src: SparseTensor) -> SparseTensor:
         csr2csc=st._csc2csr,
         csc2csr=csr2csc,
         is_sorted=True,
+        trust_data=True,  # a permutation of an already validated storage
     )
     return src.from_storage(storage)
 

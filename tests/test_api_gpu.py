@@ -232,6 +232,15 @@ def test_reduce_dim0_dim1_vs_oracle(reduce, npdtype, tdtype):
             np.testing.assert_allclose(got, ref, rtol=1e-6)
         else:
             assert np.array_equal(got, ref), (reduce, dim)
+    # with the CSC caches present, dim 0 takes the atomic-free segment path: same results
+    t.storage.csr2csc()
+    assert t.storage.has_colptr()
+    got = getattr(t, reduce)(0).cpu().numpy()
+    ref = so.reduction(st, 0, reduce)
+    if npdtype is np.float32 and reduce == "mean":
+        np.testing.assert_allclose(got, ref, rtol=1e-6)
+    else:
+        assert np.array_equal(got, ref), (reduce, "csc")
     # value-less shortcuts (reduce.py:43-58)
     t0 = SparseTensor(row=idx(row), col=idx(col), sparse_sizes=(M, N))
     st0 = so.Storage(row, col, None, (M, N))

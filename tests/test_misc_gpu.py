@@ -28,6 +28,28 @@ def test_bincount_and_count2ptr(n, size, seed):
     assert np.array_equal(ptr, np.concatenate([[0], np.cumsum(ref)]))
 
 
+@pytest.mark.parametrize("n,div,hi_max,seed", [(0, 7, 5, 0), (1, 1, 1, 1), (100_000, 1000, 1000, 2),
+                                                (300_000, 3, 1 << 40, 3), (300_000, (1 << 33) + 5, 1 << 29, 4),
+                                                (1_000_000, 16_777_216, 16_777_216, 5)])
+def test_make_keys_split_keys_round_trip(n, div, hi_max, seed):
+    """split_keys undoes make_keys bit for bit (32-bit and 64-bit division paths)."""
+    from paddle_sparse_amd import ops
+
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, hi_max, n, dtype=np.int64)
+    b = rng.integers(0, div, n, dtype=np.int64)
+    a_d = dev(a) if n else torch.empty(0, dtype=torch.int64, device="cuda")
+    b_d = dev(b) if n else torch.empty(0, dtype=torch.int64, device="cuda")
+    keys, _ = ops.make_keys(a_d, b_d, div)
+    assert np.array_equal(keys.cpu().numpy(), a * div + b)
+    hi, lo = ops.split_keys(keys, div)
+    assert np.array_equal(hi.cpu().numpy(), a) and np.array_equal(lo.cpu().numpy(), b)
+    hi, lo = ops.split_keys(keys, div, want_lo=False)
+    assert lo is None and np.array_equal(hi.cpu().numpy(), a)
+    hi, lo = ops.split_keys(keys, div, want_hi=False)
+    assert hi is None and np.array_equal(lo.cpu().numpy(), b)
+
+
 @pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max"])
 @pytest.mark.parametrize("npdtype", [np.float32, np.float64, np.int32, np.int64])
 @pytest.mark.parametrize("tail", [(), (3,), (64,)])

@@ -127,6 +127,49 @@ def test_eye_caches_kat(kats):
             assert getattr(st, name)().tolist() == c[name], (c["M"], c["N"], name)
 
 
+@pytest.mark.parametrize("threads", [1, 4])
+def test_c_coalesce_kats_and_numpy(kats, threads):
+    """coalesce_oracle.c (the timed CPU baseline of the sort/coalesce rows)
+    gives the reference's known answers and the numpy restatement's results."""
+    k = kats["coalesce"]
+    val = np.array(k["value"], np.float32)
+    for op, key in (("add", "out_add"), ("max", "out_max")):
+        idx, out = oracle.coalesce_c(k["row"], k["col"], val, k["m"], k["n"], op, threads)
+        assert idx.tolist() == k["out_index"] and out.tolist() == k[key]
+    idx, out = oracle.coalesce_c(k["row"], k["col"], None, k["m"], k["n"], "add", threads)
+    assert idx.tolist() == k["out_index"] and out is None
+    k = kats["storage_coalesce"]
+    idx, out = oracle.coalesce_c(k["row"], k["col"], np.array(k["value"], np.float32), 2, 2, "add", threads)
+    assert idx.tolist() == [k["out_row"], k["out_col"]] and out.tolist() == k["out_value"]
+    idx, out = oracle.coalesce_c([], [], np.zeros(0, np.float32), 4, 4, "add", threads)
+    assert idx.shape == (2, 0) and out.shape == (0,)
+    rng = np.random.default_rng(7)
+    for M, N, nnz, D in ((1000, 1000, 10_000, None), (300, 70_000, 200_000, 2), (5, 3, 4000, 3)):
+        row, col = rng.integers(0, M, nnz), rng.integers(0, N, nnz)
+        v = rng.standard_normal((nnz,) if D is None else (nnz, D)).astype(np.float32)
+        for op in ("add", "mean", "min", "max"):
+            ref_idx, ref_v = so.coalesce(np.stack([row, col]), v, M, N, op)
+            idx, out = oracle.coalesce_c(row, col, v, M, N, op, threads)
+            assert np.array_equal(idx, ref_idx)
+            if op in ("min", "max"):
+                assert np.array_equal(out, ref_v)
+            else:  # the numpy side switches to reduceat (pairwise order) above 4096 values
+                np.testing.assert_allclose(out, ref_v, rtol=1e-5, atol=1e-6)
+        # already-sorted input skips the sort (storage.py:163)
+        idx2, out2 = oracle.coalesce_c(idx[0], idx[1], out, M, N, "add", threads)
+        assert np.array_equal(idx2, idx) and np.array_equal(out2, out)
+
+
+@pytest.mark.parametrize("threads", [1, 3])
+def test_c_index_sort_is_the_stable_permutation(threads):
+    rng = np.random.default_rng(8)
+    for n, mx in ((0, 10), (1, 1), (1000, 7), (50_000, 1 << 20), (20_000, 1 << 47)):
+        keys = rng.integers(0, mx, n)
+        s, p = oracle.index_sort_c(keys, mx, threads)
+        assert np.array_equal(p, so.index_sort(keys))
+        assert np.array_equal(s, keys[p])
+
+
 def test_segment_csr_fast_matches_loop():
     rng = np.random.default_rng(0)
     src = rng.integers(-50, 50, (300, 3)).astype(np.int64)
