@@ -279,6 +279,30 @@ int psa_scatter_reduce(int reduce, int dtype, const void* src,
                        int64_t dim_size, void* out, void* workspace,
                        size_t workspace_bytes, psa_stream_t stream);
 
+/* ---- spspmm: C = A @ B with both operands sparse (README.md:308-353) -------
+ * The reference documents `spspmm(indexA, valueA, indexB, valueB, m, k, n)` but
+ * ships no kernel for it.  Here it is expand / sort / compress on the path's
+ * own kernels: psa_spspmm_count -> psa_count2ptr (product offsets) ->
+ * psa_ptr2ind (owner A entry of every product) -> psa_spspmm_expand ->
+ * psa_sort_pairs_u32 | psa_index_sort -> psa_unique_* -> psa_segment_reduce.
+ *
+ * counts[e] = entries stored in B's row colA[e] (A entries in storage order). */
+int psa_spspmm_count(const int64_t* colA, int64_t nnzA, const int64_t* rowptrB,
+                     int64_t* counts, psa_stream_t stream);
+
+/* For product p in [0, total): e = owner[p], q = rowptrB[colA[e]] + p -
+ * offsets[e]; keys[p] = rowA[e] * n + colB[q]; vals[p] = valA[e] * valB[q]
+ * (a NULL value array counts as ones; vals may be NULL).  dtype: f32, f64,
+ * i32 or i64.  Products of one C entry keep the order in which a sequential
+ * row-by-row product meets them, so a stable sort + psa_segment_reduce's
+ * in-order kernel (runs averaging < 32 products) reproduces that sum bit for
+ * bit. */
+int psa_spspmm_expand(int dtype, const int64_t* rowA, const int64_t* colA,
+                      const void* valA, const int64_t* rowptrB, const int64_t* colB,
+                      const void* valB, const int64_t* offsets, const int64_t* owner,
+                      int64_t total, int64_t n, int64_t* keys, void* vals,
+                      psa_stream_t stream);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

@@ -12,6 +12,7 @@ Contents
                      transpose.py / reduce.py / add.py / mul.py
   coalesce_oracle.c  C form of the sort + coalesce path (the timed CPU
                      baseline of those rows; checked against storage_oracle)
+  spspmm_oracle.c    row-by-row sparse x sparse product (README.md:308-353)
 
 oracle/_ref (a build of the reference's own C++): NOT buildable in this
 image — csrc/*.cpp include <paddle/extension.h> (no Paddle headers on disk)
@@ -31,7 +32,8 @@ import numpy as np
 HERE = Path(__file__).resolve().parent
 BUILD_DIR = HERE / "_build"
 LIB_PATH = BUILD_DIR / "liboracle.so"
-SOURCES = [HERE / "convert_oracle.c", HERE / "spmm_oracle.c", HERE / "coalesce_oracle.c"]
+SOURCES = [HERE / "convert_oracle.c", HERE / "spmm_oracle.c", HERE / "coalesce_oracle.c",
+           HERE / "spspmm_oracle.c"]
 
 SUM, MEAN, MIN, MAX = 0, 1, 2, 3
 REDUCE_ID = {"sum": SUM, "add": SUM, "mean": MEAN, "min": MIN, "max": MAX}
@@ -121,6 +123,24 @@ def coalesce_c(row, col, value, M: int, N: int, reduce: str = "add", threads: in
     if value is None:
         return index, None
     return index, out_val[:cnt].reshape((cnt,) + value.shape[1:])
+
+
+def spspmm(indexA, valueA, indexB, valueB, m: int, k: int, n: int):
+    """README.md:308-353 on coalesced COO operands -> (index[2, nnz'], value') — spspmm_oracle.c."""
+    indexA, indexB = _i64(indexA), _i64(indexB)
+    valueA, valueB = _f32(valueA), _f32(valueB)
+    rowptrA, rowptrB = ind2ptr(indexA[0], m), ind2ptr(indexB[0], k)
+    colA, colB = _i64(indexA[1]), _i64(indexB[1])
+    fn = lib().oracle_spspmm_f32
+    fn.restype = ctypes.c_int64
+    args = [_p(rowptrA, ctypes.c_int64), _p(colA, ctypes.c_int64), _p(valueA, ctypes.c_float),
+            _p(rowptrB, ctypes.c_int64), _p(colB, ctypes.c_int64), _p(valueB, ctypes.c_float),
+            ctypes.c_int64(m), ctypes.c_int64(n)]
+    nnz = fn(*args, None, None, None)
+    row, col = np.empty(nnz, np.int64), np.empty(nnz, np.int64)
+    val = np.empty(nnz, np.float32)
+    fn(*args, _p(row, ctypes.c_int64), _p(col, ctypes.c_int64), _p(val, ctypes.c_float))
+    return np.stack([row, col]), val
 
 
 def spmm(reduce: str, rowptr, col, value, mat, threads: int = 1):

@@ -33,6 +33,7 @@ from .convert import to_scipy, from_scipy  # noqa: E402,F401
 from .coalesce import coalesce  # noqa: E402,F401
 from .transpose import transpose, t  # noqa: E402,F401
 from .matmul import spmm, matmul  # noqa: E402,F401
+from .spspmm import spspmm  # noqa: E402,F401
 
 __all__ = [
     "SparseStorage",
@@ -63,5 +64,6 @@ __all__ = [
     "transpose",
     "spmm",
     "matmul",
+    "spspmm",
     "__version__",
 ]

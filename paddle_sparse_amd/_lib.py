@@ -64,6 +64,10 @@ SIGNATURES = {
     "psa_scatter_workspace_bytes": (c_size_t, [c_int64]),
     "psa_scatter_reduce": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int64, c_int64,
                                    c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "psa_spspmm_count": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "psa_spspmm_expand": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
+                                  c_void_p, c_void_p]),
 }
 
 _lib = None

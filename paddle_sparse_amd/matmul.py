@@ -72,7 +72,13 @@ def spmm_sparse(src: SparseTensor, other: torch.Tensor, reduce: str = "sum") -> 
 def matmul(src: SparseTensor, other, reduce: str = "sum") -> torch.Tensor:
     if isinstance(other, torch.Tensor):
         return spmm_sparse(src, other, reduce)
-    raise NotImplementedError("sparse @ sparse (spspmm) is not part of this build (SURVEY.md §8(f) f-4)")
+    if isinstance(other, SparseTensor):
+        if reduce not in ("sum", "add"):
+            raise NotImplementedError("sparse @ sparse supports reduce='sum' only")
+        from .spspmm import spspmm_tensor
+
+        return spspmm_tensor(src, other)
+    raise ValueError("matmul: `other` must be a dense torch.Tensor or a SparseTensor")
 
 
 def spmm(index: torch.Tensor, value: Optional[torch.Tensor], m: int, n: int,

@@ -425,3 +425,38 @@ def scatter(src: torch.Tensor, index: torch.Tensor, dim_size: int, reduce: str =
                                      index.numel(), D, dim_size, _ptr(out), _ptr(ws), ws.numel(),
                                      _stream()))
     return out
+
+
+def spspmm_count(colA: torch.Tensor, rowptrB: torch.Tensor) -> torch.Tensor:
+    """counts[e] = stored entries of B's row colA[e] (products A entry e takes part in)."""
+    colA, rowptrB = _index(colA, "colA"), _index(rowptrB, "rowptrB")
+    out = torch.empty_like(colA)
+    with torch.cuda.device(colA.device):
+        check(_lib.load().psa_spspmm_count(_ptr(colA), colA.numel(), _ptr(rowptrB), _ptr(out),
+                                           _stream()))
+    return out
+
+
+def spspmm_expand(rowA, colA, valA, rowptrB, colB, valB, offsets, owner, total: int, n: int,
+                  dtype: torch.dtype):
+    """All `total` partial products of A @ B as (key = i * n + j, value) pairs,
+    in A-storage order (see csrc/spspmm.hip)."""
+    rowA, colA = _index(rowA, "rowA"), _index(colA, "colA")
+    rowptrB, colB = _index(rowptrB, "rowptrB"), _index(colB, "colB")
+    offsets, owner = _index(offsets, "offsets"), _index(owner, "owner")
+    if dtype not in (torch.float32, torch.float64, torch.int32, torch.int64):
+        raise TypeError(f"spspmm: unsupported dtype {dtype}")
+    for name, v, cnt in (("valueA", valA, colA.numel()), ("valueB", valB, colB.numel())):
+        if v is not None:
+            _gpu(v, name)
+            if v.dtype != dtype or v.dim() != 1 or v.numel() != cnt or not v.is_contiguous():
+                raise ValueError(f"{name} must be a contiguous 1-D {dtype} tensor with one entry per index")
+    has_value = valA is not None or valB is not None
+    keys = torch.empty(total, dtype=torch.int64, device=colA.device)
+    vals = torch.empty(total, dtype=dtype, device=colA.device) if has_value else None
+    with torch.cuda.device(colA.device):
+        check(_lib.load().psa_spspmm_expand(_DTYPE_ID[dtype], _ptr(rowA), _ptr(colA), _ptr(valA),
+                                            _ptr(rowptrB), _ptr(colB), _ptr(valB), _ptr(offsets),
+                                            _ptr(owner), int(total), int(n), _ptr(keys), _ptr(vals),
+                                            _stream()))
+    return keys, vals

@@ -1,0 +1,94 @@
+"""spspmm(indexA, valueA, indexB, valueB, m, k, n) — sparse x sparse product
+(README.md:308-353; documented by the reference, no kernel in its tree).
+
+Expand / sort / compress on the path's own HIP kernels:
+
+    counts[e]  = |B row colA[e]|                 spspmm_count
+    offsets    = [0, cumsum(counts)]             count2ptr      (one host read: total)
+    owner[p]   = A entry of product p            ptr2ind
+    key, val   = (i*n + j, a*b) per product      spspmm_expand
+    sort by key (stable), add the runs           the coalesce chain (coalesce.py)
+
+The products of one C entry reach the segmented sum in the order a sequential
+row-by-row product meets them (A's storage order, then B's).  While runs
+average fewer than 32 products the sum is taken in exactly that order and fp32
+results equal a Gustavson CPU product bit for bit; longer runs are summed
+lane-strided by one wave each (a fixed order too, within fp32 rounding of the
+sequential one).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import ops
+from .coalesce import _stack_index, coalesce
+
+
+def _spspmm_csr(rowA, colA, valueA, rowptrB, colB, valueB, m: int, n: int):
+    """A as sorted COO (row, col, value), B as CSR; returns (row, col, value) of C."""
+    dtype = valueA.dtype if valueA is not None else (valueB.dtype if valueB is not None else torch.float32)
+    device = colA.device
+    empty_i = torch.empty(0, dtype=torch.int64, device=device)
+    has_value = valueA is not None or valueB is not None
+    empty_v = torch.empty(0, dtype=dtype, device=device) if has_value else None
+    if colA.numel() == 0 or colB.numel() == 0:
+        return empty_i, empty_i.clone(), empty_v
+    counts = ops.spspmm_count(colA, rowptrB)
+    offsets = ops.count2ptr(counts)
+    total = int(offsets[-1].item())
+    if total == 0:
+        return empty_i, empty_i.clone(), empty_v
+    owner = ops.ptr2ind(offsets, total)
+    keys, vals = ops.spspmm_expand(rowA, colA, valueA, rowptrB, colB, valueB, offsets, owner,
+                                   total, n, dtype)
+    del owner, offsets, counts
+    # rows of A are sorted, so keys are already grouped by C row; the sort
+    # orders columns inside rows and brings equal (i, j) together
+    if vals is not None and vals.element_size() == 4:
+        keys, vals = ops.sort_pairs(keys, vals, m * n)
+        perm = None
+    else:
+        keys, perm = ops.index_sort(keys, m * n, with_sorted_inputs=True)
+    count, ptr, row, col = ops.unique_sorted(keys, n)
+    if vals is not None:
+        if count < total:
+            vals = ops.segment_csr(vals, ptr, "sum", perm=perm)
+        elif perm is not None:
+            vals = ops.gather_rows(vals, perm)
+    return row, col, vals
+
+
+def spspmm(indexA: torch.Tensor, valueA: Optional[torch.Tensor], indexB: torch.Tensor,
+           valueB: Optional[torch.Tensor], m: int, k: int, n: int, coalesced: bool = False
+           ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """Matrix product of two sparse matrices given as COO (index[2, nnz], value).
+    Both must be coalesced (row-major sorted, no duplicates); `coalesced=True`
+    coalesces them first.  Returns the coalesced (index, value) of the [m, n]
+    product."""
+    if coalesced:
+        indexA, valueA = coalesce(indexA, valueA, m, k)
+        indexB, valueB = coalesce(indexB, valueB, k, n)
+    rowA, colA = indexA[0].contiguous(), indexA[1].contiguous()
+    rowB, colB = indexB[0].contiguous(), indexB[1].contiguous()
+    rowptrB = ops.ind2ptr(rowB, k)
+    row, col, value = _spspmm_csr(rowA, colA, valueA, rowptrB, colB, valueB, m, n)
+    return _stack_index(row, col), value
+
+
+def spspmm_tensor(a, b):
+    """SparseTensor @ SparseTensor -> SparseTensor (the `matmul(src, other)`
+    branch for a sparse `other`)."""
+    from .tensor import SparseTensor
+
+    assert a.size(1) == b.size(0), "inner dimensions differ"
+    rowA, colA, valueA = a.coo()
+    rowptrB, colB, valueB = b.csr()
+    m, n = a.size(0), b.size(1)
+    row, col, value = _spspmm_csr(rowA, colA, valueA, rowptrB, colB, valueB, m, n)
+    return SparseTensor(row=row, col=col, value=value, sparse_sizes=(m, n), is_sorted=True,
+                        trust_data=True)
+
+
+__all__ = ["spspmm", "spspmm_tensor"]

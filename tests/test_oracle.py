@@ -170,6 +170,33 @@ def test_c_index_sort_is_the_stable_permutation(threads):
         assert np.array_equal(s, keys[p])
 
 
+def test_spspmm_readme_kat_and_scipy(kats):
+    k = kats["spspmm"]
+    idx, val = oracle.spspmm(k["indexA"], k["valueA"], k["indexB"], k["valueB"], k["m"], k["k"], k["n"])
+    assert idx.tolist() == k["indexC"] and val.tolist() == k["valueC"]
+    rng = np.random.default_rng(9)
+    for m, kk, n, nnzA, nnzB in ((50, 40, 30, 300, 200), (400, 300, 500, 5000, 4000), (7, 5000, 9, 900, 2000)):
+        keyA, keyB = np.unique(rng.integers(0, m * kk, nnzA)), np.unique(rng.integers(0, kk * n, nnzB))
+        iA, iB = np.stack([keyA // kk, keyA % kk]), np.stack([keyB // n, keyB % n])
+        # small integers: every fp32 sum is exact, so scipy's order cannot matter
+        vA = rng.integers(-4, 5, keyA.size).astype(np.float32)
+        vB = rng.integers(-4, 5, keyB.size).astype(np.float32)
+        idx, val = oracle.spspmm(iA, vA, iB, vB, m, kk, n)
+        A = scipy.sparse.csr_matrix((vA, (iA[0], iA[1])), (m, kk))
+        B = scipy.sparse.csr_matrix((vB, (iB[0], iB[1])), (kk, n))
+        dense = np.zeros((m, n), np.float32)
+        dense[idx[0], idx[1]] = val
+        assert np.array_equal(dense, (A @ B).toarray())
+        # structure: every (i, j) with a structural product, explicit zeros kept, row-major sorted
+        S = (abs(A).sign() @ abs(B).sign()).tocoo()
+        structural = np.unique(np.asarray(S.row, np.int64) * n + S.col)
+        A1 = scipy.sparse.csr_matrix((np.ones(keyA.size), (iA[0], iA[1])), (m, kk))
+        B1 = scipy.sparse.csr_matrix((np.ones(keyB.size), (iB[0], iB[1])), (kk, n))
+        full = (A1 @ B1).tocoo()
+        assert np.array_equal(idx[0] * n + idx[1], np.unique(np.asarray(full.row, np.int64) * n + full.col))
+        assert structural.size <= idx.shape[1]
+
+
 def test_segment_csr_fast_matches_loop():
     rng = np.random.default_rng(0)
     src = rng.integers(-50, 50, (300, 3)).astype(np.int64)
