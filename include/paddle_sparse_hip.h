@@ -303,6 +303,55 @@ int psa_spspmm_expand(int dtype, const int64_t* rowA, const int64_t* colA,
                       int64_t total, int64_t n, int64_t* keys, void* vals,
                       psa_stream_t stream);
 
+/* ---- sample_adj on the GPU ------------------------------------------------
+ * Replaces sample_adj (csrc/sample.cpp:8-24, which throws for GPU tensors;
+ * CPU text csrc/cpu/sample_cpu.cpp:9-148).  The op is a chain, because its
+ * output sizes are data dependent (two host reads: E and the new-node count):
+ *
+ *   psa_sample_count  -> psa_count2ptr (out_rowptr; E = out_rowptr[S])
+ *   psa_ptr2ind(out_rowptr) -> owner;  psa_sample_select -> e_raw[E]
+ *   psa_relabel_mark -> flags;  psa_count2ptr(flags) -> rank; new = rank[E]
+ *   psa_relabel_finish -> n_id[S + new], keys[E] = i * n_out + new column id
+ *   psa_index_sort(keys) -> out_col = keys % n_out, out_e_id = e_raw[perm]
+ *
+ * Conventions where the CPU text leaves the order open: picks of one row are
+ * taken in draw order (sample_cpu.cpp:108 iterates an unordered_set), and
+ * equal new column ids inside a row keep that order (the reference's std::sort
+ * at :134-140 is not stable).  num_neighbors < 0 (no sampling) involves
+ * neither, apart from multi-edges.
+ *
+ * Random draws are counter based: draw t of subset row i is a function of
+ * (seed, i, t) alone (oracle/sample_oracle.c restates it), in place of the
+ * reference's framework-global generator.
+ *
+ * counts[i] = picks of subset row i: deg if num_neighbors < 0; num_neighbors if
+ * replace and deg > 0; min(deg, num_neighbors) otherwise. */
+int psa_sample_count(const int64_t* rowptr, const int64_t* idx, int64_t S,
+                     int64_t num_neighbors, int replace, int64_t* counts,
+                     psa_stream_t stream);
+
+/* e_raw[p] = edge picked by slot p (p = out_rowptr[i] + t, i = owner[p]). */
+int psa_sample_select(const int64_t* rowptr, const int64_t* idx, int64_t S,
+                      const int64_t* out_rowptr, const int64_t* owner, int64_t E,
+                      int64_t num_neighbors, int replace, uint64_t seed,
+                      int64_t* e_raw, psa_stream_t stream);
+
+/* newid: int64[num_nodes] scratch (filled by the call).  Afterwards newid[c] =
+ * position of c in idx (the last one for duplicates, as the CPU map does) for
+ * subset nodes, -2 - (first slot that picked c) for other picked nodes.
+ * flags[p] = 1 when slot p is that first pick, else 0 (int64[E]). */
+int psa_relabel_mark(const int64_t* idx, int64_t S, const int64_t* col,
+                     const int64_t* e_raw, int64_t E, int64_t num_nodes,
+                     int64_t* newid, int64_t* flags, psa_stream_t stream);
+
+/* rank = exclusive scan of flags (psa_count2ptr); n_out = S + rank[E].
+ * n_id[0:S] = idx, n_id[S + rank[p]] = node first picked at slot p;
+ * keys[p] = owner[p] * n_out + (new id of slot p's node). */
+int psa_relabel_finish(const int64_t* idx, int64_t S, const int64_t* col,
+                       const int64_t* e_raw, int64_t E, const int64_t* newid,
+                       const int64_t* rank, const int64_t* owner, int64_t n_out,
+                       int64_t* n_id, int64_t* keys, psa_stream_t stream);
+
 #ifdef __cplusplus
 } /* extern "C" */
 #endif

@@ -13,6 +13,7 @@ Contents
   coalesce_oracle.c  C form of the sort + coalesce path (the timed CPU
                      baseline of those rows; checked against storage_oracle)
   spspmm_oracle.c    row-by-row sparse x sparse product (README.md:308-353)
+  sample_oracle.c    sample_adj, restating csrc/cpu/sample_cpu.cpp
 
 oracle/_ref (a build of the reference's own C++): NOT buildable in this
 image — csrc/*.cpp include <paddle/extension.h> (no Paddle headers on disk)
@@ -33,7 +34,7 @@ HERE = Path(__file__).resolve().parent
 BUILD_DIR = HERE / "_build"
 LIB_PATH = BUILD_DIR / "liboracle.so"
 SOURCES = [HERE / "convert_oracle.c", HERE / "spmm_oracle.c", HERE / "coalesce_oracle.c",
-           HERE / "spspmm_oracle.c"]
+           HERE / "spspmm_oracle.c", HERE / "sample_oracle.c"]
 
 SUM, MEAN, MIN, MAX = 0, 1, 2, 3
 REDUCE_ID = {"sum": SUM, "add": SUM, "mean": MEAN, "min": MIN, "max": MAX}
@@ -141,6 +142,30 @@ def spspmm(indexA, valueA, indexB, valueB, m: int, k: int, n: int):
     val = np.empty(nnz, np.float32)
     fn(*args, _p(row, ctypes.c_int64), _p(col, ctypes.c_int64), _p(val, ctypes.c_float))
     return np.stack([row, col]), val
+
+
+def sample_adj(rowptr, col, idx, num_neighbors: int, replace: bool = False, seed: int = 0,
+               num_nodes: int = None):
+    """csrc/cpu/sample_cpu.cpp:9-148 -> (out_rowptr, out_col, n_id, e_id) — sample_oracle.c."""
+    rowptr, col, idx = _i64(rowptr), _i64(col), _i64(idx)
+    S = idx.size
+    if num_nodes is None:
+        num_nodes = max(rowptr.size - 1, int(col.max()) + 1 if col.size else 0)
+    deg = rowptr[idx + 1] - rowptr[idx] if S else np.zeros(0, np.int64)
+    cap = int(deg.sum()) if num_neighbors < 0 else S * max(int(num_neighbors), 0)
+    out_rowptr = np.empty(S + 1, np.int64)
+    out_col, e_id = np.empty(cap, np.int64), np.empty(cap, np.int64)
+    n_id = np.empty(S + cap, np.int64)
+    fn = lib().oracle_sample_adj
+    fn.restype = ctypes.c_int64
+    n = fn(_p(rowptr, ctypes.c_int64), _p(col, ctypes.c_int64), _p(idx, ctypes.c_int64),
+           ctypes.c_int64(S), ctypes.c_int64(num_nodes), ctypes.c_int64(num_neighbors),
+           ctypes.c_int(int(bool(replace))), ctypes.c_uint64(seed & (2**64 - 1)), ctypes.c_int64(cap),
+           _p(out_rowptr, ctypes.c_int64), _p(out_col, ctypes.c_int64), _p(n_id, ctypes.c_int64),
+           _p(e_id, ctypes.c_int64))
+    assert n >= 0
+    E = int(out_rowptr[-1])
+    return out_rowptr, out_col[:E].copy(), n_id[:n].copy(), e_id[:E].copy()
 
 
 def spmm(reduce: str, rowptr, col, value, mat, threads: int = 1):

@@ -34,6 +34,8 @@ from .coalesce import coalesce  # noqa: E402,F401
 from .transpose import transpose, t  # noqa: E402,F401
 from .matmul import spmm, matmul  # noqa: E402,F401
 from .spspmm import spspmm  # noqa: E402,F401
+from .cat import cat  # noqa: E402,F401
+from .sample import sample, sample_adj, permute  # noqa: E402,F401
 
 __all__ = [
     "SparseStorage",
@@ -65,5 +67,9 @@ __all__ = [
     "spmm",
     "matmul",
     "spspmm",
+    "cat",
+    "sample",
+    "sample_adj",
+    "permute",
     "__version__",
 ]

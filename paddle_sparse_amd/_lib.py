@@ -6,7 +6,7 @@ ops fails loudly — there is no CPU or eager fallback anywhere in this package.
 from __future__ import annotations
 
 import ctypes
-from ctypes import c_int, c_int64, c_size_t, c_void_p, c_char_p
+from ctypes import c_int, c_int64, c_size_t, c_uint64, c_void_p, c_char_p
 from pathlib import Path
 
 # The framework must bring its HIP runtime into the process FIRST: the core
@@ -64,6 +64,13 @@ SIGNATURES = {
     "psa_scatter_workspace_bytes": (c_size_t, [c_int64]),
     "psa_scatter_reduce": (c_int, [c_int, c_int, c_void_p, c_void_p, c_int64, c_int64,
                                    c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "psa_sample_count": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p]),
+    "psa_sample_select": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                                  c_int64, c_int, c_uint64, c_void_p, c_void_p]),
+    "psa_relabel_mark": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64,
+                                 c_void_p, c_void_p, c_void_p]),
+    "psa_relabel_finish": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
+                                   c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "psa_spspmm_count": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "psa_spspmm_expand": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p,

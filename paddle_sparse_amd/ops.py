@@ -460,3 +460,49 @@ def spspmm_expand(rowA, colA, valA, rowptrB, colB, valB, offsets, owner, total: 
                                             _ptr(owner), int(total), int(n), _ptr(keys), _ptr(vals),
                                             _stream()))
     return keys, vals
+
+
+def sample_adj(rowptr: torch.Tensor, col: torch.Tensor, idx: torch.Tensor, num_neighbors: int,
+               replace: bool = False, seed: int = 0, num_cols: Optional[int] = None
+               ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """paddle_sparse_ops.sample_adj(rowptr, col, idx, num_neighbors, replace)
+    (csrc/sample.cpp:8-24, CPU text csrc/cpu/sample_cpu.cpp:9-148) on GPU
+    tensors: returns (out_rowptr, out_col, n_id, e_id).  `seed` selects the
+    counter-based random stream (see include/paddle_sparse_hip.h); `num_cols`
+    (exclusive bound on col, known to the SparseTensor caller) saves the
+    col.max() pass that sizes the relabel scratch."""
+    rowptr, col, idx = _index(rowptr, "rowptr"), _index(col, "col"), _index(idx, "idx")
+    dev = rowptr.device
+    lib = _lib.load()
+    S, k, rep, seed = idx.numel(), int(num_neighbors), int(bool(replace)), int(seed) & (2**64 - 1)
+    num_nodes = rowptr.numel() - 1
+    with torch.cuda.device(dev):
+        counts = torch.empty(S, dtype=torch.int64, device=dev)
+        check(lib.psa_sample_count(_ptr(rowptr), _ptr(idx), S, k, rep, _ptr(counts), _stream()))
+        out_rowptr = count2ptr(counts)
+        E = int(out_rowptr[-1].item())
+        owner = ptr2ind(out_rowptr, E)
+        e_raw = torch.empty(E, dtype=torch.int64, device=dev)
+        check(lib.psa_sample_select(_ptr(rowptr), _ptr(idx), S, _ptr(out_rowptr), _ptr(owner), E,
+                                    k, rep, seed, _ptr(e_raw), _stream()))
+        # node ids live in [0, max(num_rows, num_cols)): col values index newid too
+        if num_cols is not None:
+            n_scratch = max(num_nodes, int(num_cols))
+        else:
+            n_scratch = max(num_nodes, int(col.max().item()) + 1 if col.numel() else 0) if E else num_nodes
+        newid = torch.empty(n_scratch, dtype=torch.int64, device=dev)
+        flags = torch.empty(E, dtype=torch.int64, device=dev)
+        check(lib.psa_relabel_mark(_ptr(idx), S, _ptr(col), _ptr(e_raw), E, n_scratch,
+                                   _ptr(newid), _ptr(flags), _stream()))
+        rank = count2ptr(flags)
+        n_out = S + int(rank[-1].item())
+        n_id = torch.empty(n_out, dtype=torch.int64, device=dev)
+        keys = torch.empty(E, dtype=torch.int64, device=dev)
+        check(lib.psa_relabel_finish(_ptr(idx), S, _ptr(col), _ptr(e_raw), E, _ptr(newid),
+                                     _ptr(rank), _ptr(owner), n_out, _ptr(n_id), _ptr(keys),
+                                     _stream()))
+    if E == 0:
+        return out_rowptr, keys, n_id, e_raw
+    keys, perm = index_sort(keys, max(S * n_out, 1), with_sorted_inputs=True)
+    _, out_col = split_keys(keys, n_out, want_hi=False)
+    return out_rowptr, out_col, n_id, gather_rows(e_raw, perm)

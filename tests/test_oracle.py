@@ -197,6 +197,45 @@ def test_spspmm_readme_kat_and_scipy(kats):
         assert structural.size <= idx.shape[1]
 
 
+def test_sample_adj_kat_and_properties(kats):
+    k = kats["sample_adj"]
+    M = k["sparse_sizes"][0]
+    rowptr = oracle.ind2ptr(k["row"], M)
+    col, subset = np.array(k["col"]), np.array(k["subset"])
+    value = np.arange(len(k["row"]))
+    rp, c, n_id, e_id = oracle.sample_adj(rowptr, col, subset, -1)
+    a = k["all_neighbors"]
+    assert n_id.tolist() == a["n_id"]
+    assert oracle.ptr2ind(rp, c.size).tolist() == a["row"] and c.tolist() == a["col"]
+    assert value[e_id].tolist() == a["val"]
+    for seed in range(5):
+        rp, c, n_id, e_id = oracle.sample_adj(rowptr, col, subset, 2, True, seed)
+        assert c.size == k["nnz_2_with_replacement"]
+        rp, c, n_id, e_id = oracle.sample_adj(rowptr, col, subset, 2, False, seed)
+        assert c.size == k["nnz_2_without_replacement"]
+    # larger graph: picks are edges of the right row, distinct without replacement, ids consistent
+    rng = np.random.default_rng(3)
+    row, rowptr, col, _ = random_csr(3000, 3000, 40_000, 3)
+    subset = rng.permutation(3000)[:500]
+    for kk, rep in ((5, False), (5, True), (50, False), (-1, False)):
+        rp, c, n_id, e_id = oracle.sample_adj(rowptr, col, subset, kk, rep, seed=11)
+        assert np.array_equal(n_id[:500], subset) and np.unique(n_id).size == n_id.size
+        assert np.array_equal(n_id[c], col[e_id])
+        r = oracle.ptr2ind(rp, c.size)
+        assert np.array_equal(row[e_id], subset[r])
+        deg = rowptr[subset + 1] - rowptr[subset]
+        want = deg if kk < 0 else (np.where(deg > 0, kk, 0) if rep else np.minimum(deg, kk))
+        assert np.array_equal(rp[1:] - rp[:-1], want)
+        assert np.all((c[1:] >= c[:-1]) | (r[1:] != r[:-1]))
+        if not rep:
+            assert np.unique(e_id).size == e_id.size
+        # a different seed gives a different sample, the same seed the same one
+        if kk == 5:
+            again = oracle.sample_adj(rowptr, col, subset, kk, rep, seed=11)
+            other = oracle.sample_adj(rowptr, col, subset, kk, rep, seed=12)
+            assert np.array_equal(again[3], e_id) and not np.array_equal(other[3], e_id)
+
+
 def test_segment_csr_fast_matches_loop():
     rng = np.random.default_rng(0)
     src = rng.integers(-50, 50, (300, 3)).astype(np.int64)
