@@ -189,3 +189,77 @@ PD_BUILD_OP(segment_csr_perm)
     .Outputs({"out"})
     .Attrs({"reduce: int64_t"})
     .SetKernelFn(PD_KERNEL(segment_csr_perm));
+
+// ---- sample_adj (csrc/sample.cpp:8-40: same name, inputs, outputs, attrs) ----------
+// The reference's kernel function throws "No CUDA version supported" for GPU
+// tensors (csrc/sample.cpp:13-18); this one runs the chain of csrc/sample.hip.
+// Two sizes are data dependent (as in the reference, which skips InferShape for
+// that reason, csrc/sample.cpp:33): E and the number of new nodes are read back
+// from the device.  `seed` comes from Paddle's default generator so that
+// paddle.seed() governs the draws as it does in the reference.
+std::vector<paddle::Tensor> sample_adj(paddle::Tensor& rowptr, paddle::Tensor& col, paddle::Tensor& idx,
+                                       int64_t num_neighbors, bool replace) {
+  CHECK_GPU(rowptr);
+  CHECK_GPU(col);
+  CHECK_GPU(idx);
+  CHECK_I64(rowptr);
+  CHECK_I64(col);
+  CHECK_I64(idx);
+  PD_CHECK(idx.shape().size() == 1, "idx must be 1-D");
+  void* s = stream_of(rowptr);
+  const auto place = rowptr.place();
+  const int64_t S = idx.numel(), num_rows = rowptr.numel() - 1;
+  const uint64_t seed = static_cast<uint64_t>(
+      paddle::experimental::randint(0, INT64_MAX, {1}, paddle::DataType::INT64, paddle::CPUPlace()).data<int64_t>()[0]);
+  auto i64_empty = [&](int64_t n) { return paddle::empty({n}, paddle::DataType::INT64, place); };
+  auto scan = [&](const paddle::Tensor& counts, int64_t n) {
+    auto out = i64_empty(n + 1);
+    const int64_t wsb = static_cast<int64_t>(psa_count2ptr_workspace_bytes(n));
+    auto ws = paddle::empty({wsb}, paddle::DataType::UINT8, place);
+    PSA_CALL(psa_count2ptr(i64(counts), n, out.data<int64_t>(), ws.data<uint8_t>(), static_cast<size_t>(wsb), s));
+    return out;
+  };
+  auto last = [&](const paddle::Tensor& ptr, int64_t n) {  // one 8-byte device -> host read
+    return paddle::experimental::slice(ptr, {0}, {n}, {n + 1}, {}, {}).copy_to(paddle::CPUPlace(), true).data<int64_t>()[0];
+  };
+
+  auto counts = i64_empty(S);
+  PSA_CALL(psa_sample_count(i64(rowptr), i64(idx), S, num_neighbors, replace, counts.data<int64_t>(), s));
+  auto out_rowptr = scan(counts, S);
+  const int64_t E = last(out_rowptr, S);
+  auto owner = i64_empty(E), e_raw = i64_empty(E), flags = i64_empty(E), keys = i64_empty(E);
+  PSA_CALL(psa_ptr2ind(i64(out_rowptr), S, E, owner.data<int64_t>(), s));
+  PSA_CALL(psa_sample_select(i64(rowptr), i64(idx), S, i64(out_rowptr), i64(owner), E, num_neighbors, replace, seed,
+                             e_raw.data<int64_t>(), s));
+  const int64_t num_nodes =
+      std::max<int64_t>(num_rows, col.numel() ? paddle::experimental::max(col, {}, false)
+                                                        .copy_to(paddle::CPUPlace(), true).data<int64_t>()[0] + 1 : 0);
+  auto newid = i64_empty(num_nodes);
+  PSA_CALL(psa_relabel_mark(i64(idx), S, i64(col), i64(e_raw), E, num_nodes, newid.data<int64_t>(),
+                            flags.data<int64_t>(), s));
+  auto rank = scan(flags, E);
+  const int64_t n_out = S + last(rank, E);
+  auto n_id = i64_empty(n_out);
+  PSA_CALL(psa_relabel_finish(i64(idx), S, i64(col), i64(e_raw), E, i64(newid), i64(rank), i64(owner), n_out,
+                              n_id.data<int64_t>(), keys.data<int64_t>(), s));
+  // rows by new column id: one stable sort of i * n_out + id, then read id back
+  auto sorted = i64_empty(E), perm = i64_empty(E), out_col = i64_empty(E), e_id = i64_empty(E);
+  const int64_t max_key = std::max<int64_t>(S * n_out, 1);
+  const int64_t wsb = static_cast<int64_t>(psa_index_sort_workspace_bytes(E, max_key));
+  auto ws = paddle::empty({wsb > 0 ? wsb : 1}, paddle::DataType::UINT8, place);
+  PSA_CALL(psa_index_sort(i64(keys), E, max_key, sorted.data<int64_t>(), perm.data<int64_t>(), ws.data<uint8_t>(),
+                          static_cast<size_t>(wsb), s));
+  if (E > 0) PSA_CALL(psa_split_keys(i64(sorted), E, n_out, nullptr, out_col.data<int64_t>(), s));
+  PSA_CALL(psa_gather_rows(e_raw.data<int64_t>(), i64(perm), E, 8, e_id.data<int64_t>(), s));
+  return {out_rowptr, out_col, n_id, e_id};
+}
+std::vector<paddle::DataType> sample_adj_infer_dtype(const paddle::DataType rowptr_dtype, const paddle::DataType col_dtype,
+                                                     const paddle::DataType idx_dtype) {
+  return {rowptr_dtype, col_dtype, col_dtype, col_dtype};
+}
+PD_BUILD_OP(sample_adj)
+    .Inputs({"rowptr", "col", "idx"})
+    .Outputs({"out_rowptr", "out_col", "out_n_id", "out_e_id"})
+    .Attrs({"num_neighbors: int64_t", "replace: bool"})
+    .SetKernelFn(PD_KERNEL(sample_adj))
+    .SetInferDtypeFn(PD_INFER_DTYPE(sample_adj_infer_dtype));
