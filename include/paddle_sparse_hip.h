@@ -150,6 +150,36 @@ int psa_spmm_minmax_bw(const int64_t* col, const float* value, const float* mat,
                        int64_t N, int64_t K, int64_t nnz, float* grad_value,
                        float* grad_mat, psa_stream_t stream);
 
+/* min/max backward WITHOUT atomics, in one pass over the CSC view of the
+ * matrix (the caches storage.py:425-434 / tensor.py:254-257 already keep for
+ * the sum/mean backward).  For column c and each stored entry e = (r, c):
+ *   grad_mat[c, k]  += w_e * grad[r, k]        where arg_out[r, k] == e
+ *   grad_value[e]    = sum of mat[c, k] * grad[r, k] over those k
+ * Scattered float atomics run at ~20-50 G adds/s on this chip whatever their
+ * shape (256 M of them at M = 2 M, K = 128: 5 ms); this pass is a gather like
+ * the forward, every output element is written once and sums run in CSC edge
+ * order (reproducible bit for bit).
+ *
+ * tag: uint8[nnz] from psa_csc_edge_tags (depends on the sparsity structure
+ * only: cache it with csr2csc).  value: f32[nnz] in CSR order, or NULL.
+ * grad_value: f32[nnz] in CSR order or NULL (then mat may be NULL too).
+ * workspace: psa_spmm_minmax_bw_csc_workspace_bytes(M, K, nnz) bytes, 16-byte
+ * aligned (M*K bytes of arg_out compressed to row-local byte indices +
+ * long-column scratch).  Returns PSA_ERR_UNSUPPORTED unless K % 4 == 0 and
+ * K <= 256 (callers then use psa_spmm_minmax_bw). */
+int psa_csc_edge_tags(const int64_t* rowptr, const int64_t* row_csc,
+                      const int64_t* csr2csc, int64_t nnz, uint8_t* tag,
+                      psa_stream_t stream);
+size_t psa_spmm_minmax_bw_csc_workspace_bytes(int64_t M, int64_t K, int64_t nnz);
+int psa_spmm_minmax_bw_csc(const int64_t* rowptr, const int64_t* colptr,
+                           const int64_t* row_csc, const int64_t* csr2csc,
+                           const uint8_t* tag, const float* value,
+                           const float* mat, const float* grad,
+                           const int64_t* arg_out, int64_t M, int64_t N,
+                           int64_t K, int64_t nnz, float* grad_value,
+                           float* grad_mat, void* workspace,
+                           size_t workspace_bytes, psa_stream_t stream);
+
 /* Test/bench hook: choose the SpMM kernel variant for subsequent psa_spmm
  * calls of this process (0 = auto).  Returns the previous value.  Variants
  * compute identical results up to fp32 summation order; listed in DESIGN.md. */

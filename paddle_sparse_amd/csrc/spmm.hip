@@ -84,14 +84,38 @@ using psa::max_long_chunks;
 using psa::max_long_rows;
 using psa::push_long_row;
 
+// MASK form of the reduction (grad of the dense operand of spmm_min/max, taken
+// over the CSC view without atomics): edge j of "row" c is the CSR edge
+// edge_id[j] = (r, c); its term w * grad[r, k] counts for output column k only
+// where the forward's arg_out[r, k] named that edge.  bytes[r, k] holds
+// arg_out[r, k] as an index local to row r (one byte instead of eight), tag[j]
+// the local index of edge j in its row; 255 in either means "row r has more
+// than 255 edges, compare arg_out itself".  `val` is then the CSR-ordered value
+// array (read through edge_id), `col` the CSR row of every CSC edge.
+// With grad_value set, the same pass also forms grad_value[e] = sum over the
+// hit columns k of mat[c, k] * grad[r, k]: the gathered grad row is already in
+// registers, mat[c, :] is this wave's own row (mrow), and every CSR edge shows
+// up exactly once in the CSC walk, so each grad_value element is stored once.
+struct MaskArgs {
+  const uint8_t* bytes = nullptr;    // [M, K] at the lane's k0
+  const uint8_t* tag = nullptr;      // [nnz], CSC order
+  const int64_t* edge_id = nullptr;  // csr2csc
+  const int64_t* arg = nullptr;      // arg_out [M, K] at the lane's k0
+  const float* mat = nullptr;        // dense operand of the forward [N, K] (grad_value only)
+  const float* mrow = nullptr;       // set by the kernel: mat[c, k0..] of the wave's column
+  float* grad_value = nullptr;       // [nnz], CSR order, or NULL
+};
+
 // Reduce edges [s, e) of one row into acc/arg: LPR lanes x VEC floats cover the
 // K tile at k0, the G = 64/LPR lane groups take different edges of a step, U
 // steps are issued before any is consumed; the groups are folded at the end.
-template <int VEC, int LPR, int RED, int U>
+template <int VEC, int LPR, int RED, int U, bool MASK = false>
 __device__ __forceinline__ void reduce_edge_range(
     const int64_t* __restrict__ col, const float* __restrict__ val,
     const float* __restrict__ matk, int64_t K, bool kact, int64_t s, int64_t e,
-    int64_t nnz, int lane, float (&acc)[VEC], int64_t (&arg)[VEC]) {
+    int64_t nnz, int lane, float (&acc)[VEC], int64_t (&arg)[VEC],
+    const MaskArgs& m = MaskArgs{}) {
+  static_assert(!MASK || (RED == R_SUM && VEC == 4), "masked form: sum over float4 tiles");
   constexpr int G = 64 / LPR;
   static_assert(64 % (G * U) == 0, "edge batch must divide the wave");
   const int g = lane / LPR;
@@ -100,18 +124,31 @@ __device__ __forceinline__ void reduce_edge_range(
     acc[i] = RED == R_SUM ? 0.f : (RED == R_MAX ? -__FLT_MAX__ : __FLT_MAX__);
     arg[i] = nnz;
   }
+  float mr[VEC];  // MASK + grad_value: this lane's slice of mat[c, :]
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) mr[i] = 0.f;
+  const bool want_gv = MASK && m.grad_value != nullptr;  // wave-uniform
+  if (want_gv && kact) load_vec<VEC>(m.mrow, mr);
   for (int64_t base = s; base < e; base += 64) {
     const int n = (e - base) < 64 ? static_cast<int>(e - base) : 64;
     int64_t c_l = 0;
     float v_l = 0.f;
+    int64_t id_l = 0;  // MASK: CSR edge id; its tag rides in the top byte
     if (lane < n) {
       c_l = col[base + lane];
-      v_l = val ? val[base + lane] : 1.f;
+      if (MASK) {
+        id_l = m.edge_id[base + lane];
+        v_l = val ? val[id_l] : 1.f;
+        id_l |= static_cast<int64_t>(m.tag[base + lane]) << 56;
+      } else {
+        v_l = val ? val[base + lane] : 1.f;
+      }
     }
     for (int j = 0; j < n; j += G * U) {
       float b[U][VEC];
       float w[U];
       bool ok[U];
+      uint32_t mb[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int idx = j + u * G + g;  // < 64 by the static_assert
@@ -121,6 +158,58 @@ __device__ __forceinline__ void reduce_edge_range(
 #pragma unroll
         for (int i = 0; i < VEC; ++i) b[u][i] = 0.f;
         if (ok[u]) load_vec<VEC>(matk + c * K, b[u]);
+        if (MASK) {
+          mb[u] = 0;
+          if (ok[u]) mb[u] = *reinterpret_cast<const uint32_t*>(m.bytes + c * K);
+        }
+      }
+      if (MASK) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          // edge id / row are re-read from their lanes here rather than kept in
+          // registers across the gathers (88 -> fewer VGPRs, one more wave per SIMD)
+          const int idx = j + u * G + g;
+          const int64_t id = shfl_i64(id_l, idx);
+          const int64_t r = shfl_i64(c_l, idx);
+          const uint32_t tag = static_cast<uint32_t>(static_cast<uint64_t>(id) >> 56);
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) {
+            const uint32_t byte = (mb[u] >> (8 * i)) & 255u;
+            bool hit = byte == tag;
+            if (hit && tag == 255u && ok[u])  // a row of more than 255 edges: exact test
+              hit = m.arg[r * K + i] == (id & 0x00ffffffffffffffll);
+            if (!hit) b[u][i] = 0.f;
+          }
+        }
+        if (want_gv) {
+          static_assert(!MASK || ((U & (U - 1)) == 0 && U <= LPR), "U must be a power of two <= LPR");
+          const int l = lane % LPR;
+          float dot[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            dot[u] = 0.f;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) dot[u] += b[u][i] * mr[i];
+          }
+          // fold the U partial dots of the lane group (as value_bw_range does):
+          // lane l ends up with the whole dot of edge slot u = l % U
+          int cnt = U;
+#pragma unroll
+          for (int bit = 1; bit < U; bit <<= 1, cnt >>= 1) {
+            const bool up = (l & bit) != 0;
+#pragma unroll
+            for (int i = 0; i < cnt / 2; ++i) {
+              const float keep = up ? dot[2 * i + 1] : dot[2 * i];
+              const float send = up ? dot[2 * i] : dot[2 * i + 1];
+              dot[i] = keep + __shfl_xor(send, bit);
+            }
+          }
+#pragma unroll
+          for (int bit = U; bit < LPR; bit <<= 1) dot[0] += __shfl_xor(dot[0], bit);
+          const int slot = j + (l % U) * G + g;  // < 64
+          const int64_t my_id = shfl_i64(id_l, slot) & 0x00ffffffffffffffll;
+          if (l < U && slot < n) m.grad_value[my_id] = dot[0];
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -412,7 +501,7 @@ find_long_rows_kernel(const int64_t* __restrict__ rowptr, int64_t M,
   if (deg > kLongRow) push_long_row(ctr, list, r, deg);
 }
 
-template <int VEC, int LPR, int RED, int U>
+template <int VEC, int LPR, int RED, int U, bool MASK = false>
 __global__ void __launch_bounds__(kThreads)
 spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col,
                   const float* __restrict__ val, const float* __restrict__ mat,
@@ -420,7 +509,7 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
                   int64_t K, int64_t nnz, int mean,
                   const unsigned long long* __restrict__ long_ctr,
                   const LongEntry* __restrict__ long_list, float* __restrict__ part_val,
-                  int64_t* __restrict__ part_arg) {
+                  int64_t* __restrict__ part_arg, MaskArgs mask) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane / LPR;
@@ -429,6 +518,10 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
   const bool kact = k0 < K;
   float acc[VEC];
   int64_t arg[VEC];
+  if (MASK) {
+    mask.bytes += k0;
+    mask.arg += k0;
+  }
   if (blockIdx.x < kFusedChunkBlocks) {  // ---- chunk role ----
     const unsigned long long ctr = *long_ctr;
     const uint32_t total = static_cast<uint32_t>(ctr & 0xffffffffull);
@@ -438,7 +531,8 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
       const int64_t rs = rowptr[ent.row], re = rowptr[ent.row + 1];
       const int64_t s = rs + static_cast<int64_t>(c - ent.first_chunk) * kLongChunk;
       const int64_t e = s + kLongChunk < re ? s + kLongChunk : re;
-      reduce_edge_range<VEC, LPR, RED, U>(col, val, mat + k0, K, kact, s, e, nnz, lane, acc, arg);
+      if (MASK && mask.mat) mask.mrow = mask.mat + ent.row * K + k0;
+      reduce_edge_range<VEC, LPR, RED, U, MASK>(col, val, mat + k0, K, kact, s, e, nnz, lane, acc, arg, mask);
       if (g == 0 && kact) {
         store_vec<VEC>(part_val + static_cast<int64_t>(c) * K + k0, acc);
         if (RED != R_SUM) {
@@ -455,7 +549,8 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
   const int64_t s = rowptr[row];
   const int64_t e = rowptr[row + 1];
   if (e - s > kLongRow) return;  // on the list: chunk role + combine write it
-  reduce_edge_range<VEC, LPR, RED, U>(col, val, mat + k0, K, kact, s, e, nnz, lane, acc, arg);
+  if (MASK && mask.mat) mask.mrow = mask.mat + row * K + k0;
+  reduce_edge_range<VEC, LPR, RED, U, MASK>(col, val, mat + k0, K, kact, s, e, nnz, lane, acc, arg, mask);
   if (g == 0 && kact) {
     const int64_t deg = e - s;
     if (RED == R_SUM) {
@@ -679,7 +774,7 @@ int launch_fused(int red, const int64_t* rowptr, const int64_t* col, const float
   do {                                                                                        \
     hipLaunchKernelGGL((spmm_fused_kernel<VEC, LPR, R, U>), grid, block, 0, s, rowptr, col,   \
                        val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list, w.part_val,    \
-                       w.part_arg);                                                           \
+                       w.part_arg, MaskArgs{});                                               \
     hipLaunchKernelGGL((spmm_long_combine_kernel<R>), cgrid, cblock, 0, s, rowptr, K, mean,   \
                        w.ctr, w.list, w.part_val, w.part_arg, out, arg_out);                  \
   } while (0)
@@ -689,6 +784,62 @@ int launch_fused(int red, const int64_t* rowptr, const int64_t* col, const float
 #undef PSA_FUSED
   PSA_LAUNCH_CHECK();
   return PSA_OK;
+}
+
+// The same three launches in the MASK form (sum over the CSC view; see MaskArgs).
+template <int LPR, int U>
+int launch_fused_masked(const int64_t* colptr, const int64_t* row_csc, const float* value,
+                        const float* grad, float* out, int64_t N, int64_t K, int64_t nnz,
+                        const MaskArgs& mask, const LongScratch& w, hipStream_t s) {
+  const int64_t gx = psa::ceil_div(N, kWaves) + kFusedChunkBlocks;
+  PSA_REQUIRE(gx <= 0x7fffffff, "N too large for one launch");
+  const dim3 block(kThreads), grid(static_cast<unsigned>(gx));
+  hipLaunchKernelGGL(find_long_rows_kernel, dim3(static_cast<unsigned>(psa::ceil_div(N, kThreads))),
+                     block, 0, s, colptr, N, w.ctr, w.list);
+  hipLaunchKernelGGL((spmm_fused_kernel<4, LPR, R_SUM, U, true>), grid, block, 0, s, colptr, row_csc,
+                     value, grad, out, static_cast<int64_t*>(nullptr), N, K, nnz, 0, w.ctr, w.list,
+                     w.part_val, w.part_arg, mask);
+  hipLaunchKernelGGL((spmm_long_combine_kernel<R_SUM>), dim3(kLongBlocks), dim3(psa::kLongThreads), 0, s,
+                     colptr, K, 0, w.ctr, w.list, w.part_val, w.part_arg, out,
+                     static_cast<int64_t*>(nullptr));
+  PSA_LAUNCH_CHECK();
+  return PSA_OK;
+}
+
+// bytes[r, k] = arg_out[r, k] as an index local to row r; 255 for rows of more
+// than 255 edges (and for empty rows, which no edge ever asks about).  Four
+// elements per thread: 32 B in, 4 B out.
+__global__ void __launch_bounds__(kThreads)
+minmax_compress_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ arg_out,
+                       int64_t M, int64_t K, uint8_t* __restrict__ bytes) {
+  const int64_t q = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;  // group of 4
+  const int64_t kq = K / 4;
+  if (q >= M * kq) return;
+  const int64_t r = q / kq;
+  const int64_t start = rowptr[r];
+  const bool big = rowptr[r + 1] - start > 255;
+  const longlong2 a01 = *reinterpret_cast<const longlong2*>(arg_out + 4 * q);
+  const longlong2 a23 = *reinterpret_cast<const longlong2*>(arg_out + 4 * q + 2);
+  const int64_t a[4] = {a01.x, a01.y, a23.x, a23.y};
+  uint32_t packed = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint32_t b = big ? 255u : static_cast<uint32_t>((a[i] - start) & 255);
+    packed |= b << (8 * i);
+  }
+  *reinterpret_cast<uint32_t*>(bytes + 4 * q) = packed;
+}
+
+// tag[j] = index of CSC edge j inside its CSR row (255: row of more than 255 edges).
+__global__ void __launch_bounds__(kThreads)
+csc_edge_tags_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ row_csc,
+                     const int64_t* __restrict__ csr2csc, int64_t nnz,
+                     uint8_t* __restrict__ tag) {
+  const int64_t j = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (j >= nnz) return;
+  const int64_t r = row_csc[j];
+  const int64_t start = rowptr[r];
+  tag[j] = rowptr[r + 1] - start > 255 ? 255 : static_cast<uint8_t>(csr2csc[j] - start);
 }
 
 template <int VEC, int LPR, int U>
@@ -776,6 +927,74 @@ int psa_spmm_set_variant(int variant) {
   const int prev = g_variant;
   g_variant = variant;
   return prev;
+}
+
+int psa_csc_edge_tags(const int64_t* rowptr, const int64_t* row_csc, const int64_t* csr2csc,
+                      int64_t nnz, uint8_t* tag, psa_stream_t stream) {
+  PSA_REQUIRE(nnz >= 0, "negative size");
+  if (nnz == 0) return PSA_OK;
+  PSA_REQUIRE(rowptr && row_csc && csr2csc && tag, "NULL pointer");
+  const int64_t blocks = psa::ceil_div(nnz, kThreads);
+  PSA_REQUIRE(blocks <= 0x7fffffff, "nnz too large for one launch");
+  hipLaunchKernelGGL(csc_edge_tags_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0,
+                     psa::as_stream(stream), rowptr, row_csc, csr2csc, nnz, tag);
+  PSA_LAUNCH_CHECK();
+  return PSA_OK;
+}
+
+size_t psa_spmm_minmax_bw_csc_workspace_bytes(int64_t M, int64_t K, int64_t nnz) {
+  if (M <= 0 || K <= 0) return 256;
+  return align256(static_cast<size_t>(M) * K) + long_workspace_bytes(false, K, nnz > 0 ? nnz : 1);
+}
+
+int psa_spmm_minmax_bw_csc(const int64_t* rowptr, const int64_t* colptr,
+                           const int64_t* row_csc, const int64_t* csr2csc,
+                           const uint8_t* tag, const float* value, const float* mat,
+                           const float* grad, const int64_t* arg_out, int64_t M, int64_t N,
+                           int64_t K, int64_t nnz, float* grad_value, float* grad_mat,
+                           void* workspace, size_t workspace_bytes, psa_stream_t stream) {
+  PSA_REQUIRE(M >= 0 && N >= 0 && K >= 0 && nnz >= 0, "negative size");
+  if (N == 0 || K == 0) return PSA_OK;
+  if (K % 4 != 0 || K > 256 || !psa::aligned(grad, 16) || !psa::aligned(grad_mat, 16) ||
+      !psa::aligned(arg_out, 16) || !psa::aligned(mat, 16)) {
+    psa::set_error("psa_spmm_minmax_bw_csc: needs K % 4 == 0, K <= 256 and 16-byte aligned "
+                   "operands (use psa_spmm_minmax_bw)");
+    return PSA_ERR_UNSUPPORTED;
+  }
+  PSA_REQUIRE(colptr && grad_mat, "NULL pointer");
+  PSA_REQUIRE(nnz == 0 || (rowptr && row_csc && csr2csc && tag && grad && arg_out), "NULL pointer");
+  PSA_REQUIRE(grad_value == nullptr || mat != nullptr || nnz == 0, "grad_value needs mat");
+  PSA_REQUIRE(max_long_chunks(nnz) < (1ll << 32), "too many chunks");
+  if (workspace == nullptr || workspace_bytes < psa_spmm_minmax_bw_csc_workspace_bytes(M, K, nnz)) {
+    psa::set_error("psa_spmm_minmax_bw_csc: workspace too small");
+    return PSA_ERR_WORKSPACE;
+  }
+  PSA_REQUIRE(psa::aligned(workspace, 16), "workspace must be 16-byte aligned");
+  hipStream_t s = psa::as_stream(stream);
+  uint8_t* bytes = static_cast<uint8_t*>(workspace);
+  const LongScratch w = carve(bytes + align256(static_cast<size_t>(M) * K), false, K, nnz > 0 ? nnz : 1);
+  PSA_ZERO(w.ctr, 8, s);
+  if (M > 0 && nnz > 0) {
+    const int64_t blocks = psa::ceil_div(M * (K / 4), kThreads);
+    PSA_REQUIRE(blocks <= 0x7fffffff, "M*K too large for one launch");
+    hipLaunchKernelGGL(minmax_compress_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0,
+                       s, rowptr, arg_out, M, K, bytes);
+  }
+  MaskArgs mask;
+  mask.bytes = bytes;
+  mask.tag = tag;
+  mask.edge_id = csr2csc;
+  mask.arg = arg_out;
+  if (grad_value != nullptr && nnz > 0) {
+    mask.mat = mat;
+    mask.grad_value = grad_value;
+  }
+  const int64_t q = K / 4;
+  if (q <= 4) return launch_fused_masked<4, 1>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
+  if (q <= 8) return launch_fused_masked<8, 2>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
+  if (q <= 16) return launch_fused_masked<16, 4>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
+  if (q <= 32) return launch_fused_masked<32, 4>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
+  return launch_fused_masked<64, 8>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
 }
 
 size_t psa_spmm_workspace_bytes(int reduce, int64_t K, int64_t nnz) {

@@ -39,8 +39,18 @@ class _SpMM(torch.autograd.Function):
         grad_out = grad_out.contiguous()
         grad_value = grad_mat = None
         if reduce in ("min", "max"):
-            grad_value, grad_mat = ops.spmm_minmax_bw(st.col(), value, mat, grad_out, arg,
-                                                     want_value=need_value, want_mat=need_mat)
+            # With grad_mat wanted and a K tile the kernel takes, both gradients
+            # come from ONE gather pass over the CSC view (no atomics): 256 M
+            # scattered float atomics cost more than the one-off CSC build, which
+            # the storage keeps for the next step.
+            if need_mat and ops.minmax_bw_csc_supported(grad_out.shape[1]):
+                csr2csc = st.csr2csc()  # first: it leaves colptr and row[csr2csc] behind
+                grad_value, grad_mat = ops.spmm_minmax_bw_csc(
+                    st.rowptr(), st.colptr(), st._row_in_csc_order(), csr2csc, st._csc_edge_tags(),
+                    value, mat, grad_out, arg, want_value=need_value)
+            else:
+                grad_value, grad_mat = ops.spmm_minmax_bw(st.col(), value, mat, grad_out, arg,
+                                                         want_value=need_value, want_mat=need_mat)
         else:
             mean = reduce == "mean"
             if need_value:

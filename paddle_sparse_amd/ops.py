@@ -383,6 +383,57 @@ def spmm_minmax_bw(col, value, mat, grad, arg_out, want_value: bool = True, want
     return gv, gm
 
 
+def csc_edge_tags(rowptr, row_csc, csr2csc) -> torch.Tensor:
+    """uint8[nnz]: position of every CSC-ordered edge inside its CSR row (255 for
+    rows of more than 255 edges).  Structure only — cache it next to csr2csc."""
+    rowptr, row_csc, csr2csc = _index(rowptr, "rowptr"), _index(row_csc, "row_csc"), _index(csr2csc, "csr2csc")
+    tag = torch.empty(csr2csc.numel(), dtype=torch.uint8, device=csr2csc.device)
+    with torch.cuda.device(csr2csc.device):
+        check(_lib.load().psa_csc_edge_tags(_ptr(rowptr), _ptr(row_csc), _ptr(csr2csc),
+                                            csr2csc.numel(), _ptr(tag), _stream()))
+    return tag
+
+
+def minmax_bw_csc_supported(K: int) -> bool:
+    return K % 4 == 0 and 0 < K <= 256
+
+
+def spmm_minmax_bw_csc(rowptr, colptr, row_csc, csr2csc, tag, value, mat, grad, arg_out,
+                       want_value: bool = True):
+    """Backward of spmm_min / spmm_max in one pass over the CSC view, no atomics
+    (see include/paddle_sparse_hip.h).  Returns (grad_value f32[nnz] | None,
+    grad_mat f32[N, K])."""
+    rowptr, colptr = _index(rowptr, "rowptr"), _index(colptr, "colptr")
+    row_csc, csr2csc = _index(row_csc, "row_csc"), _index(csr2csc, "csr2csc")
+    grad = _f32(grad, "grad")
+    _gpu(arg_out, "arg_out")
+    arg_out = arg_out.contiguous()
+    if value is not None:
+        value = _f32(value, "value")
+    _gpu(tag, "tag")
+    if tag.dtype != torch.uint8 or tag.numel() != csr2csc.numel():
+        raise ValueError("tag must be uint8[nnz] (ops.csc_edge_tags)")
+    (M, K), N, nnz = grad.shape, colptr.numel() - 1, csr2csc.numel()
+    if arg_out.shape != grad.shape or arg_out.dtype != torch.int64:
+        raise ValueError("arg_out must be int64[M, K] like grad")
+    gv = None
+    if want_value:
+        mat = _f32(mat, "mat")
+        if mat.shape != (N, K):
+            raise ValueError("mat must be [N, K]")
+        gv = torch.empty(nnz, dtype=torch.float32, device=grad.device)
+    gm = torch.empty((N, K), dtype=torch.float32, device=grad.device)
+    lib = _lib.load()
+    ws = _workspace(lib.psa_spmm_minmax_bw_csc_workspace_bytes(M, K, nnz), grad.device)
+    with torch.cuda.device(grad.device):
+        check(lib.psa_spmm_minmax_bw_csc(_ptr(rowptr), _ptr(colptr), _ptr(row_csc), _ptr(csr2csc),
+                                         _ptr(tag.contiguous()), _ptr(value),
+                                         _ptr(mat) if want_value else None, _ptr(grad), _ptr(arg_out),
+                                         M, N, K, nnz, _ptr(gv), _ptr(gm), _ptr(ws), ws.numel(),
+                                         _stream()))
+    return gv, gm
+
+
 def bincount(index: torch.Tensor, size: int) -> torch.Tensor:
     """int64[size] occurrence counts (colcount, storage.py:414-418)."""
     index = _index(index, "index")

@@ -115,6 +115,7 @@ class SparseStorage(object):
         self._rowcount, self._colptr, self._colcount = rowcount, colptr, colcount
         self._csr2csc, self._csc2csr = csr2csc, csc2csr
         self._row_csc: Optional[torch.Tensor] = None  # row[csr2csc], private
+        self._edge_tags: Optional[torch.Tensor] = None  # uint8 per CSC edge, private (min/max backward)
 
         # storage.py:158-171 — sort by (row, col) unless told it is sorted
         if not is_sorted and nnz > 0:
@@ -294,6 +295,13 @@ class SparseStorage(object):
             self._row_csc = ops.gather_rows(self.row(), self.csr2csc())
         return self._row_csc
 
+    def _csc_edge_tags(self) -> torch.Tensor:
+        """Position of every CSC-ordered edge inside its CSR row, one byte each
+        (ops.csc_edge_tags): structure only, memoised for the min/max backward."""
+        if self._edge_tags is None:
+            self._edge_tags = ops.csc_edge_tags(self.rowptr(), self._row_in_csc_order(), self.csr2csc())
+        return self._edge_tags
+
     # ---- coalesce -------------------------------------------------------------
     def is_coalesced(self) -> bool:
         """storage.py:449-452: keys strictly increasing."""
@@ -334,6 +342,7 @@ class SparseStorage(object):
         for k in _CACHES:
             setattr(self, "_" + k, None)
         self._row_csc = None
+        self._edge_tags = None
         return self
 
     def cached_keys(self) -> List[str]:
@@ -348,7 +357,10 @@ class SparseStorage(object):
         args = {k: getattr(self, "_" + k) for k in _FIELDS}
         args["sparse_sizes"] = self._sparse_sizes
         args.update(kw)
-        return SparseStorage(is_sorted=True, trust_data=True, **args)
+        out = SparseStorage(is_sorted=True, trust_data=True, **args)
+        if not (set(kw) - {"value"}):  # same sparsity structure: the private CSC helpers carry over
+            out._row_csc, out._edge_tags = self._row_csc, self._edge_tags
+        return out
 
     def _map(self, fn: Callable[[torch.Tensor], torch.Tensor]):
         return self._replace(**{k: (None if getattr(self, "_" + k) is None else fn(getattr(self, "_" + k)))

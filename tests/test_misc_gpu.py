@@ -123,6 +123,68 @@ def test_transposed_spmm_is_grad_mat(mean, has_value):
 
 
 @pytest.mark.parametrize("reduce", ["min", "max"])
+@pytest.mark.parametrize("has_value", [True, False])
+@pytest.mark.parametrize("K", [4, 16, 32, 64, 100, 128, 256])
+@pytest.mark.parametrize("graph", ["uniform", "hubs"])
+def test_minmax_bw_over_csc(reduce, has_value, K, graph):
+    """The atomic-free min/max backward (one CSC gather pass over byte-compressed
+    arg_out, both gradients) against the oracle: short rows take the byte test,
+    rows of > 255 edges the exact one, columns of > 128 edges the chunked path."""
+    from paddle_sparse_amd import SparseStorage, ops
+
+    if graph == "hubs":  # rows 0 / 7 have 700 edges; few columns, so columns are long too
+        row, rowptr, col, val = skewed_csr(600, 40, seed=3 + K, long_rows=(0, 7, 599), long_deg=700)
+        M, N = 600, 40
+    else:
+        row, rowptr, col, val = random_csr(3000, 2500, 30_000, 4 + K)
+        M, N = 3000, 2500
+    if not has_value:
+        val = None
+    rng = np.random.default_rng(2)
+    B = rng.standard_normal((N, K)).astype(np.float32)
+    G = rng.standard_normal((M, K)).astype(np.float32)
+    _, arg = oracle.spmm(reduce, rowptr, col, val, B)
+    ref_v, ref_m = oracle.spmm_minmax_bw(col, val, B, G, arg)
+    st = SparseStorage(rowptr=dev(rowptr), col=dev(col), value=dev(val), sparse_sizes=(M, N), is_sorted=True)
+    csr2csc = st.csr2csc()
+
+    def run(want_value=True):
+        return ops.spmm_minmax_bw_csc(st.rowptr(), st.colptr(), st._row_in_csc_order(), csr2csc,
+                                      st._csc_edge_tags(), st.value(), dev(B), dev(G), dev(arg),
+                                      want_value=want_value)
+
+    gv, gm = run()
+    live = arg < col.size
+    rr, kk = np.nonzero(live)
+    ee = arg[rr, kk]
+    scale_m = np.zeros((N, K), np.float32)  # sum of |terms| per output element
+    w = np.ones(col.size, np.float32) if val is None else np.abs(val)
+    np.add.at(scale_m, (col[ee], kk), w[ee] * np.abs(G[rr, kk]))
+    assert np.all(np.abs(gm.cpu().numpy() - ref_m) <= 1e-5 * scale_m + 1e-30)
+    scale_v = np.zeros(col.size, np.float32)
+    np.add.at(scale_v, ee, np.abs(B[col[ee], kk] * G[rr, kk]))
+    assert np.all(np.abs(gv.cpu().numpy() - ref_v) <= 1e-5 * scale_v + 1e-30)
+    assert ops.minmax_bw_csc_supported(K)
+    # two launches give the same bits (no atomics anywhere on this path)
+    gv2, gm2 = run()
+    assert torch.equal(gm, gm2) and torch.equal(gv, gv2)
+    none, gm3 = run(want_value=False)
+    assert none is None and torch.equal(gm, gm3)
+
+
+def test_minmax_bw_over_csc_rejects_unaligned_k():
+    from paddle_sparse_amd import ops
+    from paddle_sparse_amd._lib import HipCoreError
+
+    assert not ops.minmax_bw_csc_supported(130) and not ops.minmax_bw_csc_supported(512)
+    z = torch.zeros(3, dtype=torch.int64, device="cuda")
+    with pytest.raises(HipCoreError, match="K % 4"):
+        ops.spmm_minmax_bw_csc(z, z, z[:0], z[:0], torch.zeros(0, dtype=torch.uint8, device="cuda"), None,
+                               torch.zeros(2, 6, device="cuda"), torch.zeros(2, 6, device="cuda"),
+                               torch.zeros(2, 6, dtype=torch.int64, device="cuda"))
+
+
+@pytest.mark.parametrize("reduce", ["min", "max"])
 @pytest.mark.parametrize("K", [5, 48, 100, 128, 130, 256, 300])
 def test_spmm_minmax_bw(reduce, K):
     from paddle_sparse_amd import ops
