@@ -193,8 +193,8 @@ int psa_make_keys(const int64_t* a, const int64_t* b, int64_t mul, int64_t n,
 int psa_split_keys(const int64_t* keys, int64_t n, int64_t div, int64_t* hi,
                    int64_t* lo, psa_stream_t stream) {
   PSA_REQUIRE(n >= 0, "negative size");
-  PSA_REQUIRE(div > 0, "div must be positive");
   if (n == 0 || (hi == nullptr && lo == nullptr)) return PSA_OK;
+  PSA_REQUIRE(div > 0, "div must be positive");
   PSA_REQUIRE(keys != nullptr, "keys is NULL");
   const int64_t blocks = psa::ceil_div(n, kThreads);
   PSA_REQUIRE(blocks <= 0x7fffffff, "n too large for one launch");

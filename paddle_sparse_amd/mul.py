@@ -7,67 +7,40 @@ coalesced a key occurs at most twice, and the stable sort puts A's entry first.
 """
 from __future__ import annotations
 
-from typing import Optional
-
 import torch
 
+from . import elementwise as ew
 from . import ops
-from .add import _broadcast_operand
 from .tensor import SparseTensor
+
+_mul_dense = ew.dense_variant("mul", inplace=False)
+mul_ = ew.dense_variant("mul", inplace=True)
+mul_nnz = ew.nnz_variant("mul", inplace=False)
+mul_nnz_ = ew.nnz_variant("mul", inplace=True)
+
+
+def _mul_sparse(a: SparseTensor, b: SparseTensor) -> SparseTensor:
+    for name, t in (("src", a), ("other", b)):
+        if not t.is_coalesced():
+            raise ValueError(f"The `{name}` tensor is not coalesced")
+    (ra, ca, va), (rb, cb, vb) = a.coo(), b.coo()
+    if va is None or vb is None:
+        raise ValueError("Both sparse tensors must contain values")
+    M, N = max(a.size(0), b.size(0)), max(a.size(1), b.size(1))
+    keys, _ = ops.make_keys(torch.cat([ra, rb]), torch.cat([ca, cb]), N)
+    keys, perm = ops.index_sort(keys, M * N, with_sorted_inputs=True)
+    value = ops.gather_rows(torch.cat([va, vb], dim=0), perm)
+    first = (keys[1:] == keys[:-1]).nonzero().view(-1)  # A's entry of every key both operands hold
+    row, col = ops.split_keys(keys[first], N)
+    return SparseTensor(row=row, col=col, value=value[first] * value[first + 1], sparse_sizes=(M, N),
+                        is_sorted=True, trust_data=True)
 
 
 def mul(src: SparseTensor, other):
     if isinstance(other, torch.Tensor):
-        picked = _broadcast_operand(src, other)
-        value = src.storage.value()
-        value = picked.to(value.dtype) * value if value is not None else picked
-        return src.set_value(value, layout="coo")
-
+        return _mul_dense(src, other)
     assert isinstance(other, SparseTensor)
-    if not src.is_coalesced():
-        raise ValueError("The `src` tensor is not coalesced")
-    if not other.is_coalesced():
-        raise ValueError("The `other` tensor is not coalesced")
-    row_a, col_a, value_a = src.coo()
-    row_b, col_b, value_b = other.coo()
-    if value_a is None or value_b is None:
-        raise ValueError("Both sparse tensors must contain values")
-    M = max(src.size(0), other.size(0))
-    N = max(src.size(1), other.size(1))
-    value = torch.cat([value_a, value_b], dim=0)
-    keys, _ = ops.make_keys(torch.cat([row_a, row_b]), torch.cat([col_a, col_b]), N)
-    keys, perm = ops.index_sort(keys, M * N, with_sorted_inputs=True)
-    value = ops.gather_rows(value, perm)
-    hit = (keys[1:] == keys[:-1]).nonzero().view(-1)  # position of A's entry of each common key
-    common = keys[hit]
-    row = torch.div(common, N, rounding_mode="floor")
-    return SparseTensor(row=row, col=common - row * N, value=value[hit] * value[hit + 1],
-                        sparse_sizes=(M, N), is_sorted=True, trust_data=True)
+    return _mul_sparse(src, other)
 
 
-def mul_(src: SparseTensor, other: torch.Tensor) -> SparseTensor:
-    picked = _broadcast_operand(src, other)
-    value = src.storage.value()
-    value = value.mul_(picked.to(value.dtype)) if value is not None else picked
-    return src.set_value_(value, layout="coo")
-
-
-def mul_nnz(src: SparseTensor, other: torch.Tensor, layout: Optional[str] = None) -> SparseTensor:
-    value = src.storage.value()
-    value = value * other.to(value.dtype) if value is not None else other
-    return src.set_value(value, layout=layout)
-
-
-def mul_nnz_(src: SparseTensor, other: torch.Tensor, layout: Optional[str] = None) -> SparseTensor:
-    value = src.storage.value()
-    value = value.mul_(other.to(value.dtype)) if value is not None else other
-    return src.set_value_(value, layout=layout)
-
-
-SparseTensor.mul = lambda self, other: mul(self, other)
-SparseTensor.mul_ = lambda self, other: mul_(self, other)
-SparseTensor.mul_nnz = lambda self, other, layout=None: mul_nnz(self, other, layout)
-SparseTensor.mul_nnz_ = lambda self, other, layout=None: mul_nnz_(self, other, layout)
-SparseTensor.__mul__ = SparseTensor.mul
-SparseTensor.__rmul__ = SparseTensor.mul
-SparseTensor.__imul__ = SparseTensor.mul_
+ew.install("mul", mul, mul_, mul_nnz, mul_nnz_)

@@ -61,23 +61,13 @@ def reduction(src: SparseTensor, dim: Optional[int] = None, reduce: str = "sum")
     raise ValueError
 
 
-def sum(src: SparseTensor, dim: Optional[int] = None) -> torch.Tensor:
-    return reduction(src, dim, reduce="sum")
+def _named(reduce: str):
+    """The public one-reduction form and its SparseTensor method (reduce.py:74-93)."""
+    def fn(src: SparseTensor, dim: Optional[int] = None) -> torch.Tensor:
+        return reduction(src, dim, reduce=reduce)
+    fn.__name__ = fn.__qualname__ = reduce
+    setattr(SparseTensor, reduce, lambda self, dim=None: fn(self, dim))
+    return fn
 
 
-def mean(src: SparseTensor, dim: Optional[int] = None) -> torch.Tensor:
-    return reduction(src, dim, reduce="mean")
-
-
-def min(src: SparseTensor, dim: Optional[int] = None) -> torch.Tensor:
-    return reduction(src, dim, reduce="min")
-
-
-def max(src: SparseTensor, dim: Optional[int] = None) -> torch.Tensor:
-    return reduction(src, dim, reduce="max")
-
-
-SparseTensor.sum = lambda self, dim=None: sum(self, dim)
-SparseTensor.mean = lambda self, dim=None: mean(self, dim)
-SparseTensor.min = lambda self, dim=None: min(self, dim)
-SparseTensor.max = lambda self, dim=None: max(self, dim)
+sum, mean, min, max = (_named(r) for r in ("sum", "mean", "min", "max"))  # noqa: A001

@@ -134,6 +134,40 @@ def narrow(src: SparseTensor, dim: int, start: int, length: int) -> SparseTensor
     return src.set_value(value.narrow(dim - 1, start, length), layout="coo")
 
 
+def __narrow_diag__(src: SparseTensor, start, length) -> SparseTensor:
+    """narrow.py:103-168 — one block of a block-diagonal matrix, i.e. the
+    inverse of cat(..., dim=(0, 1)); only meaningful on such matrices (the
+    block's entries are then one contiguous run of every array, in CSR and in
+    CSC order alike, so each cache is a shifted slice)."""
+    (r0, c0), (nr, nc) = start, length
+    st = src.storage
+    rowptr = st.rowptr()[r0:r0 + nr + 1]
+    e0 = int(rowptr[0])
+    rowptr = rowptr - e0
+    e1 = e0 + int(rowptr[-1])
+
+    def run(x, shift):  # the block's run of an nnz-sized array, renumbered
+        return None if x is None else x[e0:e1] - shift
+
+    colptr = st._colptr
+    if colptr is not None:
+        colptr = colptr[c0:c0 + nc + 1]
+        colptr = colptr - colptr[0]
+    storage = SparseStorage(
+        row=run(st._row, r0), rowptr=rowptr, col=run(st._col, c0),
+        value=None if st._value is None else st._value[e0:e1],
+        sparse_sizes=(nr, nc),
+        rowcount=None if st._rowcount is None else st._rowcount[r0:r0 + nr],
+        colptr=colptr,
+        colcount=None if st._colcount is None else st._colcount[c0:c0 + nc],
+        csr2csc=run(st._csr2csc, e0), csc2csr=run(st._csc2csr, e0),
+        is_sorted=True, trust_data=True)
+    return src.from_storage(storage)
+
+
+SparseTensor.__narrow_diag__ = lambda self, start, length: __narrow_diag__(self, start, length)
+
+
 def select(src: SparseTensor, dim: int, idx: int) -> SparseTensor:
     return narrow(src, dim, start=idx, length=1)
 

@@ -143,6 +143,33 @@ def test_cat_kat(kats):
         cat([mat1, mat1], dim=3)
 
 
+def test_narrow_diag_undoes_cat_diag_and_eye():
+    """__narrow_diag__ (narrow.py:103-168) is the inverse of cat(dim=(0, 1)),
+    caches included; eye() is the functional identity (eye.py:6-24)."""
+    from paddle_sparse_amd import SparseTensor, __narrow_diag__, cat, eye
+
+    rng = np.random.default_rng(21)
+    mats = []
+    for M, N, nnz in ((30, 20, 150), (10, 45, 200), (25, 25, 90)):
+        key = np.unique(rng.integers(0, M * N, nnz))
+        v = rng.standard_normal(key.size).astype(np.float32)
+        t = SparseTensor(row=idx(key // N), col=idx(key % N), value=torch.from_numpy(v).cuda(), sparse_sizes=(M, N))
+        mats.append(t.fill_cache_())
+    big = cat(mats, dim=(0, 1))
+    r0 = c0 = 0
+    for t in mats:
+        M, N = t.sparse_sizes()
+        blk = __narrow_diag__(big, (r0, c0), (M, N))
+        assert blk.sparse_sizes() == (M, N)
+        for name in ("_row", "_rowptr", "_col", "_value", "_rowcount", "_colptr", "_colcount", "_csr2csc", "_csc2csr"):
+            assert torch.equal(getattr(blk.storage, name), getattr(t.storage, name)), name
+        assert torch.equal(big.__narrow_diag__((r0, c0), (M, N)).to_dense(), t.to_dense())
+        r0, c0 = r0 + M, c0 + N
+    index, value = eye(5, dtype=torch.float32, device="cuda")
+    assert index.tolist() == [[0, 1, 2, 3, 4]] * 2 and value.tolist() == [1.0] * 5
+    assert index.dtype == torch.int64 and index.is_cuda
+
+
 def test_cat_random_vs_numpy():
     from paddle_sparse_amd import SparseTensor, cat
 
