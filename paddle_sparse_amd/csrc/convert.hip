@@ -45,9 +45,56 @@ ind2ptr_kernel(const int64_t* __restrict__ ind, int64_t* __restrict__ out,
   }
 }
 
+// The same with two boundaries per lane, so that `ind` is read with one 16-byte
+// load per lane (8-byte accesses reach only ~0.6 of the 16-byte rate on this
+// chip); the entry before the pair comes from the previous lane.  Needs a
+// 16-byte aligned `ind`.
+__global__ void __launch_bounds__(kThreads)
+ind2ptr_pair_kernel(const int64_t* __restrict__ ind, int64_t* __restrict__ out,
+                    int64_t M, int64_t numel) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  const int64_t t0 = 2 * i;  // this lane's boundaries: t0 and t0 + 1
+  int64_t a = 0, b = 0;      // ind[t0], ind[t0 + 1]
+  if (t0 + 1 < numel) {
+    const longlong2 p = *reinterpret_cast<const longlong2*>(ind + t0);
+    a = p.x;
+    b = p.y;
+  } else if (t0 < numel) {
+    a = ind[t0];
+  }
+  int64_t prev = __shfl_up(static_cast<long long>(b), 1);  // ind[t0 - 1]
+  if (lane == 0) prev = (t0 > 0 && t0 <= numel) ? ind[t0 - 1] : 0;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int64_t t = t0 + h;
+    int64_t lo = 0, hi = 0;
+    if (t <= numel) {
+      lo = (t == 0) ? 0 : (h == 0 ? prev : a) + 1;
+      hi = (t == numel) ? M + 1 : (h == 0 ? a : b) + 1;
+      lo = lo < 0 ? 0 : lo;  // as in ind2ptr_kernel: no out-of-bounds store on bad input
+      hi = hi > M + 1 ? M + 1 : hi;
+    }
+    const int64_t len = hi - lo;
+    if (len > 0 && len <= kShortRun) {
+      for (int64_t r = lo; r < hi; ++r) out[r] = t;
+    }
+    unsigned long long pending = __ballot(len > kShortRun);
+    while (pending) {
+      const int src = __ffsll(static_cast<long long>(pending)) - 1;
+      pending &= pending - 1;
+      const int64_t l = __shfl(lo, src);
+      const int64_t hh = __shfl(hi, src);
+      const int64_t tv = t + 2 * (src - lane);
+      for (int64_t r = l + lane; r < hh; r += 64) out[r] = tv;
+    }
+  }
+}
+
 // One wave per 64 consecutive rows.  The wave's edges [ptr[r0], ptr[r0+64))
 // are contiguous, so it sweeps them 64 at a time (coalesced stores) and each
 // lane finds its row by a 6-step search over the 64 pointers kept in LDS.
+template <bool PAIRS>
 __global__ void __launch_bounds__(kThreads)
 ptr2ind_kernel(const int64_t* __restrict__ ptr, int64_t* __restrict__ out,
                int64_t M, int64_t E) {
@@ -70,13 +117,28 @@ ptr2ind_kernel(const int64_t* __restrict__ ptr, int64_t* __restrict__ out,
   int64_t e_end = sptr[wave][64];
   e_begin = e_begin < 0 ? 0 : e_begin;
   e_end = e_end > E ? E : e_end;
-  for (int64_t e = e_begin + lane; e < e_end; e += 64) {
+  auto row_of = [&](int64_t e) {
     int pos = 0;  // largest i in [0, 63] with sptr[i] <= e
 #pragma unroll
     for (int step = 32; step >= 1; step >>= 1) {
       if (sptr[wave][pos + step] <= e) pos += step;
     }
-    out[e] = r0 + pos;
+    return r0 + pos;
+  };
+  if (!PAIRS) {
+    for (int64_t e = e_begin + lane; e < e_end; e += 64) out[e] = row_of(e);
+    return;
+  }
+  // two edges per lane, one 16-byte store (out 16-byte aligned): pairs start at
+  // even e; the odd ends of the wave's range fall back to 8-byte stores
+  for (int64_t e = (e_begin & ~int64_t{1}) + 2 * lane; e < e_end; e += 128) {
+    const bool first = e >= e_begin, second = e + 1 < e_end;
+    longlong2 v;
+    v.x = first ? row_of(e) : 0;
+    v.y = second ? row_of(e + 1) : 0;
+    if (first && second) *reinterpret_cast<longlong2*>(out + e) = v;
+    else if (first) out[e] = v.x;
+    else if (second) out[e + 1] = v.y;
   }
 }
 
@@ -92,6 +154,14 @@ int psa_ind2ptr(const int64_t* ind, int64_t numel, int64_t M, int64_t* out,
   hipStream_t s = psa::as_stream(stream);
   if (numel == 0) {  // csrc/cpu/convert_cpu.cpp:9-11
     PSA_ZERO(out, sizeof(int64_t) * (M + 1), s);
+    return PSA_OK;
+  }
+  if (psa::aligned(ind, 16)) {
+    const int64_t blocks = psa::ceil_div(numel / 2 + 1, kThreads);
+    PSA_REQUIRE(blocks <= 0x7fffffff, "numel too large for one launch");
+    hipLaunchKernelGGL(ind2ptr_pair_kernel, dim3(static_cast<unsigned>(blocks)),
+                       dim3(kThreads), 0, s, ind, out, M, numel);
+    PSA_LAUNCH_CHECK();
     return PSA_OK;
   }
   const int64_t blocks = psa::ceil_div(numel + 1, kThreads);
@@ -111,8 +181,13 @@ int psa_ptr2ind(const int64_t* ptr, int64_t M, int64_t E, int64_t* out,
   hipStream_t s = psa::as_stream(stream);
   const int64_t blocks = psa::ceil_div(M, 64 * (kThreads / 64));
   PSA_REQUIRE(blocks <= 0x7fffffff, "M too large for one launch");
-  hipLaunchKernelGGL(ptr2ind_kernel, dim3(static_cast<unsigned>(blocks)),
-                     dim3(kThreads), 0, s, ptr, out, M, E);
+  if (psa::aligned(out, 16)) {
+    hipLaunchKernelGGL(ptr2ind_kernel<true>, dim3(static_cast<unsigned>(blocks)),
+                       dim3(kThreads), 0, s, ptr, out, M, E);
+  } else {
+    hipLaunchKernelGGL(ptr2ind_kernel<false>, dim3(static_cast<unsigned>(blocks)),
+                       dim3(kThreads), 0, s, ptr, out, M, E);
+  }
   PSA_LAUNCH_CHECK();
   return PSA_OK;
 }

@@ -6,10 +6,12 @@ Same constructor, accessors and cache semantics as the reference class
 are kept because the reference's tests read them.  Every nnz-sized pass on
 the hot path goes to a HIP kernel through paddle_sparse_amd.ops:
 
-  ctor sort (storage.py:158-171) ... make_keys + index_sort + gather_rows
+  ctor sort (storage.py:158-171) ... make_keys + sort_pairs | index_sort + split_keys
   row()/rowptr() (195-222) ......... ptr2ind / ind2ptr
   colcount()/colptr() (386-420) .... bincount / count2ptr (or ind2ptr)
-  csr2csc()/csc2csr() (425-447) .... make_keys + index_sort / invert_permutation
+  csr2csc()/csc2csr() (425-447) .... make_keys + index_sort (+ split_keys, ind2ptr: the
+                                     sorted keys also give row[csr2csc] and colptr)
+                                     / invert_permutation
   is_coalesced()/coalesce() (449-486) unique_sorted + segment_csr
 
 Tensors are torch tensors; torch supplies allocation, views and O(1) glue

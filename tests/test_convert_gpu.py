@@ -36,9 +36,20 @@ def test_random(M, nnz, seed):
     row, rowptr, _, _ = random_csr(M, 4, nnz, seed)
     got = ops.ind2ptr(dev(row), M).cpu().numpy()
     assert np.array_equal(got, oracle.ind2ptr(row, M))
+    # an index that starts 8 bytes into its buffer takes the one-boundary-per-lane kernel
+    shifted = torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda"), dev(row)])[1:]
+    assert nnz == 0 or shifted.data_ptr() % 16 == 8
+    assert np.array_equal(ops.ind2ptr(shifted, M).cpu().numpy(), got)
     back = ops.ptr2ind(dev(rowptr), nnz).cpu().numpy()
     assert np.array_equal(back, oracle.ptr2ind(rowptr, nnz))
     assert np.array_equal(back, row)
+    # an output that starts 8 bytes into its buffer takes the 8-byte-store kernel (straight C-ABI call)
+    from paddle_sparse_amd import _lib
+    buf = torch.full((nnz + 1,), -7, dtype=torch.int64, device="cuda")
+    ptr_d = dev(rowptr)
+    _lib.check(_lib.load().psa_ptr2ind(ptr_d.data_ptr(), M, nnz, buf[1:].data_ptr(),
+                                       torch.cuda.current_stream().cuda_stream))
+    assert int(buf[0]) == -7 and np.array_equal(buf[1:].cpu().numpy(), row)
 
 
 def test_first_and_last_rows_only():
