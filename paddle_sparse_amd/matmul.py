@@ -20,6 +20,25 @@ from .storage import SparseStorage
 from .tensor import SparseTensor
 
 
+def _csc_weights(st: SparseStorage, value: Optional[torch.Tensor], csr2csc, row_csc, mean: bool):
+    """Edge weights in CSC order for grad_mat = A^T grad_out (value[csr2csc],
+    over deg(row) for mean).  A fixed adjacency — the usual GNN case — asks for
+    the same array every step, so the last one is kept on the storage together
+    with the value tensor it was built from: holding that tensor keeps its
+    address from being reused, and its version counter tells an in-place update."""
+    memo = getattr(st, "_csc_weight_memo", None)
+    if memo is not None:
+        src, version, was_mean, w = memo
+        same = (src is None and value is None) or (
+            src is not None and value is not None and src.data_ptr() == value.data_ptr()
+            and src.shape == value.shape and version == value._version)
+        if same and was_mean == mean:
+            return w
+    w = ops.transpose_weights(value, csr2csc, row_csc, st.rowptr(), mean)
+    st._csc_weight_memo = (value, None if value is None else value._version, mean, w)
+    return w
+
+
 class _SpMM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, value: Optional[torch.Tensor], mat: torch.Tensor,
@@ -57,10 +76,11 @@ class _SpMM(torch.autograd.Function):
                 grad_value = ops.spmm_value_bw(None, st.rowptr(), st.col(), mat, grad_out,
                                                "mean" if mean else "sum")
             if need_mat:
+                csr2csc = st.csr2csc()  # first: it leaves colptr and row[csr2csc] behind
                 row_csc = st._row_in_csc_order()
                 w = None
                 if value is not None or mean:
-                    w = ops.transpose_weights(value, st.csr2csc(), row_csc, st.rowptr(), mean)
+                    w = _csc_weights(st, value, csr2csc, row_csc, mean)
                 grad_mat = ops.spmm_sum(st.colptr(), row_csc, w, grad_out)
         return grad_value, grad_mat, None, None
 

@@ -341,6 +341,40 @@ def test_spmm_autograd_vs_oracle(reduce, has_value):
         np.testing.assert_allclose(v.grad.cpu().numpy(), gV, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("reduce", ["sum", "mean"])
+def test_grad_mat_weights_are_reused_until_the_values_change(reduce):
+    """The CSC-ordered weights of grad_mat are memoised on the storage for a
+    fixed adjacency; an in-place change of the values must be seen."""
+    from paddle_sparse_amd import SparseTensor
+
+    rng = np.random.default_rng(22)
+    M, N, K = 300, 200, 16
+    key = np.unique(rng.integers(0, M * N, 3000))
+    row, col = key // N, key % N
+    val = rng.standard_normal(key.size).astype(np.float32)
+    G = rng.standard_normal((M, K)).astype(np.float32)
+    rowptr = oracle.ind2ptr(row, M)
+    v = torch.from_numpy(val).cuda()
+    a = SparseTensor(row=idx(row), col=idx(col), value=v, sparse_sizes=(M, N))
+
+    def grad_mat():
+        Bt = torch.zeros(N, K, device="cuda", requires_grad=True)
+        a.matmul(Bt, reduce).backward(torch.from_numpy(G).cuda())
+        return Bt.grad
+
+    first = grad_mat()
+    memo = a.storage._csc_weight_memo[3]
+    again = grad_mat()
+    assert a.storage._csc_weight_memo[3] is memo and torch.equal(first, again)
+    np.testing.assert_allclose(first.cpu().numpy(), oracle.spmm_mat_bw(reduce, row, rowptr, col, val, G, N),
+                               rtol=1e-4, atol=1e-4)
+    v.mul_(-2.0)  # in place: same address, new version
+    changed = grad_mat()
+    assert a.storage._csc_weight_memo[3] is not memo
+    np.testing.assert_allclose(changed.cpu().numpy(), oracle.spmm_mat_bw(reduce, row, rowptr, col, -2 * val, G, N),
+                               rtol=1e-4, atol=1e-4)
+
+
 def test_cpu_tensors_are_rejected_by_the_hot_path():
     from paddle_sparse_amd import SparseTensor
 
