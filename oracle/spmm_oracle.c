@@ -88,7 +88,8 @@ void oracle_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
 void oracle_spmm_omp(int reduce, const int64_t* rowptr, const int64_t* col,
                      const float* value, const float* mat, int64_t M,
                      int64_t K, int64_t nnz, float* out, int64_t* arg_out) {
-#pragma omp parallel for schedule(dynamic, 1024)
+  /* chunks of 4 x 256 rows: fine enough to balance, coarse enough to amortise */
+#pragma omp parallel for schedule(dynamic, 4)
   for (int64_t blk = 0; blk < (M + 255) / 256; ++blk) {
     const int64_t r0 = blk * 256;
     const int64_t r1 = r0 + 256 < M ? r0 + 256 : M;
