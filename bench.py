@@ -146,8 +146,16 @@ def main() -> None:
     # world == 1 runs without a process group unless a rehearsal asks for one
     use_dist = world > 1 or os.environ.get("PSA_BENCH_FORCE_DIST") == "1"
     dist = None
+    stdout_fd = None
     if use_dist:
         import torch.distributed as dist  # noqa: PLC0415
+
+        # RCCL writes a version banner to STDOUT when its communicator comes up;
+        # the contract is ONE JSON line there, so fd 1 points at stderr until
+        # the line is printed.
+        sys.stdout.flush()
+        stdout_fd = os.dup(1)
+        os.dup2(2, 1)
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -197,10 +205,24 @@ def main() -> None:
     kern_ms = event_ms(local_kernel, args.steps)
     gather_ms = event_ms(lambda: op.gather(B_local), max(3, args.steps // 5)) if use_dist else 0.0
 
-    t = torch.tensor([elapsed, kern_ms, gather_ms], dtype=torch.float64, device=device)
+    # Third figure SURVEY.md §8(e) asks for: the same step with B cut into column
+    # slices whose all-gathers are queued up front, so the SpMM of slice c runs
+    # under the exchange of the later slices.  Reported beside `value`, never as it.
+    overlap_s, overlap_steps, overlap_chunks = 0.0, 0, 4
+    if use_dist and args.feature_chunks <= 1 and F % overlap_chunks == 0:
+        overlap_steps = max(3, args.steps // 5)
+        op(B_local, feature_chunks=overlap_chunks)
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(overlap_steps):
+            op(B_local, feature_chunks=overlap_chunks)
+        sync_all()
+        overlap_s = time.perf_counter() - t1
+
+    t = torch.tensor([elapsed, kern_ms, gather_ms, overlap_s], dtype=torch.float64, device=device)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, kern_ms, gather_ms = (float(x) for x in t)
+    elapsed, kern_ms, gather_ms, overlap_s = (float(x) for x in t)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -250,6 +272,11 @@ def main() -> None:
                 "feature_chunks": args.feature_chunks,
                 "allgather_bytes_received_per_rank": (world - 1) * M * F * 4,
                 "spmm_only_aggregate_gedges_per_s": round(world * nnz / (kern_ms * 1e-3) / 1e9, 4),
+                "end_to_end_serial_gedges_per_s": round(value, 4),
+                "end_to_end_overlapped_gedges_per_s": (
+                    round(world * nnz / (overlap_s / overlap_steps) / 1e9, 4) if overlap_steps else None),
+                "overlapped_ms_per_step": round(overlap_s / overlap_steps * 1e3, 4) if overlap_steps else None,
+                "overlapped_feature_chunks": overlap_chunks if overlap_steps else None,
                 "note": "value counts the all-gather of B inside every step; spmm_only_* is the "
                         "local-kernel rate with B already assembled",
             }
@@ -259,6 +286,9 @@ def main() -> None:
             scale = np.abs(ref).max()
             line["cpu_baseline"] = info
             line["check_max_abs_err_vs_oracle"] = float(np.abs(got - ref).max() / scale)
+        if stdout_fd is not None:
+            sys.stdout.flush()
+            os.dup2(stdout_fd, 1)
         print(json.dumps(line), flush=True)
 
     if use_dist:
