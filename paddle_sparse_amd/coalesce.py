@@ -19,13 +19,20 @@ import torch
 from . import ops
 
 
+_ALWAYS_SORT_BELOW = 1 << 18
+
+
 def _coalesce_sorted_stream(row, col, value, m: int, n: int, op: str):
     nnz = col.numel()
     if nnz == 0:
         return row, col, value
-    keys, unsorted = ops.make_keys(row, col, n, check_sorted=True)
+    # Small inputs are launch- and sync-bound (10k edges: ~150 us, of which each
+    # host read is ~15): asking the device whether the keys are sorted already
+    # costs more than sorting them, so below this size the question is skipped.
+    ask = nnz > _ALWAYS_SORT_BELOW
+    keys, unsorted = ops.make_keys(row, col, n, check_sorted=ask)
     perm = None
-    was_sorted = not int(unsorted.item())
+    was_sorted = ask and not int(unsorted.item())
     if not was_sorted:
         if value is not None and value.dim() == 1 and value.element_size() == 4:
             # 4-byte scalar values ride through the sort as the payload: the
