@@ -62,7 +62,11 @@ report("C3 grad_mat (A^T gOut over CSC)", event_ms(grad_mat, 20), nnz,
        algorithmic_bytes(nnz, M, F) + nnz * (8 + 4 + 4))
 out, arg = ops.spmm_max(rowptr, col, val, B)
 ops.spmm_minmax_bw(col, val, B, G, arg)
-print(f"{'C3 spmm_max bwd (atomics)':34s} {event_ms(lambda: ops.spmm_minmax_bw(col, val, B, G, arg), 5):8.3f} ms")
+print(f"{'C3 spmm_max bwd (float atomics)':34s} {event_ms(lambda: ops.spmm_minmax_bw(col, val, B, G, arg), 5):8.3f} ms")
+tags = st._csc_edge_tags()
+ops.spmm_minmax_bw_csc(rowptr, colptr, row_csc, perm, tags, val, B, G, arg)
+t_csc_bw = event_ms(lambda: ops.spmm_minmax_bw_csc(rowptr, colptr, row_csc, perm, tags, val, B, G, arg), 5)
+print(f"{'C3 spmm_max bwd (one CSC pass)':34s} {t_csc_bw:8.3f} ms  (production: no atomics, reproducible)")
 
 # end-to-end autograd step (fwd + bwd of sum)
 v = val.clone().requires_grad_()
@@ -71,11 +75,26 @@ a2 = SparseTensor(row=row, rowptr=rowptr, col=col, value=v, sparse_sizes=(M, M),
 a2.storage._csr2csc, a2.storage._colptr, a2.storage._row_csc = perm, colptr, row_csc
 
 
-def fwd_bwd():
+def fwd_bwd(reduce="sum"):
     v.grad = Bt.grad = None
-    (a2 @ Bt).backward(G)
+    a2.matmul(Bt, reduce).backward(G)
 
 
-fwd_bwd()
-ms = event_ms(fwd_bwd, 10)
-print(f"{'C3 spmm_sum fwd+bwd (autograd)':34s} {ms:8.3f} ms  {nnz / ms / 1e6:7.2f} GEdges/s")
+for red in ("sum", "max"):
+    fwd_bwd(red)
+    ms = event_ms(lambda: fwd_bwd(red), 10)
+    print(f"{'C3 spmm_' + red + ' fwd+bwd (autograd)':34s} {ms:8.3f} ms  {nnz / ms / 1e6:7.2f} GEdges/s")
+
+# fixed adjacency (values not trained): grad wrt the dense operand only
+a3 = SparseTensor(row=row, rowptr=rowptr, col=col, value=val, sparse_sizes=(M, M), is_sorted=True, trust_data=True)
+a3.storage._csr2csc, a3.storage._colptr, a3.storage._row_csc = perm, colptr, row_csc
+
+
+def fwd_bwd_fixed():
+    Bt.grad = None
+    (a3 @ Bt).backward(G)
+
+
+fwd_bwd_fixed()
+ms = event_ms(fwd_bwd_fixed, 10)
+print(f"{'C3 spmm_sum fwd+bwd, fixed A':34s} {ms:8.3f} ms  {nnz / ms / 1e6:7.2f} GEdges/s")
