@@ -154,7 +154,8 @@ int psa_spmm_minmax_bw(const int64_t* col, const float* value, const float* mat,
  * matrix (the caches storage.py:425-434 / tensor.py:254-257 already keep for
  * the sum/mean backward).  For column c and each stored entry e = (r, c):
  *   grad_mat[c, k]  += w_e * grad[r, k]        where arg_out[r, k] == e
- *   grad_value[e]    = sum of mat[c, k] * grad[r, k] over those k
+ *   grad_value_csc[j] = sum of mat[c, k] * grad[r, k] over those k   (j = CSC
+ *                       position of e, i.e. e = csr2csc[j])
  * Scattered float atomics run at ~20-50 G adds/s on this chip whatever their
  * shape (256 M of them at M = 2 M, K = 128: 5 ms); this pass is a gather like
  * the forward, every output element is written once and sums run in CSC edge
@@ -162,7 +163,10 @@ int psa_spmm_minmax_bw(const int64_t* col, const float* value, const float* mat,
  *
  * tag: uint8[nnz] from psa_csc_edge_tags (depends on the sparsity structure
  * only: cache it with csr2csc).  value: f32[nnz] in CSR order, or NULL.
- * grad_value: f32[nnz] in CSR order or NULL (then mat may be NULL too).
+ * grad_value_csc: f32[nnz] or NULL (then mat may be NULL too); it is written in
+ * CSC order, contiguously — psa_gather_rows(grad_value_csc, csc2csr, nnz, 4, ..)
+ * puts it into the CSR order the API returns (a 4-byte scatter from inside the
+ * pass costs more than that gather).
  * workspace: psa_spmm_minmax_bw_csc_workspace_bytes(M, K, nnz) bytes, 16-byte
  * aligned (M*K bytes of arg_out compressed to row-local byte indices +
  * long-column scratch).  Returns PSA_ERR_UNSUPPORTED unless K % 4 == 0 and
@@ -176,9 +180,29 @@ int psa_spmm_minmax_bw_csc(const int64_t* rowptr, const int64_t* colptr,
                            const uint8_t* tag, const float* value,
                            const float* mat, const float* grad,
                            const int64_t* arg_out, int64_t M, int64_t N,
-                           int64_t K, int64_t nnz, float* grad_value,
+                           int64_t K, int64_t nnz, float* grad_value_csc,
                            float* grad_mat, void* workspace,
                            size_t workspace_bytes, psa_stream_t stream);
+
+/* sum backward with BOTH gradients in one pass over the CSC view (trainable
+ * edge values): for column c and each stored entry e = (r, c)
+ *   grad_mat[c, :] += value[e] * grad[r, :]      (value NULL: weights 1)
+ *   grad_value_csc[j] = <mat[c, :], grad[r, :]>   (j = CSC position of e)
+ * The gathered grad row serves both, mat[c, :] is the column's own row, and
+ * value is read through csr2csc — so the separate psa_spmm_value_bw (a second
+ * full gather, of mat rows) and psa_transpose_weights passes are not needed.
+ * For mean, hand in grad already divided by max(deg(row), 1).
+ * grad_value_csc: f32[nnz] in CSC order or NULL (CSR order: psa_gather_rows
+ * through csc2csr, as above).  workspace:
+ * psa_spmm_sum_bw_csc_workspace_bytes(K, nnz) bytes, 16-byte aligned.
+ * PSA_ERR_UNSUPPORTED unless K % 4 == 0 and K <= 256. */
+size_t psa_spmm_sum_bw_csc_workspace_bytes(int64_t K, int64_t nnz);
+int psa_spmm_sum_bw_csc(const int64_t* colptr, const int64_t* row_csc,
+                        const int64_t* csr2csc, const float* value,
+                        const float* mat, const float* grad, int64_t N,
+                        int64_t K, int64_t nnz, float* grad_value_csc,
+                        float* grad_mat, void* workspace,
+                        size_t workspace_bytes, psa_stream_t stream);
 
 /* Test/bench hook: choose the SpMM kernel variant for subsequent psa_spmm
  * calls of this process (0 = auto).  Returns the previous value.  Variants

@@ -95,7 +95,15 @@ using psa::push_long_row;
 // With grad_value set, the same pass also forms grad_value[e] = sum over the
 // hit columns k of mat[c, k] * grad[r, k]: the gathered grad row is already in
 // registers, mat[c, :] is this wave's own row (mrow), and every CSR edge shows
-// up exactly once in the CSC walk, so each grad_value element is stored once.
+// up exactly once in the CSC walk, so each grad_value element is stored once
+// (in CSC order; the caller permutes it back with one gather through csc2csr).
+// MODE of reduce_edge_range / spmm_fused_kernel:
+//   M_PLAIN  the forward (and grad_mat of sum/mean with ready-made CSC weights);
+//   M_MASK   min/max backward over the CSC view (byte test described above);
+//   M_CSC    sum/mean backward over the CSC view: the same indirection (value
+//            read through edge_id) and the same grad_value dot, every term on.
+enum { M_PLAIN = 0, M_MASK = 1, M_CSC = 2 };
+
 struct MaskArgs {
   const uint8_t* bytes = nullptr;    // [M, K] at the lane's k0
   const uint8_t* tag = nullptr;      // [nnz], CSC order
@@ -103,19 +111,21 @@ struct MaskArgs {
   const int64_t* arg = nullptr;      // arg_out [M, K] at the lane's k0
   const float* mat = nullptr;        // dense operand of the forward [N, K] (grad_value only)
   const float* mrow = nullptr;       // set by the kernel: mat[c, k0..] of the wave's column
-  float* grad_value = nullptr;       // [nnz], CSR order, or NULL
+  float* grad_value = nullptr;       // [nnz] in CSC order (position j <-> edge edge_id[j]), or NULL
 };
 
 // Reduce edges [s, e) of one row into acc/arg: LPR lanes x VEC floats cover the
 // K tile at k0, the G = 64/LPR lane groups take different edges of a step, U
 // steps are issued before any is consumed; the groups are folded at the end.
-template <int VEC, int LPR, int RED, int U, bool MASK = false>
+template <int VEC, int LPR, int RED, int U, int MODE = M_PLAIN>
 __device__ __forceinline__ void reduce_edge_range(
     const int64_t* __restrict__ col, const float* __restrict__ val,
     const float* __restrict__ matk, int64_t K, bool kact, int64_t s, int64_t e,
     int64_t nnz, int lane, float (&acc)[VEC], int64_t (&arg)[VEC],
     const MaskArgs& m = MaskArgs{}) {
-  static_assert(!MASK || (RED == R_SUM && VEC == 4), "masked form: sum over float4 tiles");
+  static_assert(MODE == M_PLAIN || (RED == R_SUM && VEC == 4), "CSC forms: sum over float4 tiles");
+  constexpr bool INDIRECT = MODE != M_PLAIN;
+  constexpr bool MASK = MODE == M_MASK;
   constexpr int G = 64 / LPR;
   static_assert(64 % (G * U) == 0, "edge batch must divide the wave");
   const int g = lane / LPR;
@@ -127,7 +137,7 @@ __device__ __forceinline__ void reduce_edge_range(
   float mr[VEC];  // MASK + grad_value: this lane's slice of mat[c, :]
 #pragma unroll
   for (int i = 0; i < VEC; ++i) mr[i] = 0.f;
-  const bool want_gv = MASK && m.grad_value != nullptr;  // wave-uniform
+  const bool want_gv = INDIRECT && m.grad_value != nullptr;  // wave-uniform
   if (want_gv && kact) load_vec<VEC>(m.mrow, mr);
   for (int64_t base = s; base < e; base += 64) {
     const int n = (e - base) < 64 ? static_cast<int>(e - base) : 64;
@@ -136,10 +146,10 @@ __device__ __forceinline__ void reduce_edge_range(
     int64_t id_l = 0;  // MASK: CSR edge id; its tag rides in the top byte
     if (lane < n) {
       c_l = col[base + lane];
-      if (MASK) {
+      if (INDIRECT) {
         id_l = m.edge_id[base + lane];
         v_l = val ? val[id_l] : 1.f;
-        id_l |= static_cast<int64_t>(m.tag[base + lane]) << 56;
+        if (MASK) id_l |= static_cast<int64_t>(m.tag[base + lane]) << 56;
       } else {
         v_l = val ? val[base + lane] : 1.f;
       }
@@ -181,8 +191,10 @@ __device__ __forceinline__ void reduce_edge_range(
             if (!hit) b[u][i] = 0.f;
           }
         }
+      }
+      if (INDIRECT) {
         if (want_gv) {
-          static_assert(!MASK || ((U & (U - 1)) == 0 && U <= LPR), "U must be a power of two <= LPR");
+          static_assert(!INDIRECT || ((U & (U - 1)) == 0 && U <= LPR), "U must be a power of two <= LPR");
           const int l = lane % LPR;
           float dot[U];
 #pragma unroll
@@ -206,9 +218,11 @@ __device__ __forceinline__ void reduce_edge_range(
           }
 #pragma unroll
           for (int bit = U; bit < LPR; bit <<= 1) dot[0] += __shfl_xor(dot[0], bit);
+          // stored at the edge's CSC position: contiguous per wave.  (Storing
+          // straight to the CSR position, a 4-byte scatter, cost 0.8 ms more at
+          // 20 M edges than this store plus the caller's gather through csc2csr.)
           const int slot = j + (l % U) * G + g;  // < 64
-          const int64_t my_id = shfl_i64(id_l, slot) & 0x00ffffffffffffffll;
-          if (l < U && slot < n) m.grad_value[my_id] = dot[0];
+          if (l < U && slot < n) m.grad_value[base + slot] = dot[0];
         }
       }
 #pragma unroll
@@ -501,7 +515,7 @@ find_long_rows_kernel(const int64_t* __restrict__ rowptr, int64_t M,
   if (deg > kLongRow) push_long_row(ctr, list, r, deg);
 }
 
-template <int VEC, int LPR, int RED, int U, bool MASK = false>
+template <int VEC, int LPR, int RED, int U, int MODE = M_PLAIN>
 __global__ void __launch_bounds__(kThreads)
 spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col,
                   const float* __restrict__ val, const float* __restrict__ mat,
@@ -518,7 +532,7 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
   const bool kact = k0 < K;
   float acc[VEC];
   int64_t arg[VEC];
-  if (MASK) {
+  if (MODE == M_MASK) {
     mask.bytes += k0;
     mask.arg += k0;
   }
@@ -531,8 +545,8 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
       const int64_t rs = rowptr[ent.row], re = rowptr[ent.row + 1];
       const int64_t s = rs + static_cast<int64_t>(c - ent.first_chunk) * kLongChunk;
       const int64_t e = s + kLongChunk < re ? s + kLongChunk : re;
-      if (MASK && mask.mat) mask.mrow = mask.mat + ent.row * K + k0;
-      reduce_edge_range<VEC, LPR, RED, U, MASK>(col, val, mat + k0, K, kact, s, e, nnz, lane, acc, arg, mask);
+      if (MODE != M_PLAIN && mask.mat) mask.mrow = mask.mat + ent.row * K + k0;
+      reduce_edge_range<VEC, LPR, RED, U, MODE>(col, val, mat + k0, K, kact, s, e, nnz, lane, acc, arg, mask);
       if (g == 0 && kact) {
         store_vec<VEC>(part_val + static_cast<int64_t>(c) * K + k0, acc);
         if (RED != R_SUM) {
@@ -549,8 +563,8 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
   const int64_t s = rowptr[row];
   const int64_t e = rowptr[row + 1];
   if (e - s > kLongRow) return;  // on the list: chunk role + combine write it
-  if (MASK && mask.mat) mask.mrow = mask.mat + row * K + k0;
-  reduce_edge_range<VEC, LPR, RED, U, MASK>(col, val, mat + k0, K, kact, s, e, nnz, lane, acc, arg, mask);
+  if (MODE != M_PLAIN && mask.mat) mask.mrow = mask.mat + row * K + k0;
+  reduce_edge_range<VEC, LPR, RED, U, MODE>(col, val, mat + k0, K, kact, s, e, nnz, lane, acc, arg, mask);
   if (g == 0 && kact) {
     const int64_t deg = e - s;
     if (RED == R_SUM) {
@@ -787,7 +801,7 @@ int launch_fused(int red, const int64_t* rowptr, const int64_t* col, const float
 }
 
 // The same three launches in the MASK form (sum over the CSC view; see MaskArgs).
-template <int LPR, int U>
+template <int LPR, int U, int MODE>
 int launch_fused_masked(const int64_t* colptr, const int64_t* row_csc, const float* value,
                         const float* grad, float* out, int64_t N, int64_t K, int64_t nnz,
                         const MaskArgs& mask, const LongScratch& w, hipStream_t s) {
@@ -796,7 +810,7 @@ int launch_fused_masked(const int64_t* colptr, const int64_t* row_csc, const flo
   const dim3 block(kThreads), grid(static_cast<unsigned>(gx));
   hipLaunchKernelGGL(find_long_rows_kernel, dim3(static_cast<unsigned>(psa::ceil_div(N, kThreads))),
                      block, 0, s, colptr, N, w.ctr, w.list);
-  hipLaunchKernelGGL((spmm_fused_kernel<4, LPR, R_SUM, U, true>), grid, block, 0, s, colptr, row_csc,
+  hipLaunchKernelGGL((spmm_fused_kernel<4, LPR, R_SUM, U, MODE>), grid, block, 0, s, colptr, row_csc,
                      value, grad, out, static_cast<int64_t*>(nullptr), N, K, nnz, 0, w.ctr, w.list,
                      w.part_val, w.part_arg, mask);
   hipLaunchKernelGGL((spmm_long_combine_kernel<R_SUM>), dim3(kLongBlocks), dim3(psa::kLongThreads), 0, s,
@@ -990,11 +1004,53 @@ int psa_spmm_minmax_bw_csc(const int64_t* rowptr, const int64_t* colptr,
     mask.grad_value = grad_value;
   }
   const int64_t q = K / 4;
-  if (q <= 4) return launch_fused_masked<4, 1>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
-  if (q <= 8) return launch_fused_masked<8, 2>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
-  if (q <= 16) return launch_fused_masked<16, 4>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
-  if (q <= 32) return launch_fused_masked<32, 4>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
-  return launch_fused_masked<64, 8>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
+  if (q <= 4) return launch_fused_masked<4, 1, M_MASK>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
+  if (q <= 8) return launch_fused_masked<8, 2, M_MASK>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
+  if (q <= 16) return launch_fused_masked<16, 4, M_MASK>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
+  if (q <= 32) return launch_fused_masked<32, 4, M_MASK>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
+  return launch_fused_masked<64, 8, M_MASK>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
+}
+
+size_t psa_spmm_sum_bw_csc_workspace_bytes(int64_t K, int64_t nnz) {
+  return long_workspace_bytes(false, K > 0 ? K : 1, nnz > 0 ? nnz : 1);
+}
+
+int psa_spmm_sum_bw_csc(const int64_t* colptr, const int64_t* row_csc, const int64_t* csr2csc,
+                        const float* value, const float* mat, const float* grad, int64_t N,
+                        int64_t K, int64_t nnz, float* grad_value, float* grad_mat,
+                        void* workspace, size_t workspace_bytes, psa_stream_t stream) {
+  PSA_REQUIRE(N >= 0 && K >= 0 && nnz >= 0, "negative size");
+  if (N == 0 || K == 0) return PSA_OK;
+  if (K % 4 != 0 || K > 256 || !psa::aligned(grad, 16) || !psa::aligned(grad_mat, 16) ||
+      !psa::aligned(mat, 16)) {
+    psa::set_error("psa_spmm_sum_bw_csc: needs K % 4 == 0, K <= 256 and 16-byte aligned operands "
+                   "(use psa_spmm_value_bw + psa_transpose_weights + psa_spmm)");
+    return PSA_ERR_UNSUPPORTED;
+  }
+  PSA_REQUIRE(colptr && grad_mat, "NULL pointer");
+  PSA_REQUIRE(nnz == 0 || (row_csc && csr2csc && grad), "NULL pointer");
+  PSA_REQUIRE(grad_value == nullptr || mat != nullptr || nnz == 0, "grad_value needs mat");
+  PSA_REQUIRE(max_long_chunks(nnz) < (1ll << 32), "too many chunks");
+  if (workspace == nullptr || workspace_bytes < psa_spmm_sum_bw_csc_workspace_bytes(K, nnz)) {
+    psa::set_error("psa_spmm_sum_bw_csc: workspace too small");
+    return PSA_ERR_WORKSPACE;
+  }
+  PSA_REQUIRE(psa::aligned(workspace, 16), "workspace must be 16-byte aligned");
+  hipStream_t s = psa::as_stream(stream);
+  const LongScratch w = carve(workspace, false, K, nnz > 0 ? nnz : 1);
+  PSA_ZERO(w.ctr, 8, s);
+  MaskArgs mask;
+  mask.edge_id = csr2csc;
+  if (grad_value != nullptr && nnz > 0) {
+    mask.mat = mat;
+    mask.grad_value = grad_value;
+  }
+  const int64_t q = K / 4;
+  if (q <= 4) return launch_fused_masked<4, 1, M_CSC>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
+  if (q <= 8) return launch_fused_masked<8, 2, M_CSC>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
+  if (q <= 16) return launch_fused_masked<16, 4, M_CSC>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
+  if (q <= 32) return launch_fused_masked<32, 4, M_CSC>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
+  return launch_fused_masked<64, 8, M_CSC>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
 }
 
 size_t psa_spmm_workspace_bytes(int reduce, int64_t K, int64_t nnz) {

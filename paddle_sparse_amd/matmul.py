@@ -6,7 +6,8 @@ Semantics and the backward formulas are upstream pytorch_sparse
 (torch_sparse/matmul.py): sum/mean differentiate wrt the dense operand with
 an SpMM over the CSC view and wrt the values with an SDDMM-shaped kernel;
 min/max route gradients through arg_out.  All compute is HIP
-(psa_spmm, psa_spmm_value_bw, psa_transpose_weights, psa_spmm_minmax_bw).
+(psa_spmm, psa_spmm_value_bw, psa_transpose_weights, psa_spmm_sum_bw_csc,
+psa_spmm_minmax_bw_csc, psa_spmm_minmax_bw).
 """
 from __future__ import annotations
 
@@ -66,12 +67,25 @@ class _SpMM(torch.autograd.Function):
                 csr2csc = st.csr2csc()  # first: it leaves colptr and row[csr2csc] behind
                 grad_value, grad_mat = ops.spmm_minmax_bw_csc(
                     st.rowptr(), st.colptr(), st._row_in_csc_order(), csr2csc, st._csc_edge_tags(),
-                    value, mat, grad_out, arg, want_value=need_value)
+                    value, mat, grad_out, arg, want_value=need_value,
+                    csc2csr=st.csc2csr() if need_value else None)
             else:
                 grad_value, grad_mat = ops.spmm_minmax_bw(st.col(), value, mat, grad_out, arg,
                                                          want_value=need_value, want_mat=need_mat)
         else:
             mean = reduce == "mean"
+            if need_value and need_mat and ops.minmax_bw_csc_supported(grad_out.shape[1]):
+                # Trainable edge values: both gradients in ONE pass over the CSC
+                # view — the gathered grad_out row feeds grad_mat and, dotted with
+                # the column's own mat row, grad_value (instead of a second full
+                # gather of mat rows in spmm_value_bw plus the weight gather).
+                csr2csc = st.csr2csc()
+                g = grad_out
+                if mean:  # 1/deg(row) folded into grad_out serves both gradients
+                    g = grad_out / st.rowcount().clamp(min=1).to(grad_out.dtype).view(-1, 1)
+                grad_value, grad_mat = ops.spmm_sum_bw_csc(st.colptr(), st._row_in_csc_order(), csr2csc,
+                                                           value, mat, g, True, csc2csr=st.csc2csr())
+                return grad_value, grad_mat, None, None
             if need_value:
                 grad_value = ops.spmm_value_bw(None, st.rowptr(), st.col(), mat, grad_out,
                                                "mean" if mean else "sum")

@@ -399,10 +399,11 @@ def minmax_bw_csc_supported(K: int) -> bool:
 
 
 def spmm_minmax_bw_csc(rowptr, colptr, row_csc, csr2csc, tag, value, mat, grad, arg_out,
-                       want_value: bool = True):
+                       want_value: bool = True, csc2csr: Optional[torch.Tensor] = None):
     """Backward of spmm_min / spmm_max in one pass over the CSC view, no atomics
     (see include/paddle_sparse_hip.h).  Returns (grad_value f32[nnz] | None,
-    grad_mat f32[N, K])."""
+    grad_mat f32[N, K]); grad_value is in CSR order (the pass writes it in CSC
+    order, `csc2csr` — computed here when not given — brings it back)."""
     rowptr, colptr = _index(rowptr, "rowptr"), _index(colptr, "colptr")
     row_csc, csr2csc = _index(row_csc, "row_csc"), _index(csr2csc, "csr2csc")
     grad = _f32(grad, "grad")
@@ -431,6 +432,36 @@ def spmm_minmax_bw_csc(rowptr, colptr, row_csc, csr2csc, tag, value, mat, grad, 
                                          _ptr(mat) if want_value else None, _ptr(grad), _ptr(arg_out),
                                          M, N, K, nnz, _ptr(gv), _ptr(gm), _ptr(ws), ws.numel(),
                                          _stream()))
+    if gv is not None:
+        gv = gather_rows(gv, csc2csr if csc2csr is not None else invert_permutation(csr2csc))
+    return gv, gm
+
+
+def spmm_sum_bw_csc(colptr, row_csc, csr2csc, value, mat, grad, want_value: bool = True,
+                    csc2csr: Optional[torch.Tensor] = None):
+    """sum backward, both gradients in one pass over the CSC view (see
+    include/paddle_sparse_hip.h).  Returns (grad_value f32[nnz] | None, in CSR
+    order, grad_mat f32[N, K]).  For mean, pass grad / max(deg, 1)."""
+    colptr, row_csc, csr2csc = _index(colptr, "colptr"), _index(row_csc, "row_csc"), _index(csr2csc, "csr2csc")
+    grad = _f32(grad, "grad")
+    if value is not None:
+        value = _f32(value, "value")
+    K, N, nnz = grad.shape[1], colptr.numel() - 1, csr2csc.numel()
+    gv = None
+    if want_value:
+        mat = _f32(mat, "mat")
+        if mat.shape != (N, K):
+            raise ValueError("mat must be [N, K]")
+        gv = torch.empty(nnz, dtype=torch.float32, device=grad.device)
+    gm = torch.empty((N, K), dtype=torch.float32, device=grad.device)
+    lib = _lib.load()
+    ws = _workspace(lib.psa_spmm_sum_bw_csc_workspace_bytes(K, nnz), grad.device)
+    with torch.cuda.device(grad.device):
+        check(lib.psa_spmm_sum_bw_csc(_ptr(colptr), _ptr(row_csc), _ptr(csr2csc), _ptr(value),
+                                      _ptr(mat) if want_value else None, _ptr(grad), N, K, nnz,
+                                      _ptr(gv), _ptr(gm), _ptr(ws), ws.numel(), _stream()))
+    if gv is not None:
+        gv = gather_rows(gv, csc2csr if csc2csr is not None else invert_permutation(csr2csc))
     return gv, gm
 
 

@@ -172,6 +172,43 @@ def test_minmax_bw_over_csc(reduce, has_value, K, graph):
     assert none is None and torch.equal(gm, gm3)
 
 
+@pytest.mark.parametrize("has_value", [True, False])
+@pytest.mark.parametrize("K", [4, 32, 64, 100, 128, 256])
+@pytest.mark.parametrize("graph", ["uniform", "hubs"])
+def test_sum_bw_one_csc_pass(has_value, K, graph):
+    """psa_spmm_sum_bw_csc (both sum gradients from one pass over the CSC view)
+    against the oracle's spmm_value_bw / spmm_mat_bw."""
+    from paddle_sparse_amd import SparseStorage, ops
+
+    if graph == "hubs":
+        row, rowptr, col, val = skewed_csr(600, 40, seed=5 + K, long_rows=(0, 7, 599), long_deg=700)
+        M, N = 600, 40
+    else:
+        row, rowptr, col, val = random_csr(3000, 2500, 30_000, 6 + K)
+        M, N = 3000, 2500
+    if not has_value:
+        val = None
+    rng = np.random.default_rng(3)
+    B = rng.standard_normal((N, K)).astype(np.float32)
+    G = rng.standard_normal((M, K)).astype(np.float32)
+    ref_m = oracle.spmm_mat_bw("sum", row, rowptr, col, val, G, N)
+    ref_v = oracle.spmm_value_bw("sum", row, rowptr, col, B, G)
+    st = SparseStorage(rowptr=dev(rowptr), col=dev(col), value=dev(val), sparse_sizes=(M, N), is_sorted=True)
+    csr2csc = st.csr2csc()
+    gv, gm = ops.spmm_sum_bw_csc(st.colptr(), st._row_in_csc_order(), csr2csc, st.value(), dev(B), dev(G), True,
+                                 csc2csr=st.csc2csr())
+    w = np.ones(col.size, np.float32) if val is None else np.abs(val)
+    scale_m = np.zeros((N, K), np.float32)
+    np.add.at(scale_m, col, w[:, None] * np.abs(G[row]))
+    assert np.all(np.abs(gm.cpu().numpy() - ref_m) <= 1e-5 * scale_m + 1e-30)
+    scale_v = (np.abs(B[col]) * np.abs(G[row])).sum(1)
+    assert np.all(np.abs(gv.cpu().numpy() - ref_v) <= 1e-5 * scale_v + 1e-30)
+    # without the inverse permutation handed in, the op builds it itself; grad_mat alone skips the dots
+    gv2, gm2 = ops.spmm_sum_bw_csc(st.colptr(), st._row_in_csc_order(), csr2csc, st.value(), dev(B), dev(G), True)
+    none, gm3 = ops.spmm_sum_bw_csc(st.colptr(), st._row_in_csc_order(), csr2csc, st.value(), None, dev(G), False)
+    assert torch.equal(gv, gv2) and torch.equal(gm, gm2) and none is None and torch.equal(gm, gm3)
+
+
 def test_minmax_bw_over_csc_rejects_unaligned_k():
     from paddle_sparse_amd import ops
     from paddle_sparse_amd._lib import HipCoreError

@@ -53,7 +53,7 @@ tags = st._csc_edge_tags()
 
 def csc(want_value):
     return ops.spmm_minmax_bw_csc(st.rowptr(), st.colptr(), st._row_in_csc_order(), csr2csc, tags, val_d, B, grad,
-                                  arg, want_value=want_value)
+                                  arg, want_value=want_value, csc2csr=st.csc2csr())
 
 
 gv_csc, gm_csc = csc(True)

@@ -64,15 +64,16 @@ out, arg = ops.spmm_max(rowptr, col, val, B)
 ops.spmm_minmax_bw(col, val, B, G, arg)
 print(f"{'C3 spmm_max bwd (float atomics)':34s} {event_ms(lambda: ops.spmm_minmax_bw(col, val, B, G, arg), 5):8.3f} ms")
 tags = st._csc_edge_tags()
-ops.spmm_minmax_bw_csc(rowptr, colptr, row_csc, perm, tags, val, B, G, arg)
-t_csc_bw = event_ms(lambda: ops.spmm_minmax_bw_csc(rowptr, colptr, row_csc, perm, tags, val, B, G, arg), 5)
+inv = st.csc2csr()
+ops.spmm_minmax_bw_csc(rowptr, colptr, row_csc, perm, tags, val, B, G, arg, csc2csr=inv)
+t_csc_bw = event_ms(lambda: ops.spmm_minmax_bw_csc(rowptr, colptr, row_csc, perm, tags, val, B, G, arg, csc2csr=inv), 5)
 print(f"{'C3 spmm_max bwd (one CSC pass)':34s} {t_csc_bw:8.3f} ms  (production: no atomics, reproducible)")
 
 # end-to-end autograd step (fwd + bwd of sum)
 v = val.clone().requires_grad_()
 Bt = B.clone().requires_grad_()
 a2 = SparseTensor(row=row, rowptr=rowptr, col=col, value=v, sparse_sizes=(M, M), is_sorted=True, trust_data=True)
-a2.storage._csr2csc, a2.storage._colptr, a2.storage._row_csc = perm, colptr, row_csc
+a2.storage._csr2csc, a2.storage._colptr, a2.storage._row_csc, a2.storage._csc2csr = perm, colptr, row_csc, inv
 
 
 def fwd_bwd(reduce="sum"):
