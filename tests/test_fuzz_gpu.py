@@ -1,0 +1,141 @@
+"""GPU: seeded random shapes through the public surface against the oracle —
+odd sizes, empty rows/columns, hubs, every K tile class and reduce — to catch
+what the hand-picked cases of the other files do not (kernel selection happens
+inside the package, so this walks whichever kernel a shape lands on)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import storage_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+# PSA_FUZZ=10 runs ten times as many seeds (a soak run; the default keeps the suite short)
+SCALE = int(os.environ.get("PSA_FUZZ", "1"))
+
+
+def idx(x):
+    return torch.as_tensor(np.asarray(x), dtype=torch.int64).cuda()
+
+
+def random_graph(rng):
+    M, N = int(rng.integers(1, 3000)), int(rng.integers(1, 3000))
+    style = rng.integers(0, 3)
+    if style == 0:  # uniform
+        nnz = int(rng.integers(0, 20_000))
+        row, col = rng.integers(0, M, nnz), rng.integers(0, N, nnz)
+    elif style == 1:  # a few hub rows and hub columns
+        nnz = int(rng.integers(1, 30_000))
+        row = np.where(rng.random(nnz) < 0.3, rng.integers(0, min(M, 3), nnz), rng.integers(0, M, nnz))
+        col = np.where(rng.random(nnz) < 0.3, rng.integers(0, min(N, 2), nnz), rng.integers(0, N, nnz))
+    else:  # very sparse: most rows empty
+        nnz = int(rng.integers(0, max(2, M // 4)))
+        row, col = rng.integers(0, M, nnz), rng.integers(0, N, nnz)
+    key = np.unique(row.astype(np.int64) * N + col)  # coalesced, row-major
+    return M, N, key // N, key % N
+
+
+@pytest.mark.parametrize("seed", range(24 * SCALE))
+def test_spmm_forward_backward_random_shapes(seed):
+    from paddle_sparse_amd import SparseTensor
+
+    rng = np.random.default_rng(1000 + seed)
+    M, N, row, col = random_graph(rng)
+    K = int(rng.choice([1, 2, 3, 4, 7, 8, 16, 20, 31, 32, 33, 64, 65, 100, 128, 130, 192, 256, 260, 300]))
+    reduce = ["sum", "mean", "min", "max"][seed % 4]
+    has_value = bool(rng.integers(0, 2))
+    nnz = row.size
+    val = rng.standard_normal(nnz).astype(np.float32) if has_value else None
+    B = rng.standard_normal((N, K)).astype(np.float32)
+    G = rng.standard_normal((M, K)).astype(np.float32)
+    rowptr = oracle.ind2ptr(row, M)
+
+    v = torch.from_numpy(val).cuda().requires_grad_() if has_value else None
+    Bt = torch.from_numpy(B).cuda().requires_grad_()
+    a = SparseTensor(row=idx(row), col=idx(col), value=v, sparse_sizes=(M, N), is_sorted=True)
+    out = a.matmul(Bt, reduce)
+    out.backward(torch.from_numpy(G).cuda())
+
+    ref, arg = oracle.spmm(reduce, rowptr, col, val, B)
+    S = oracle.spmm_abs_sum(rowptr, col, val, B)
+    assert np.all(np.abs(out.detach().cpu().numpy() - ref) <= 1e-5 * S + 1e-30), (M, N, K, reduce)
+    if reduce in ("sum", "mean"):
+        gB = oracle.spmm_mat_bw(reduce, row, rowptr, col, val, G, N)
+        gV = oracle.spmm_value_bw(reduce, row, rowptr, col, B, G)
+    else:
+        gV, gB = oracle.spmm_minmax_bw(col, val, B, G, arg)
+    np.testing.assert_allclose(Bt.grad.cpu().numpy(), gB, rtol=2e-4, atol=2e-4, err_msg=str((M, N, K, reduce)))
+    if has_value:
+        np.testing.assert_allclose(v.grad.cpu().numpy(), gV, rtol=2e-4, atol=2e-4, err_msg=str((M, N, K, reduce)))
+
+
+@pytest.mark.parametrize("seed", range(16 * SCALE))
+def test_coalesce_transpose_reduce_random_shapes(seed):
+    import paddle_sparse_amd as ps
+
+    rng = np.random.default_rng(2000 + seed)
+    M, N = int(rng.integers(1, 4000)), int(rng.integers(1, 4000))
+    nnz = int(rng.integers(0, 40_000))
+    row, col = rng.integers(0, M, nnz), rng.integers(0, N, nnz)
+    if seed % 3 == 0 and nnz:  # heavy duplication
+        row, col = row % 7, col % 5
+    npdtype, tdtype = [(np.float32, torch.float32), (np.int64, torch.int64), (np.float64, torch.float64),
+                       (np.int32, torch.int32)][seed % 4]
+    shape = [(nnz,), (nnz, 3)][seed % 2]
+    val = rng.integers(-9, 10, shape).astype(npdtype)
+    op = ["add", "mean", "min", "max"][seed % 4]
+    index = np.stack([row, col])
+    ref_i, ref_v = so.coalesce(index, val, M, N, op)
+    got_i, got_v = ps.coalesce(idx(index), torch.from_numpy(val).cuda(), M, N, op)
+    assert np.array_equal(got_i.cpu().numpy(), ref_i), (M, N, nnz, op)
+    if npdtype in (np.float32, np.float64) and op == "mean":
+        np.testing.assert_allclose(got_v.cpu().numpy(), ref_v, rtol=1e-6)
+    else:
+        assert np.array_equal(got_v.cpu().numpy(), ref_v), (M, N, nnz, op, npdtype)
+    tr_i, tr_v = so.transpose(index, val, M, N)
+    gt_i, gt_v = ps.transpose(idx(index), torch.from_numpy(val).cuda(), M, N)
+    assert np.array_equal(gt_i.cpu().numpy(), tr_i) and np.array_equal(gt_v.cpu().numpy(), tr_v)
+    # SparseTensor: t(), caches and row/column reductions of the coalesced matrix
+    t = ps.SparseTensor(row=got_i[0].contiguous(), col=got_i[1].contiguous(), value=got_v, sparse_sizes=(M, N),
+                        is_sorted=True)
+    st = so.Storage(ref_i[0], ref_i[1], ref_v, (M, N), is_sorted=True)
+    tt = t.t()
+    ot = so.t(st)
+    r, c, v = tt.coo()
+    assert np.array_equal(r.cpu().numpy(), ot.row) and np.array_equal(c.cpu().numpy(), ot.col)
+    assert np.array_equal(v.cpu().numpy(), ot.value)
+    for name in ("rowptr", "rowcount", "colptr", "colcount", "csr2csc", "csc2csr"):
+        assert np.array_equal(getattr(t.storage, name)().cpu().numpy(), getattr(st, name)()), name
+    if npdtype is not np.int32:
+        for dim in (0, 1):
+            got = getattr(t, "sum" if op in ("add", "mean") else op)(dim).cpu().numpy()
+            assert np.array_equal(got, so.reduction(st, dim, "sum" if op in ("add", "mean") else op)), (dim, op)
+
+
+@pytest.mark.parametrize("seed", range(12 * SCALE))
+def test_sample_adj_and_spspmm_random_shapes(seed):
+    import paddle_sparse_amd as ps
+    from paddle_sparse_amd import ops
+
+    rng = np.random.default_rng(3000 + seed)
+    M, N, row, col = random_graph(rng)
+    rowptr = oracle.ind2ptr(row, M)
+    S = int(rng.integers(0, M + 1))
+    subset = rng.integers(0, M, S)
+    k, replace = [(-1, False), (3, False), (3, True), (17, False)][seed % 4]
+    ref = oracle.sample_adj(rowptr, col, subset, k, replace, seed=seed, num_nodes=max(M, N))
+    got = ops.sample_adj(idx(rowptr), idx(col), idx(subset), k, replace, seed=seed, num_cols=N)
+    for name, g, r in zip(("rowptr", "col", "n_id", "e_id"), got, ref):
+        assert np.array_equal(g.cpu().numpy(), r), (name, M, N, S, k, replace)
+    # A (M x N) times a random (N x P) sparse matrix
+    P = int(rng.integers(1, 2000))
+    keyB = np.unique(rng.integers(0, N * P, int(rng.integers(0, 20_000))))
+    iA, iB = np.stack([row, col]), np.stack([keyB // P, keyB % P])
+    vA = rng.integers(-3, 4, row.size).astype(np.float32)  # small integers: sums are exact in fp32
+    vB = rng.integers(-3, 4, keyB.size).astype(np.float32)
+    ref_i, ref_v = oracle.spspmm(iA, vA, iB, vB, M, N, P)
+    got_i, got_v = ps.spspmm(idx(iA), torch.from_numpy(vA).cuda(), idx(iB), torch.from_numpy(vB).cuda(), M, N, P)
+    assert np.array_equal(got_i.cpu().numpy(), ref_i) and np.array_equal(got_v.cpu().numpy(), ref_v), (M, N, P)
