@@ -9,7 +9,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 import oracle  # noqa: E402  (CPU baseline leg only)
 from oracle import storage_oracle as so  # noqa: E402

@@ -8,7 +8,7 @@ Workloads: C3 (M = N = 2M, nnz = 20M uniform, F = 128) for every row, plus the
 measured HBM yardsticks (device copy and triad) the fractions can be read
 against.  `--cpu-edges` bounds the CPU sample for the sort rows.
 
-    python tools/path_bench.py > gpurun_out/path_bench.txt
+    python tests/perf/path_bench.py > gpurun_out/path_bench.txt
 """
 import argparse
 import os
@@ -34,7 +34,7 @@ os.environ["OMP_NUM_THREADS"] = str(host_threads())
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 import oracle  # noqa: E402  (CPU baseline leg only)
 import paddle_sparse_amd as ps  # noqa: E402

@@ -3,7 +3,7 @@
 restated, single thread like the reference), same graph, same seed: a
 mini-batch (GraphSAGE fan-out) and a whole-graph pass.
 
-    python tools/sample_bench.py --nodes 2000000 --edges 20000000
+    python tests/perf/sample_bench.py --nodes 2000000 --edges 20000000
 """
 import argparse
 import sys
@@ -13,7 +13,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 import oracle  # noqa: E402  (CPU baseline leg only)

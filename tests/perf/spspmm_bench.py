@@ -3,7 +3,7 @@
 products/s, and the row-by-row CPU oracle beside it (single thread, bounded
 by --cpu-rows).
 
-    python tools/spspmm_bench.py --nodes 2000000 --edges 20000000
+    python tests/perf/spspmm_bench.py --nodes 2000000 --edges 20000000
 """
 import argparse
 import sys
@@ -13,7 +13,7 @@ from pathlib import Path
 import numpy as np
 import torch
 
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 import oracle  # noqa: E402  (CPU baseline leg only)
 from paddle_sparse_amd import ops, spspmm  # noqa: E402
