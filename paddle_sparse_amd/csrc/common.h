@@ -29,7 +29,8 @@ inline bool aligned(const void* p, size_t a) {
 // Zero-fill by a kernel of the core (4-byte aligned pointer and size).  Used
 // instead of hipMemsetAsync everywhere: memset NODES of a captured HIP graph
 // replay wrongly from the second launch on with the ROCm runtime torch 2.10
-// ships (tools/graph_debug.py), kernels replay fine.
+// ships (seen as wrong sort results on the second replay; tests/test_graph_capture_gpu.py
+// now holds the replays to the eager results), kernels replay fine.
 int zero_async(void* p, size_t bytes, hipStream_t s);
 
 }  // namespace psa
