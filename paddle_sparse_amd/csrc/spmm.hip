@@ -112,6 +112,7 @@ struct MaskArgs {
   const float* mat = nullptr;        // dense operand of the forward [N, K] (grad_value only)
   const float* mrow = nullptr;       // set by the kernel: mat[c, k0..] of the wave's column
   float* grad_value = nullptr;       // [nnz] in CSC order (position j <-> edge edge_id[j]), or NULL
+  int xcd_rows = 0;                  // row role: give each XCD one contiguous eighth of the rows
 };
 
 // Reduce edges [s, e) of one row into acc/arg: LPR lanes x VEC floats cover the
@@ -558,7 +559,17 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
     return;
   }
   // ---- row role ----
-  const int64_t row = (static_cast<int64_t>(blockIdx.x) - kFusedChunkBlocks) * kWaves + wave;
+  // Workgroups go to the 8 XCDs round-robin (blockIdx % 8), each with its own
+  // L2.  With xcd_rows the row blocks are renumbered so that XCD x owns the
+  // contiguous eighth x of the rows: neighbouring rows of a graph with locality
+  // (communities, banded orderings) then share their B rows through ONE L2
+  // instead of spreading them over eight.  (The grid is a multiple of 8 blocks.)
+  int64_t rb = static_cast<int64_t>(blockIdx.x) - kFusedChunkBlocks;
+  if (mask.xcd_rows) {
+    const int64_t per = (static_cast<int64_t>(gridDim.x) - kFusedChunkBlocks) / 8;
+    rb = (rb % 8) * per + rb / 8;
+  }
+  const int64_t row = rb * kWaves + wave;
   if (row >= M) return;
   const int64_t s = rowptr[row];
   const int64_t e = rowptr[row + 1];
@@ -778,17 +789,19 @@ template <int VEC, int LPR, int U>
 int launch_fused(int red, const int64_t* rowptr, const int64_t* col, const float* val,
                  const float* mat, float* out, int64_t* arg_out, int64_t M, int64_t K,
                  int64_t nnz, int mean, const LongScratch& w, hipStream_t s) {
-  const int64_t gx = psa::ceil_div(M, kWaves) + kFusedChunkBlocks;
+  const int64_t gx = psa::ceil_div(psa::ceil_div(M, kWaves), 8) * 8 + kFusedChunkBlocks;
   PSA_REQUIRE(gx <= 0x7fffffff, "M too large for one launch");
   const dim3 block(kThreads), grid(static_cast<unsigned>(gx));
   hipLaunchKernelGGL(find_long_rows_kernel, dim3(static_cast<unsigned>(psa::ceil_div(M, kThreads))),
                      block, 0, s, rowptr, M, w.ctr, w.list);
   const dim3 cgrid(kLongBlocks), cblock(psa::kLongThreads);
+  MaskArgs plain;
+  plain.xcd_rows = g_variant == 16;
 #define PSA_FUSED(R)                                                                          \
   do {                                                                                        \
     hipLaunchKernelGGL((spmm_fused_kernel<VEC, LPR, R, U>), grid, block, 0, s, rowptr, col,   \
                        val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list, w.part_val,    \
-                       w.part_arg, MaskArgs{});                                               \
+                       w.part_arg, plain);                                                    \
     hipLaunchKernelGGL((spmm_long_combine_kernel<R>), cgrid, cblock, 0, s, rowptr, K, mean,   \
                        w.ctr, w.list, w.part_val, w.part_arg, out, arg_out);                  \
   } while (0)
@@ -1124,7 +1137,7 @@ int psa_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
     // 64 < K <= 256 with a workspace: fused roles (R-MAT scale 21: 2.55 -> 2.34 ms
     // against chunk and row launches back to back; uniform graphs unchanged);
     // variant 15 forces the separate launches
-    if ((g_variant == 0 || g_variant == 14) && w.list && q > 16 && q <= 64) {
+    if ((g_variant == 0 || g_variant == 14 || g_variant == 16) && w.list && q > 16 && q <= 64) {
       if (q <= 32)
         return launch_fused<4, 32, 4>(red, rowptr, col, value, mat, out, arg_out, M, K, nnz, mean, w, s);
       return launch_fused<4, 64, 8>(red, rowptr, col, value, mat, out, arg_out, M, K, nnz, mean, w, s);
