@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Workload for --pmc passes on the backward kernels at config-3 size: three
+calls each of the one-pass CSC sum backward, the one-pass CSC max backward and
+spmm_value_bw."""
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from bench import make_workload  # noqa: E402
+from paddle_sparse_amd import SparseStorage, ops  # noqa: E402
+
+dev = torch.device("cuda", 0)
+M = N = 2_000_000
+F = 128
+rowptr, col, val = make_workload(M, N, 20_000_000, F, 2, dev)
+g = torch.Generator(device=dev).manual_seed(1)
+B = torch.randn(N, F, generator=g, device=dev)
+G = torch.randn(M, F, generator=g, device=dev)
+st = SparseStorage(rowptr=rowptr, col=col, value=val, sparse_sizes=(M, N), is_sorted=True, trust_data=True)
+csr2csc, colptr, row_csc, inv, tags = st.csr2csc(), st.colptr(), st._row_in_csc_order(), st.csc2csr(), st._csc_edge_tags()
+out, arg = ops.spmm_max(rowptr, col, val, B)
+torch.cuda.synchronize()
+for _ in range(3):
+    ops.spmm_sum_bw_csc(colptr, row_csc, csr2csc, val, B, G, True, csc2csr=inv)
+    ops.spmm_minmax_bw_csc(rowptr, colptr, row_csc, csr2csc, tags, val, B, G, arg, csc2csr=inv)
+    ops.spmm_value_bw(None, rowptr, col, B, G, "sum")
+torch.cuda.synchronize()
+print("done")
