@@ -241,6 +241,23 @@ int psa_sort_pairs_u32(const int64_t* keys, const void* payload, int64_t n,
                        int64_t max_value, int64_t* sorted_out, void* payload_out,
                        void* workspace, size_t workspace_bytes, psa_stream_t stream);
 
+/* Small inputs (n <= psa_coalesce_small_max(), 40960): the sort by (row, col)
+ * AND the run-length structure of a coalesce (storage.py:158-171 + 455-470) in
+ * one launch of one workgroup — at BASELINE config 1 (10 k entries) the
+ * multi-launch chain is pure launch latency.  Outputs are sized for the worst
+ * case: out_row / out_col / perm int64[n], ptr int64[n + 1]; on return
+ * count_out[0] (device) = number of distinct (row, col), out_row/out_col[0:count]
+ * the sorted distinct pairs, ptr[0:count + 1] the run starts in sorted order,
+ * perm the stable sorting permutation (same bits as psa_index_sort).
+ * workspace: psa_coalesce_small_workspace_bytes(n) bytes, 16-byte aligned. */
+int64_t psa_coalesce_small_max(void);
+size_t psa_coalesce_small_workspace_bytes(int64_t n);
+int psa_coalesce_small(const int64_t* row, const int64_t* col, int64_t n,
+                       int64_t M, int64_t N, int64_t* out_row, int64_t* out_col,
+                       int64_t* ptr, int64_t* perm, int64_t* count_out,
+                       void* workspace, size_t workspace_bytes,
+                       psa_stream_t stream);
+
 /* Test/bench hook: scatter kernel variant of psa_index_sort for this process
  * (0 = production: single-sweep passes with decoupled look-back, 512 threads x
  * 16 keys; 5 = the same with 1024 x 8; 1-4, 7 = histogram / scan / scatter

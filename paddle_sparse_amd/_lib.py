@@ -56,6 +56,10 @@ SIGNATURES = {
     "psa_sort_pairs_u32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
                                    c_void_p, c_size_t, c_void_p]),
     "psa_sort_set_variant": (c_int, [c_int]),
+    "psa_coalesce_small_max": (c_int64, []),
+    "psa_coalesce_small_workspace_bytes": (c_size_t, [c_int64]),
+    "psa_coalesce_small": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "psa_make_keys": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p,
                               c_void_p, c_void_p]),
     "psa_split_keys": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),

@@ -20,12 +20,19 @@ from . import ops
 
 
 _ALWAYS_SORT_BELOW = 1 << 18
+_ONE_WORKGROUP_BELOW = 1 << 14  # entries; ops.coalesce_small takes up to 40960
 
 
 def _coalesce_sorted_stream(row, col, value, m: int, n: int, op: str):
     nnz = col.numel()
     if nnz == 0:
         return row, col, value
+    if nnz <= _ONE_WORKGROUP_BELOW and m * n < (1 << 62) and m > 0 and n > 0:
+        # one launch for sort + run lengths, one for the values
+        count, ptr, new_row, new_col, perm = ops.coalesce_small(row, col, m, n)
+        if value is not None:
+            value = ops.segment_csr(value, ptr, op, perm=perm) if count < nnz else ops.gather_rows(value, perm)
+        return new_row, new_col, value
     # Small inputs are launch- and sync-bound (10k edges: ~150 us, of which each
     # host read is ~15): asking the device whether the keys are sorted already
     # costs more than sorting them, so below this size the question is skipped.

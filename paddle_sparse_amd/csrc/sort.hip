@@ -805,9 +805,239 @@ void launch_scatter(int variant, dim3 grid, hipStream_t s, const uint64_t* kin,
 #undef PSA_SCATTER
 }
 
+// ===========================================================================
+// Small inputs: the whole "sort by (row, col) + run-length structure" of a
+// coalesce in ONE launch of ONE workgroup.
+//
+// At 10 k entries (BASELINE config 1) the multi-launch chain is pure latency:
+// a dozen launches of ~5-10 us each (histogram, scan, three passes, run
+// counts, block scan, write, ...) plus host reads, 135 us in all — slower than
+// a tight single-threaded CPU loop (85-100 us).  One workgroup of 1024 threads
+// does every step here with barriers instead of launches: keys are formed on
+// the fly in pass 0, each radix pass is {digit histogram, 256-bin scan, stable
+// ranks by wave-wide digit matching, scatter} over global ping-pong buffers
+// (L2-resident at this size; __syncthreads orders the block's global writes
+// and reads), and the last stage turns the sorted keys into (row, col), run
+// starts and the run count.  Same stable permutation, bit for bit.
+// ===========================================================================
+constexpr int kSmallThreads = 1024;
+constexpr int kSmallItems = 10;
+constexpr int kSmallTile = kSmallThreads * kSmallItems;  // 10240 keys per tile step
+
+__global__ void __launch_bounds__(kSmallThreads)
+small_sort_unique_kernel(const int64_t* __restrict__ row, const int64_t* __restrict__ col,
+                         int64_t mul, int64_t n, int passes,
+                         uint64_t* kbuf0, uint64_t* kbuf1, uint32_t* ibuf0, uint32_t* ibuf1,
+                         int64_t* __restrict__ out_row, int64_t* __restrict__ out_col,
+                         int64_t* __restrict__ ptr, int64_t* __restrict__ perm,
+                         int64_t* __restrict__ count_out) {
+  // Every global access below is one of kSmallItems unrolled, independent loads
+  // or stores per thread: a single workgroup has no other way to hide the
+  // ~1 us memory latency (a first version with `for (i = tid; i < n; i +=
+  // 1024)` loops spent 100 us on 10 k keys, one round trip per iteration).
+  constexpr int WAVES = kSmallThreads / 64;
+  constexpr int ITEMS = kSmallItems;
+  __shared__ uint32_t wcnt[2][WAVES][kRadix];
+  __shared__ uint32_t gbase[kRadix];
+  __shared__ uint32_t wtot[WAVES];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wbase = wave * (ITEMS * 64);  // item i of lane l: tile element wbase + i*64 + l
+  const bool single = n <= kSmallTile;
+
+  const uint64_t* kin = kbuf0;  // pass 0 reads (row, col) instead
+  const uint32_t* iin = ibuf0;
+  uint64_t key[ITEMS];
+  uint32_t idx[ITEMS];
+  auto load_tile = [&](int p, int64_t tile_begin, int tile_n) {
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int q = wbase + i * 64 + lane;
+      const bool valid = q < tile_n;
+      if (p == 0) {
+        key[i] = valid ? static_cast<uint64_t>(row[tile_begin + q] * mul + col[tile_begin + q]) : ~0ull;
+        idx[i] = static_cast<uint32_t>(tile_begin + q);
+      } else {
+        key[i] = valid ? kin[tile_begin + q] : ~0ull;
+        idx[i] = valid ? iin[tile_begin + q] : 0u;
+      }
+    }
+  };
+
+  for (int p = 0; p < passes; ++p) {
+    const int shift = 8 * p;
+    uint64_t* ko = (p & 1) ? kbuf1 : kbuf0;
+    uint32_t* io = (p & 1) ? ibuf1 : ibuf0;
+    if (tid < kRadix) gbase[tid] = 0;
+    for (int i = tid; i < 2 * WAVES * kRadix; i += kSmallThreads) (&wcnt[0][0][0])[i] = 0;
+    __syncthreads();
+    // ---- digit histogram of the whole array -> exclusive bases --------------
+    for (int64_t tile_begin = 0; tile_begin < n; tile_begin += kSmallTile) {
+      const int64_t rem = n - tile_begin;
+      const int tile_n = rem < kSmallTile ? static_cast<int>(rem) : kSmallTile;
+      load_tile(p, tile_begin, tile_n);
+#pragma unroll
+      for (int i = 0; i < ITEMS; ++i)
+        if (wbase + i * 64 + lane < tile_n) atomicAdd(&gbase[digit_of(key[i], shift)], 1u);
+    }
+    __syncthreads();
+    if (tid < kRadix) {  // 256-bin exclusive scan: 4 waves, shuffle scan + wave totals
+      const uint32_t c = gbase[tid];
+      uint32_t incl = c;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+      }
+      if (lane == 63) wtot[wave] = incl;
+      gbase[tid] = incl - c;  // exclusive inside the wave; wave offset added below
+    }
+    __syncthreads();
+    if (tid < kRadix) {
+      uint32_t add = 0;
+      for (int w = 0; w < wave; ++w) add += wtot[w];
+      gbase[tid] += add;
+    }
+    __syncthreads();
+    // ---- stable scatter, tile by tile (as radix_scatter_direct_kernel) ---------
+    int buf = 0;
+    for (int64_t tile_begin = 0; tile_begin < n; tile_begin += kSmallTile, buf ^= 1) {
+      const int64_t rem = n - tile_begin;
+      const int tile_n = rem < kSmallTile ? static_cast<int>(rem) : kSmallTile;
+      if (!single) load_tile(p, tile_begin, tile_n);  // a single tile is still in registers
+      uint32_t rank[ITEMS];
+      uint32_t* mine = wcnt[buf][wave];
+#pragma unroll
+      for (int i = 0; i < ITEMS; ++i) {
+        const bool valid = wbase + i * 64 + lane < tile_n;
+        const unsigned d = digit_of(key[i], shift);
+        rank[i] = wave_rank(mine, d, valid, wave_match(d, valid));
+      }
+      __syncthreads();
+      if (tid < kRadix) {
+        uint32_t run = gbase[tid];
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+          const uint32_t c = wcnt[buf][w][tid];
+          wcnt[buf][w][tid] = run;
+          run += c;
+          wcnt[buf ^ 1][w][tid] = 0;
+        }
+        gbase[tid] = run;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < ITEMS; ++i) {
+        if (wbase + i * 64 + lane < tile_n) {
+          const uint32_t dst = mine[digit_of(key[i], shift)] + rank[i];
+          ko[dst] = key[i];
+          io[dst] = idx[i];
+        }
+      }
+    }
+    __syncthreads();  // this pass's writes are visible to the whole block
+    kin = ko;
+    iin = io;
+  }
+  // ---- run-length structure of the sorted keys, in the same striped order -----
+  uint32_t heads_before = 0;  // distinct keys in earlier tiles
+  for (int64_t tile_begin = 0; tile_begin < n; tile_begin += kSmallTile) {
+    const int64_t rem = n - tile_begin;
+    const int tile_n = rem < kSmallTile ? static_cast<int>(rem) : kSmallTile;
+    uint64_t prev[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int q = wbase + i * 64 + lane;
+      const bool valid = q < tile_n;
+      const int64_t g = tile_begin + q;
+      key[i] = valid ? kin[g] : 0ull;
+      idx[i] = valid ? iin[g] : 0u;
+      prev[i] = (valid && g > 0) ? kin[g - 1] : ~0ull;
+    }
+    // position of every head inside its wave: ballots, item after item
+    uint32_t pos[ITEMS];
+    uint32_t wave_heads = 0;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int q = wbase + i * 64 + lane;
+      const bool head = q < tile_n && (tile_begin + q == 0 || key[i] != prev[i]);
+      const unsigned long long m = __ballot(head);
+      const uint32_t below = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32),
+                                                       __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+      pos[i] = head ? wave_heads + below : 0xffffffffu;
+      wave_heads += static_cast<uint32_t>(__popcll(m));
+    }
+    __syncthreads();  // wtot is free again
+    if (lane == 0) wtot[wave] = wave_heads;
+    __syncthreads();
+    uint32_t before = heads_before, total = 0;
+    for (int w = 0; w < WAVES; ++w) {
+      if (w < wave) before += wtot[w];
+      total += wtot[w];
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      const int q = wbase + i * 64 + lane;
+      if (q < tile_n) {
+        const int64_t g = tile_begin + q;
+        perm[g] = static_cast<int64_t>(idx[i]);
+        if (pos[i] != 0xffffffffu) {
+          const int64_t o = before + pos[i];
+          const int64_t r = static_cast<int64_t>(key[i]) / mul;
+          out_row[o] = r;
+          out_col[o] = static_cast<int64_t>(key[i]) - r * mul;
+          ptr[o] = g;
+        }
+      }
+    }
+    heads_before += total;
+  }
+  if (tid == 0) {
+    ptr[heads_before] = n;
+    *count_out = heads_before;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t psa_coalesce_small_workspace_bytes(int64_t n) {
+  if (n <= 0) return 256;
+  return 2 * align_up(sizeof(uint64_t) * static_cast<size_t>(n), 256) +
+         2 * align_up(sizeof(uint32_t) * static_cast<size_t>(n), 256);
+}
+
+int64_t psa_coalesce_small_max(void) { return 4 * kSmallTile; }
+
+int psa_coalesce_small(const int64_t* row, const int64_t* col, int64_t n, int64_t M, int64_t N,
+                       int64_t* out_row, int64_t* out_col, int64_t* ptr, int64_t* perm,
+                       int64_t* count_out, void* workspace, size_t workspace_bytes,
+                       psa_stream_t stream) {
+  PSA_REQUIRE(n > 0 && n <= psa_coalesce_small_max(), "n out of range for the one-workgroup path");
+  PSA_REQUIRE(M > 0 && N > 0, "empty matrix");
+  PSA_REQUIRE(row && col && out_row && out_col && ptr && perm && count_out, "NULL pointer");
+  if (workspace == nullptr || workspace_bytes < psa_coalesce_small_workspace_bytes(n)) {
+    psa::set_error("psa_coalesce_small: workspace too small");
+    return PSA_ERR_WORKSPACE;
+  }
+  PSA_REQUIRE(psa::aligned(workspace, 16), "workspace must be 16-byte aligned");
+  int passes = (bits_for(M * N) + 7) / 8;
+  if (passes < 1) passes = 1;
+  char* p = static_cast<char*>(workspace);
+  const size_t kb = align_up(sizeof(uint64_t) * static_cast<size_t>(n), 256);
+  const size_t ib = align_up(sizeof(uint32_t) * static_cast<size_t>(n), 256);
+  uint64_t* k0 = reinterpret_cast<uint64_t*>(p);
+  uint64_t* k1 = reinterpret_cast<uint64_t*>(p + kb);
+  uint32_t* i0 = reinterpret_cast<uint32_t*>(p + 2 * kb);
+  uint32_t* i1 = reinterpret_cast<uint32_t*>(p + 2 * kb + ib);
+  hipLaunchKernelGGL(small_sort_unique_kernel, dim3(1), dim3(kSmallThreads), 0,
+                     psa::as_stream(stream), row, col, N, n, passes, k0, k1, i0, i1, out_row,
+                     out_col, ptr, perm, count_out);
+  PSA_LAUNCH_CHECK();
+  return PSA_OK;
+}
 
 int psa_sort_set_variant(int variant) {
   const int prev = g_sort_variant;

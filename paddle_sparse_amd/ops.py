@@ -209,6 +209,32 @@ def sort_pairs(keys: torch.Tensor, payload: torch.Tensor, max_value: Optional[in
     return out_keys, out_pay
 
 
+def coalesce_small_max() -> int:
+    return int(_lib.load().psa_coalesce_small_max())
+
+
+def coalesce_small(row: torch.Tensor, col: torch.Tensor, m: int, n: int):
+    """Sort by (row, col) + run-length structure in ONE launch of one workgroup
+    (inputs of at most coalesce_small_max() entries; see the header).  Returns
+    (count, ptr int64[count + 1], row' int64[count], col' int64[count], perm
+    int64[nnz]) like index_sort + unique_sorted.  One host read (count)."""
+    row, col = _index(row, "row"), _index(col, "col")
+    nnz = row.numel()
+    dev = row.device
+    out = torch.empty((2, nnz), dtype=torch.int64, device=dev)
+    ptr = torch.empty(nnz + 1, dtype=torch.int64, device=dev)
+    perm = torch.empty(nnz, dtype=torch.int64, device=dev)
+    count = torch.empty(1, dtype=torch.int64, device=dev)
+    lib = _lib.load()
+    ws = _workspace(lib.psa_coalesce_small_workspace_bytes(nnz), dev)
+    with torch.cuda.device(dev):
+        check(lib.psa_coalesce_small(_ptr(row), _ptr(col), nnz, int(m), int(n), out[0].data_ptr(),
+                                     out[1].data_ptr(), _ptr(ptr), _ptr(perm), _ptr(count), _ptr(ws),
+                                     ws.numel(), _stream()))
+    c = int(count.item())
+    return c, ptr[:c + 1], out[0, :c], out[1, :c], perm
+
+
 def make_keys(a: torch.Tensor, b: torch.Tensor, mul: int, check_sorted: bool = False
               ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """keys = a * mul + b  (+ device flag "some key is smaller than its
