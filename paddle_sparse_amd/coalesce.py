@@ -20,7 +20,8 @@ from . import ops
 
 
 _ALWAYS_SORT_BELOW = 1 << 18
-_ONE_WORKGROUP_BELOW = 1 << 14  # entries; ops.coalesce_small takes up to 40960
+_ONE_WORKGROUP_BELOW = 10_240  # entries = one tile step of the one-workgroup kernel (it takes up to 40960,
+# but from its second tile step on the multi-launch chain is faster: 174 vs 145 us at 16384, tools/coalesce_sizes.py)
 
 
 def _coalesce_sorted_stream(row, col, value, m: int, n: int, op: str):

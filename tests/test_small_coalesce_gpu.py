@@ -62,7 +62,7 @@ def test_small_path_sorted_constant_and_limits():
 @pytest.mark.parametrize("op", ["add", "mean", "min", "max"])
 @pytest.mark.parametrize("shape_tail,npdtype", [((), np.float32), ((2,), np.float32), ((), np.int64), ((3,), np.float64)])
 def test_coalesce_takes_the_small_path_with_the_same_results(op, shape_tail, npdtype):
-    """Below 16384 entries coalesce() routes through the one-workgroup kernel;
+    """Up to 10240 entries coalesce() routes through the one-workgroup kernel;
     results equal the numpy oracle (integers and min/max bit for bit)."""
     import paddle_sparse_amd as ps
 
