@@ -25,7 +25,7 @@ tests/test_distributed.py covers it at world_size 2).
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Callable, List, Optional, Tuple
+from typing import Callable, List, Optional
 
 import torch
 import torch.distributed as dist

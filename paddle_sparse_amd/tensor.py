@@ -10,7 +10,7 @@ matmul.py — the reference monkey-patches its methods the same way.
 from __future__ import annotations
 
 from textwrap import indent
-from typing import Any, List, Optional, Tuple, Union
+from typing import List, Optional, Tuple, Union
 
 import numpy as np
 import scipy.sparse
