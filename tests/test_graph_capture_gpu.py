@@ -49,3 +49,44 @@ def test_spmm_and_sort_replay_from_a_hip_graph():
         assert torch.equal(gv, ops.spmm_value_bw(None, rowptr, col, B, G))
         ts, tp = torch.sort(keys, stable=True)
         assert torch.equal(srt, ts) and torch.equal(perm, tp)
+
+
+def test_backward_passes_over_the_csc_view_replay_from_a_hip_graph():
+    """The one-pass backward kernels (sum and max, both gradients) take their
+    scratch from the caller and read no device value on the host, so a whole
+    forward + backward step of a fixed graph replays from a HIP graph."""
+    from paddle_sparse_amd import SparseStorage, ops
+
+    g = torch.Generator(device="cuda").manual_seed(1)
+    M, nnz, K = 30_000, 300_000, 64
+    key = torch.unique(torch.randint(0, M * M, (nnz,), generator=g, device="cuda"))
+    row, col = torch.div(key, M, rounding_mode="floor"), key % M
+    val = torch.randn(row.numel(), generator=g, device="cuda")
+    st = SparseStorage(row=row, col=col, value=val, sparse_sizes=(M, M), is_sorted=True, trust_data=True)
+    rowptr, csr2csc, colptr = st.rowptr(), st.csr2csc(), st.colptr()
+    row_csc, inv, tags = st._row_in_csc_order(), st.csc2csr(), st._csc_edge_tags()
+    B = torch.randn(M, K, generator=g, device="cuda")
+    G = torch.randn(M, K, generator=g, device="cuda")
+
+    def step():
+        out = ops.spmm_sum(rowptr, col, val, B)
+        gv, gm = ops.spmm_sum_bw_csc(colptr, row_csc, csr2csc, val, B, G, True, csc2csr=inv)
+        out_max, arg = ops.spmm_max(rowptr, col, val, B)
+        gv2, gm2 = ops.spmm_minmax_bw_csc(rowptr, colptr, row_csc, csr2csc, tags, val, B, G, arg, csc2csr=inv)
+        return out, gv, gm, out_max, gv2, gm2
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = step()
+    for trial in range(3):
+        B.copy_(torch.randn(M, K, generator=g, device="cuda"))
+        G.copy_(torch.randn(M, K, generator=g, device="cuda"))
+        graph.replay()
+        torch.cuda.synchronize()
+        for got, want in zip(captured, step()):
+            assert torch.equal(got, want)
