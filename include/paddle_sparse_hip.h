@@ -191,7 +191,9 @@ int psa_spmm_minmax_bw_csc(const int64_t* rowptr, const int64_t* colptr,
  * The gathered grad row serves both, mat[c, :] is the column's own row, and
  * value is read through csr2csc — so the separate psa_spmm_value_bw (a second
  * full gather, of mat rows) and psa_transpose_weights passes are not needed.
- * For mean, hand in grad already divided by max(deg(row), 1).
+ * row_scale: f32[M] or NULL; with it both gradients carry the factor
+ * row_scale[r] (mean: 1 / max(deg(r), 1), folded in per edge instead of a
+ * pre-scaling pass over grad).
  * grad_value_csc: f32[nnz] in CSC order or NULL (CSR order: psa_gather_rows
  * through csc2csr, as above).  workspace:
  * psa_spmm_sum_bw_csc_workspace_bytes(K, nnz) bytes, 16-byte aligned.
@@ -199,7 +201,8 @@ int psa_spmm_minmax_bw_csc(const int64_t* rowptr, const int64_t* colptr,
 size_t psa_spmm_sum_bw_csc_workspace_bytes(int64_t K, int64_t nnz);
 int psa_spmm_sum_bw_csc(const int64_t* colptr, const int64_t* row_csc,
                         const int64_t* csr2csc, const float* value,
-                        const float* mat, const float* grad, int64_t N,
+                        const float* row_scale, const float* mat,
+                        const float* grad, int64_t N,
                         int64_t K, int64_t nnz, float* grad_value_csc,
                         float* grad_mat, void* workspace,
                         size_t workspace_bytes, psa_stream_t stream);

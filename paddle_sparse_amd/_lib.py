@@ -46,7 +46,7 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                        c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "psa_spmm_sum_bw_csc_workspace_bytes": (c_size_t, [c_int64, c_int64]),
-    "psa_spmm_sum_bw_csc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+    "psa_spmm_sum_bw_csc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                     c_size_t, c_void_p]),
     "psa_index_sort_workspace_bytes": (c_size_t, [c_int64, c_int64]),

@@ -112,6 +112,7 @@ struct MaskArgs {
   const float* mat = nullptr;        // dense operand of the forward [N, K] (grad_value only)
   const float* mrow = nullptr;       // set by the kernel: mat[c, k0..] of the wave's column
   float* grad_value = nullptr;       // [nnz] in CSC order (position j <-> edge edge_id[j]), or NULL
+  const float* row_scale = nullptr;  // M_CSC, mean: 1 / max(deg(r), 1) per CSR row, folded into both gradients
   int xcd_rows = 0;                  // row role: give each XCD one contiguous eighth of the rows
 };
 
@@ -145,11 +146,16 @@ __device__ __forceinline__ void reduce_edge_range(
     int64_t c_l = 0;
     float v_l = 0.f;
     int64_t id_l = 0;  // MASK: CSR edge id; its tag rides in the top byte
+    float s_l = 1.f;   // M_CSC with row_scale: 1 / deg of this edge's CSR row
     if (lane < n) {
       c_l = col[base + lane];
       if (INDIRECT) {
         id_l = m.edge_id[base + lane];
         v_l = val ? val[id_l] : 1.f;
+        if (MODE == M_CSC && m.row_scale) {
+          s_l = m.row_scale[c_l];
+          v_l *= s_l;
+        }
         if (MASK) id_l |= static_cast<int64_t>(m.tag[base + lane]) << 56;
       } else {
         v_l = val ? val[base + lane] : 1.f;
@@ -223,7 +229,8 @@ __device__ __forceinline__ void reduce_edge_range(
           // straight to the CSR position, a 4-byte scatter, cost 0.8 ms more at
           // 20 M edges than this store plus the caller's gather through csc2csr.)
           const int slot = j + (l % U) * G + g;  // < 64
-          if (l < U && slot < n) m.grad_value[base + slot] = dot[0];
+          const float scale = MODE == M_CSC ? __shfl(s_l, slot) : 1.f;
+          if (l < U && slot < n) m.grad_value[base + slot] = dot[0] * scale;
         }
       }
 #pragma unroll
@@ -1029,9 +1036,10 @@ size_t psa_spmm_sum_bw_csc_workspace_bytes(int64_t K, int64_t nnz) {
 }
 
 int psa_spmm_sum_bw_csc(const int64_t* colptr, const int64_t* row_csc, const int64_t* csr2csc,
-                        const float* value, const float* mat, const float* grad, int64_t N,
-                        int64_t K, int64_t nnz, float* grad_value, float* grad_mat,
-                        void* workspace, size_t workspace_bytes, psa_stream_t stream) {
+                        const float* value, const float* row_scale, const float* mat,
+                        const float* grad, int64_t N, int64_t K, int64_t nnz,
+                        float* grad_value, float* grad_mat, void* workspace,
+                        size_t workspace_bytes, psa_stream_t stream) {
   PSA_REQUIRE(N >= 0 && K >= 0 && nnz >= 0, "negative size");
   if (N == 0 || K == 0) return PSA_OK;
   if (K % 4 != 0 || K > 256 || !psa::aligned(grad, 16) || !psa::aligned(grad_mat, 16) ||
@@ -1054,6 +1062,7 @@ int psa_spmm_sum_bw_csc(const int64_t* colptr, const int64_t* row_csc, const int
   PSA_ZERO(w.ctr, 8, s);
   MaskArgs mask;
   mask.edge_id = csr2csc;
+  mask.row_scale = row_scale;
   if (grad_value != nullptr && nnz > 0) {
     mask.mat = mat;
     mask.grad_value = grad_value;

@@ -80,11 +80,11 @@ class _SpMM(torch.autograd.Function):
                 # the column's own mat row, grad_value (instead of a second full
                 # gather of mat rows in spmm_value_bw plus the weight gather).
                 csr2csc = st.csr2csc()
-                g = grad_out
-                if mean:  # 1/deg(row) folded into grad_out serves both gradients
-                    g = grad_out / st.rowcount().clamp(min=1).to(grad_out.dtype).view(-1, 1)
+                # mean: 1/deg(row) multiplies both gradients, per edge, inside the pass
+                scale = (1.0 / st.rowcount().clamp(min=1).to(torch.float32)) if mean else None
                 grad_value, grad_mat = ops.spmm_sum_bw_csc(st.colptr(), st._row_in_csc_order(), csr2csc,
-                                                           value, mat, g, True, csc2csr=st.csc2csr())
+                                                           value, mat, grad_out, True, csc2csr=st.csc2csr(),
+                                                           row_scale=scale)
                 return grad_value, grad_mat, None, None
             if need_value:
                 grad_value = ops.spmm_value_bw(None, st.rowptr(), st.col(), mat, grad_out,

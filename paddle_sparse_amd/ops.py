@@ -464,15 +464,20 @@ def spmm_minmax_bw_csc(rowptr, colptr, row_csc, csr2csc, tag, value, mat, grad, 
 
 
 def spmm_sum_bw_csc(colptr, row_csc, csr2csc, value, mat, grad, want_value: bool = True,
-                    csc2csr: Optional[torch.Tensor] = None):
+                    csc2csr: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None):
     """sum backward, both gradients in one pass over the CSC view (see
     include/paddle_sparse_hip.h).  Returns (grad_value f32[nnz] | None, in CSR
-    order, grad_mat f32[N, K]).  For mean, pass grad / max(deg, 1)."""
+    order, grad_mat f32[N, K]).  For mean, pass row_scale = 1 / max(deg, 1)
+    (f32[M]): it multiplies both gradients per edge."""
     colptr, row_csc, csr2csc = _index(colptr, "colptr"), _index(row_csc, "row_csc"), _index(csr2csc, "csr2csc")
     grad = _f32(grad, "grad")
     if value is not None:
         value = _f32(value, "value")
     K, N, nnz = grad.shape[1], colptr.numel() - 1, csr2csc.numel()
+    if row_scale is not None:
+        row_scale = _f32(row_scale, "row_scale")
+        if row_scale.shape != (grad.shape[0],):
+            raise ValueError("row_scale must be f32[M]")
     gv = None
     if want_value:
         mat = _f32(mat, "mat")
@@ -484,7 +489,7 @@ def spmm_sum_bw_csc(colptr, row_csc, csr2csc, value, mat, grad, want_value: bool
     ws = _workspace(lib.psa_spmm_sum_bw_csc_workspace_bytes(K, nnz), grad.device)
     with torch.cuda.device(grad.device):
         check(lib.psa_spmm_sum_bw_csc(_ptr(colptr), _ptr(row_csc), _ptr(csr2csc), _ptr(value),
-                                      _ptr(mat) if want_value else None, _ptr(grad), N, K, nnz,
+                                      _ptr(row_scale), _ptr(mat) if want_value else None, _ptr(grad), N, K, nnz,
                                       _ptr(gv), _ptr(gm), _ptr(ws), ws.numel(), _stream()))
     if gv is not None:
         gv = gather_rows(gv, csc2csr if csc2csr is not None else invert_permutation(csr2csc))

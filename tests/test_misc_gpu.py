@@ -203,6 +203,14 @@ def test_sum_bw_one_csc_pass(has_value, K, graph):
     assert np.all(np.abs(gm.cpu().numpy() - ref_m) <= 1e-5 * scale_m + 1e-30)
     scale_v = (np.abs(B[col]) * np.abs(G[row])).sum(1)
     assert np.all(np.abs(gv.cpu().numpy() - ref_v) <= 1e-5 * scale_v + 1e-30)
+    # mean: 1 / deg(row) folded into both gradients per edge
+    deg = np.maximum(rowptr[1:] - rowptr[:-1], 1).astype(np.float32)
+    gv_mean, gm_mean = ops.spmm_sum_bw_csc(st.colptr(), st._row_in_csc_order(), csr2csc, st.value(), dev(B), dev(G),
+                                           True, csc2csr=st.csc2csr(), row_scale=dev(1.0 / deg))
+    ref_mm = oracle.spmm_mat_bw("mean", row, rowptr, col, val, G, N)
+    ref_mv = oracle.spmm_value_bw("mean", row, rowptr, col, B, G)
+    np.testing.assert_allclose(gm_mean.cpu().numpy(), ref_mm, rtol=1e-4, atol=1e-5 * float(scale_m.max() + 1))
+    np.testing.assert_allclose(gv_mean.cpu().numpy(), ref_mv, rtol=1e-4, atol=1e-5 * float(scale_v.max() + 1))
     # without the inverse permutation handed in, the op builds it itself; grad_mat alone skips the dots
     gv2, gm2 = ops.spmm_sum_bw_csc(st.colptr(), st._row_in_csc_order(), csr2csc, st.value(), dev(B), dev(G), True)
     none, gm3 = ops.spmm_sum_bw_csc(st.colptr(), st._row_in_csc_order(), csr2csc, st.value(), None, dev(G), False)
