@@ -106,6 +106,12 @@ int psa_ptr2ind(const int64_t* ptr, int64_t M, int64_t E, int64_t* out,
  * for MIN/MAX, ignored otherwise; may be NULL for SUM/MEAN).
  * nnz is passed explicitly because rowptr lives on the device.
  *
+ * arg_bytes: uint8[M,K] or NULL (MIN/MAX only, needs K % 4 == 0): arg_out once
+ * more as the winner's index INSIDE its row, one byte per element (255 for
+ * rows of more than 255 edges) — the form psa_spmm_minmax_bw_csc reads.  The
+ * forward has it in registers, so writing it here (0.26 GB at M = 2 M, K = 128)
+ * saves the backward a pass that re-reads all of arg_out (2 GB).
+ *
  * workspace (psa_spmm_workspace_bytes(reduce, K, nnz) bytes, 16-byte aligned)
  * enables the long-row path: rows with more than 128 edges are split into
  * 128-edge chunks reduced by separate wavefronts and folded in chunk order
@@ -115,7 +121,8 @@ size_t psa_spmm_workspace_bytes(int reduce, int64_t K, int64_t nnz);
 int psa_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
              const float* value, const float* mat, int64_t M, int64_t N,
              int64_t K, int64_t nnz, float* out, int64_t* arg_out,
-             void* workspace, size_t workspace_bytes, psa_stream_t stream);
+             uint8_t* arg_bytes, void* workspace, size_t workspace_bytes,
+             psa_stream_t stream);
 
 /* ---- SpMM backward (fp32) ------------------------------------------------ */
 
@@ -163,6 +170,8 @@ int psa_spmm_minmax_bw(const int64_t* col, const float* value, const float* mat,
  *
  * tag: uint8[nnz] from psa_csc_edge_tags (depends on the sparsity structure
  * only: cache it with csr2csc).  value: f32[nnz] in CSR order, or NULL.
+ * arg_bytes: what psa_spmm left behind (see there), or NULL — the call then
+ * derives it from arg_out itself in a first pass.
  * grad_value_csc: f32[nnz] or NULL (then mat may be NULL too); it is written in
  * CSC order, contiguously — psa_gather_rows(grad_value_csc, csc2csr, nnz, 4, ..)
  * puts it into the CSR order the API returns (a 4-byte scatter from inside the
@@ -179,7 +188,8 @@ int psa_spmm_minmax_bw_csc(const int64_t* rowptr, const int64_t* colptr,
                            const int64_t* row_csc, const int64_t* csr2csc,
                            const uint8_t* tag, const float* value,
                            const float* mat, const float* grad,
-                           const int64_t* arg_out, int64_t M, int64_t N,
+                           const int64_t* arg_out, const uint8_t* arg_bytes,
+                           int64_t M, int64_t N,
                            int64_t K, int64_t nnz, float* grad_value_csc,
                            float* grad_mat, void* workspace,
                            size_t workspace_bytes, psa_stream_t stream);

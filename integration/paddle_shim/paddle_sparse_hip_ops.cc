@@ -119,7 +119,8 @@ static std::vector<paddle::Tensor> spmm_impl(int reduce, paddle::Tensor& rowptr,
   auto ws = paddle::empty({ws_bytes > 0 ? ws_bytes : 1}, paddle::DataType::UINT8, mat.place());
   PSA_CALL(psa_spmm(reduce, i64(rowptr), i64(col), value ? f32(value.get()) : nullptr, f32(mat), M, N,
                     K, nnz, out.data<float>(), minmax ? arg.data<int64_t>() : nullptr,
-                    ws_bytes > 0 ? ws.data<uint8_t>() : nullptr, static_cast<size_t>(ws_bytes),
+                    /*arg_bytes=*/nullptr, ws_bytes > 0 ? ws.data<uint8_t>() : nullptr,
+                    static_cast<size_t>(ws_bytes),
                     stream_of(mat)));
   return {out, arg};
 }

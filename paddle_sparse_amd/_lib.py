@@ -30,7 +30,7 @@ SIGNATURES = {
     "psa_ptr2ind": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "psa_spmm_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64]),
     "psa_spmm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
-                         c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                         c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                          c_size_t, c_void_p]),
     "psa_spmm_set_variant": (c_int, [c_int]),
     "psa_spmm_value_bw_workspace_bytes": (c_size_t, [c_int64]),
@@ -43,7 +43,7 @@ SIGNATURES = {
     "psa_csc_edge_tags": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "psa_spmm_minmax_bw_csc_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "psa_spmm_minmax_bw_csc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                       c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
                                        c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "psa_spmm_sum_bw_csc_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "psa_spmm_sum_bw_csc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

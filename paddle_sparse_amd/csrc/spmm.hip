@@ -112,6 +112,7 @@ struct MaskArgs {
   const float* mat = nullptr;        // dense operand of the forward [N, K] (grad_value only)
   const float* mrow = nullptr;       // set by the kernel: mat[c, k0..] of the wave's column
   float* grad_value = nullptr;       // [nnz] in CSC order (position j <-> edge edge_id[j]), or NULL
+  uint8_t* arg_bytes_out = nullptr;  // M_PLAIN min/max: also store arg_out as row-local bytes (see M_MASK)
   const float* row_scale = nullptr;  // M_CSC, mean: 1 / max(deg(r), 1) per CSR row, folded into both gradients
   int xcd_rows = 0;                  // row role: give each XCD one contiguous eighth of the rows
 };
@@ -598,6 +599,15 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
       }
 #pragma unroll
       for (int i = 0; i < VEC; ++i) arg_out[row * K + k0 + i] = arg[i];
+      if (VEC == 4 && mask.arg_bytes_out) {  // the backward's 1-byte form, for free while arg is in registers
+        uint32_t packed = 0;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) {
+          const uint32_t b = deg > 255 ? 255u : static_cast<uint32_t>((arg[i] - s) & 255);
+          packed |= b << (8 * i);
+        }
+        *reinterpret_cast<uint32_t*>(mask.arg_bytes_out + row * K + k0) = packed;
+      }
     }
     store_vec<VEC>(out + row * K + k0, acc);
   }
@@ -611,7 +621,8 @@ spmm_long_combine_kernel(const int64_t* __restrict__ rowptr, int64_t K, int mean
                          const LongEntry* __restrict__ long_list,
                          const float* __restrict__ part_val,
                          const int64_t* __restrict__ part_arg,
-                         float* __restrict__ out, int64_t* __restrict__ arg_out) {
+                         float* __restrict__ out, int64_t* __restrict__ arg_out,
+                         uint8_t* __restrict__ arg_bytes) {
   const int lane = threadIdx.x & 63;
   const int nrows = static_cast<int>(*long_ctr >> 32);
   const int num_waves = gridDim.x * (blockDim.x >> 6);
@@ -644,6 +655,8 @@ spmm_long_combine_kernel(const int64_t* __restrict__ rowptr, int64_t K, int mean
         if (mean) acc = acc / static_cast<float>(deg);
       } else {
         arg_out[ent.row * K + k] = arg;
+        if (arg_bytes)
+          arg_bytes[ent.row * K + k] = deg > 255 ? uint8_t{255} : static_cast<uint8_t>(arg - rowptr[ent.row]);
       }
       out[ent.row * K + k] = acc;
     }
@@ -781,7 +794,8 @@ int launch_long(int red, const int64_t* rowptr, const int64_t* col, const float*
     hipLaunchKernelGGL((spmm_long_chunk_kernel<VEC, LPR, R, U>), grid, block, 0, s, rowptr, \
                        col, val, mat, K, nnz, w.ctr, w.list, w.part_val, w.part_arg);      \
     hipLaunchKernelGGL((spmm_long_combine_kernel<R>), grid, block, 0, s, rowptr, K,         \
-                       mean, w.ctr, w.list, w.part_val, w.part_arg, out, arg_out);         \
+                       mean, w.ctr, w.list, w.part_val, w.part_arg, out, arg_out,          \
+                       static_cast<uint8_t*>(nullptr));                                    \
   } while (0)
   if (red == R_SUM) PSA_LONG(R_SUM);
   else if (red == R_MIN) PSA_LONG(R_MIN);
@@ -795,7 +809,8 @@ int launch_long(int red, const int64_t* rowptr, const int64_t* col, const float*
 template <int VEC, int LPR, int U>
 int launch_fused(int red, const int64_t* rowptr, const int64_t* col, const float* val,
                  const float* mat, float* out, int64_t* arg_out, int64_t M, int64_t K,
-                 int64_t nnz, int mean, const LongScratch& w, hipStream_t s) {
+                 int64_t nnz, int mean, const LongScratch& w, hipStream_t s,
+                 uint8_t* arg_bytes = nullptr) {
   const int64_t gx = psa::ceil_div(psa::ceil_div(M, kWaves), 8) * 8 + kFusedChunkBlocks;
   PSA_REQUIRE(gx <= 0x7fffffff, "M too large for one launch");
   const dim3 block(kThreads), grid(static_cast<unsigned>(gx));
@@ -804,13 +819,15 @@ int launch_fused(int red, const int64_t* rowptr, const int64_t* col, const float
   const dim3 cgrid(kLongBlocks), cblock(psa::kLongThreads);
   MaskArgs plain;
   plain.xcd_rows = g_variant == 16;
+  plain.arg_bytes_out = arg_bytes;
 #define PSA_FUSED(R)                                                                          \
   do {                                                                                        \
     hipLaunchKernelGGL((spmm_fused_kernel<VEC, LPR, R, U>), grid, block, 0, s, rowptr, col,   \
                        val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list, w.part_val,    \
                        w.part_arg, plain);                                                    \
     hipLaunchKernelGGL((spmm_long_combine_kernel<R>), cgrid, cblock, 0, s, rowptr, K, mean,   \
-                       w.ctr, w.list, w.part_val, w.part_arg, out, arg_out);                  \
+                       w.ctr, w.list, w.part_val, w.part_arg, out, arg_out,                   \
+                       plain.arg_bytes_out);                                                  \
   } while (0)
   if (red == R_SUM) PSA_FUSED(R_SUM);
   else if (red == R_MIN) PSA_FUSED(R_MIN);
@@ -835,7 +852,7 @@ int launch_fused_masked(const int64_t* colptr, const int64_t* row_csc, const flo
                      w.part_val, w.part_arg, mask);
   hipLaunchKernelGGL((spmm_long_combine_kernel<R_SUM>), dim3(kLongBlocks), dim3(psa::kLongThreads), 0, s,
                      colptr, K, 0, w.ctr, w.list, w.part_val, w.part_arg, out,
-                     static_cast<int64_t*>(nullptr));
+                     static_cast<int64_t*>(nullptr), static_cast<uint8_t*>(nullptr));
   PSA_LAUNCH_CHECK();
   return PSA_OK;
 }
@@ -984,9 +1001,10 @@ size_t psa_spmm_minmax_bw_csc_workspace_bytes(int64_t M, int64_t K, int64_t nnz)
 int psa_spmm_minmax_bw_csc(const int64_t* rowptr, const int64_t* colptr,
                            const int64_t* row_csc, const int64_t* csr2csc,
                            const uint8_t* tag, const float* value, const float* mat,
-                           const float* grad, const int64_t* arg_out, int64_t M, int64_t N,
-                           int64_t K, int64_t nnz, float* grad_value, float* grad_mat,
-                           void* workspace, size_t workspace_bytes, psa_stream_t stream) {
+                           const float* grad, const int64_t* arg_out, const uint8_t* arg_bytes,
+                           int64_t M, int64_t N, int64_t K, int64_t nnz, float* grad_value,
+                           float* grad_mat, void* workspace, size_t workspace_bytes,
+                           psa_stream_t stream) {
   PSA_REQUIRE(M >= 0 && N >= 0 && K >= 0 && nnz >= 0, "negative size");
   if (N == 0 || K == 0) return PSA_OK;
   if (K % 4 != 0 || K > 256 || !psa::aligned(grad, 16) || !psa::aligned(grad_mat, 16) ||
@@ -1008,14 +1026,14 @@ int psa_spmm_minmax_bw_csc(const int64_t* rowptr, const int64_t* colptr,
   uint8_t* bytes = static_cast<uint8_t*>(workspace);
   const LongScratch w = carve(bytes + align256(static_cast<size_t>(M) * K), false, K, nnz > 0 ? nnz : 1);
   PSA_ZERO(w.ctr, 8, s);
-  if (M > 0 && nnz > 0) {
+  if (arg_bytes == nullptr && M > 0 && nnz > 0) {  // the forward did not leave the byte form behind
     const int64_t blocks = psa::ceil_div(M * (K / 4), kThreads);
     PSA_REQUIRE(blocks <= 0x7fffffff, "M*K too large for one launch");
     hipLaunchKernelGGL(minmax_compress_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0,
                        s, rowptr, arg_out, M, K, bytes);
   }
   MaskArgs mask;
-  mask.bytes = bytes;
+  mask.bytes = arg_bytes != nullptr ? arg_bytes : bytes;
   mask.tag = tag;
   mask.edge_id = csr2csc;
   mask.arg = arg_out;
@@ -1080,10 +1098,17 @@ size_t psa_spmm_workspace_bytes(int reduce, int64_t K, int64_t nnz) {
   return long_workspace_bytes(reduce == PSA_MIN || reduce == PSA_MAX, K, nnz);
 }
 
-int psa_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
-             const float* value, const float* mat, int64_t M, int64_t N,
-             int64_t K, int64_t nnz, float* out, int64_t* arg_out,
-             void* workspace, size_t workspace_bytes, psa_stream_t stream) {
+}  // extern "C"
+
+namespace {
+
+// psa_spmm proper; *bytes_done tells whether the kernel that ran also stored
+// arg_bytes (only the fused-roles path does, the caller compresses otherwise).
+int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* col,
+                  const float* value, const float* mat, int64_t M, int64_t N,
+                  int64_t K, int64_t nnz, float* out, int64_t* arg_out,
+                  void* workspace, size_t workspace_bytes, hipStream_t s,
+                  uint8_t* arg_bytes, bool* bytes_done) {
   PSA_REQUIRE(reduce >= PSA_SUM && reduce <= PSA_MAX, "bad reduce");
   PSA_REQUIRE(M >= 0 && N >= 0 && K >= 0 && nnz >= 0, "negative size");
   if (M == 0 || K == 0) return PSA_OK;
@@ -1093,7 +1118,6 @@ int psa_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
               "col/mat is NULL");
   const bool minmax = reduce == PSA_MIN || reduce == PSA_MAX;
   PSA_REQUIRE(!minmax || arg_out != nullptr, "arg_out required for min/max");
-  hipStream_t s = psa::as_stream(stream);
   const int red = reduce == PSA_MIN ? R_MIN : (reduce == PSA_MAX ? R_MAX : R_SUM);
   const int mean = reduce == PSA_MEAN;
 
@@ -1147,9 +1171,12 @@ int psa_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
     // against chunk and row launches back to back; uniform graphs unchanged);
     // variant 15 forces the separate launches
     if ((g_variant == 0 || g_variant == 14 || g_variant == 16) && w.list && q > 16 && q <= 64) {
+      *bytes_done = arg_bytes != nullptr && minmax;
       if (q <= 32)
-        return launch_fused<4, 32, 4>(red, rowptr, col, value, mat, out, arg_out, M, K, nnz, mean, w, s);
-      return launch_fused<4, 64, 8>(red, rowptr, col, value, mat, out, arg_out, M, K, nnz, mean, w, s);
+        return launch_fused<4, 32, 4>(red, rowptr, col, value, mat, out, arg_out, M, K, nnz, mean, w, s,
+                                      minmax ? arg_bytes : nullptr);
+      return launch_fused<4, 64, 8>(red, rowptr, col, value, mat, out, arg_out, M, K, nnz, mean, w, s,
+                                    minmax ? arg_bytes : nullptr);
     }
     if (g_variant == 11) { if (q <= 32) PSA_ROWS(4, 32, 4, 4); PSA_ROWS(4, 64, 8, 4); }
     if (g_variant == 12) { if (q <= 32) PSA_ROWS(4, 32, 4, 8); PSA_ROWS(4, 64, 8, 8); }
@@ -1164,6 +1191,35 @@ int psa_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
   if (K <= 16) PSA_ROW(1, 16, 2);
   PSA_ROW(1, 64, 8);
 #undef PSA_ROW
+}
+
+}  // namespace
+
+extern "C" {
+
+int psa_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
+             const float* value, const float* mat, int64_t M, int64_t N,
+             int64_t K, int64_t nnz, float* out, int64_t* arg_out,
+             uint8_t* arg_bytes, void* workspace, size_t workspace_bytes,
+             psa_stream_t stream) {
+  const bool minmax = reduce == PSA_MIN || reduce == PSA_MAX;
+  if (arg_bytes != nullptr && minmax && K % 4 != 0) {
+    psa::set_error("psa_spmm: arg_bytes needs K % 4 == 0");
+    return PSA_ERR_UNSUPPORTED;
+  }
+  hipStream_t s = psa::as_stream(stream);
+  bool bytes_done = false;
+  const int st = spmm_dispatch(reduce, rowptr, col, value, mat, M, N, K, nnz, out, arg_out, workspace,
+                               workspace_bytes, s, arg_bytes, &bytes_done);
+  if (st != PSA_OK || arg_bytes == nullptr || !minmax || bytes_done || M == 0 || K == 0) return st;
+  // the kernel that ran keeps arg_out only: one more pass turns it into bytes
+  PSA_REQUIRE(psa::aligned(arg_out, 16) && psa::aligned(arg_bytes, 4), "arg_out / arg_bytes alignment");
+  const int64_t blocks = psa::ceil_div(M * (K / 4), kThreads);
+  PSA_REQUIRE(blocks <= 0x7fffffff, "M*K too large for one launch");
+  hipLaunchKernelGGL(minmax_compress_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, s,
+                     rowptr, arg_out, M, K, arg_bytes);
+  PSA_LAUNCH_CHECK();
+  return PSA_OK;
 }
 
 }  // extern "C"

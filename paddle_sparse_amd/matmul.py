@@ -45,14 +45,18 @@ class _SpMM(torch.autograd.Function):
     def forward(ctx, value: Optional[torch.Tensor], mat: torch.Tensor,
                 storage: SparseStorage, reduce: str):
         rowptr, col = storage.rowptr(), storage.col()
-        out, arg = ops._spmm(reduce, rowptr, col, value, mat)
+        # min/max: the forward also leaves arg_out as row-local bytes (the form
+        # the one-pass backward reads) when the K tile allows that backward
+        want_bytes = reduce in ("min", "max") and ops.minmax_bw_csc_supported(mat.shape[1])
+        out, arg, arg_bytes = ops._spmm(reduce, rowptr, col, value, mat, want_arg_bytes=True) if want_bytes \
+            else (*ops._spmm(reduce, rowptr, col, value, mat), None)
         ctx.storage, ctx.reduce = storage, reduce
-        ctx.save_for_backward(value, mat, arg)
+        ctx.save_for_backward(value, mat, arg, arg_bytes)
         return out
 
     @staticmethod
     def backward(ctx, grad_out: torch.Tensor):
-        value, mat, arg = ctx.saved_tensors
+        value, mat, arg, arg_bytes = ctx.saved_tensors
         st, reduce = ctx.storage, ctx.reduce
         need_value = value is not None and ctx.needs_input_grad[0]
         need_mat = ctx.needs_input_grad[1]
@@ -68,7 +72,7 @@ class _SpMM(torch.autograd.Function):
                 grad_value, grad_mat = ops.spmm_minmax_bw_csc(
                     st.rowptr(), st.colptr(), st._row_in_csc_order(), csr2csc, st._csc_edge_tags(),
                     value, mat, grad_out, arg, want_value=need_value,
-                    csc2csr=st.csc2csr() if need_value else None)
+                    csc2csr=st.csc2csr() if need_value else None, arg_bytes=arg_bytes)
             else:
                 grad_value, grad_mat = ops.spmm_minmax_bw(st.col(), value, mat, grad_out, arg,
                                                          want_value=need_value, want_mat=need_mat)

@@ -73,8 +73,9 @@ def ptr2ind(ptr: torch.Tensor, E: int) -> torch.Tensor:
 
 
 def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
-          value: Optional[torch.Tensor], mat: torch.Tensor
-          ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+          value: Optional[torch.Tensor], mat: torch.Tensor, want_arg_bytes: bool = False):
+    """(out, arg_out | None) — and, with want_arg_bytes (min/max, K % 4 == 0), a
+    third result: arg_out as row-local byte indices for spmm_minmax_bw_csc."""
     rowptr = _index(rowptr, "rowptr")
     col = _index(col, "col")
     _gpu(mat, "mat")
@@ -96,12 +97,18 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
     arg = None
     if rid in (_lib.MIN, _lib.MAX):
         arg = torch.empty((M, K), dtype=torch.int64, device=mat.device)
+    arg_bytes = None
+    if want_arg_bytes and arg is not None and K % 4 == 0:
+        arg_bytes = torch.empty((M, K), dtype=torch.uint8, device=mat.device)
     lib = _lib.load()
     ws_bytes = lib.psa_spmm_workspace_bytes(rid, K, nnz)  # long-row scratch (0 if no row can be long)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=mat.device) if ws_bytes else None
     with torch.cuda.device(mat.device):
         check(lib.psa_spmm(rid, _ptr(rowptr), _ptr(col), _ptr(value), _ptr(mat),
-                           M, N, K, nnz, _ptr(out), _ptr(arg), _ptr(ws), ws_bytes, _stream()))
+                           M, N, K, nnz, _ptr(out), _ptr(arg), _ptr(arg_bytes), _ptr(ws), ws_bytes,
+                           _stream()))
+    if want_arg_bytes:
+        return out, arg, arg_bytes
     return out, arg
 
 
@@ -425,7 +432,8 @@ def minmax_bw_csc_supported(K: int) -> bool:
 
 
 def spmm_minmax_bw_csc(rowptr, colptr, row_csc, csr2csc, tag, value, mat, grad, arg_out,
-                       want_value: bool = True, csc2csr: Optional[torch.Tensor] = None):
+                       want_value: bool = True, csc2csr: Optional[torch.Tensor] = None,
+                       arg_bytes: Optional[torch.Tensor] = None):
     """Backward of spmm_min / spmm_max in one pass over the CSC view, no atomics
     (see include/paddle_sparse_hip.h).  Returns (grad_value f32[nnz] | None,
     grad_mat f32[N, K]); grad_value is in CSR order (the pass writes it in CSC
@@ -443,6 +451,10 @@ def spmm_minmax_bw_csc(rowptr, colptr, row_csc, csr2csc, tag, value, mat, grad, 
     (M, K), N, nnz = grad.shape, colptr.numel() - 1, csr2csc.numel()
     if arg_out.shape != grad.shape or arg_out.dtype != torch.int64:
         raise ValueError("arg_out must be int64[M, K] like grad")
+    if arg_bytes is not None:
+        _gpu(arg_bytes, "arg_bytes")
+        if arg_bytes.dtype != torch.uint8 or arg_bytes.shape != grad.shape or not arg_bytes.is_contiguous():
+            raise ValueError("arg_bytes must be a contiguous uint8[M, K] (the third result of ops._spmm)")
     gv = None
     if want_value:
         mat = _f32(mat, "mat")
@@ -456,7 +468,7 @@ def spmm_minmax_bw_csc(rowptr, colptr, row_csc, csr2csc, tag, value, mat, grad, 
         check(lib.psa_spmm_minmax_bw_csc(_ptr(rowptr), _ptr(colptr), _ptr(row_csc), _ptr(csr2csc),
                                          _ptr(tag.contiguous()), _ptr(value),
                                          _ptr(mat) if want_value else None, _ptr(grad), _ptr(arg_out),
-                                         M, N, K, nnz, _ptr(gv), _ptr(gm), _ptr(ws), ws.numel(),
+                                         _ptr(arg_bytes), M, N, K, nnz, _ptr(gv), _ptr(gm), _ptr(ws), ws.numel(),
                                          _stream()))
     if gv is not None:
         gv = gather_rows(gv, csc2csr if csc2csr is not None else invert_permutation(csr2csc))

@@ -217,6 +217,36 @@ def test_sum_bw_one_csc_pass(has_value, K, graph):
     assert torch.equal(gv, gv2) and torch.equal(gm, gm2) and none is None and torch.equal(gm, gm3)
 
 
+@pytest.mark.parametrize("reduce", ["min", "max"])
+@pytest.mark.parametrize("K", [8, 32, 64, 100, 128, 256])
+def test_forward_leaves_arg_out_as_row_local_bytes(reduce, K):
+    """psa_spmm(arg_bytes=...): the byte form of arg_out the one-pass backward
+    reads, written by the forward itself (fused-roles kernel and its long-row
+    combine) or by the compress pass behind the other kernels."""
+    from paddle_sparse_amd import SparseStorage, ops
+
+    # rows of 0, a few, 200 (chunked: > 128) and 700 (> 255: marked 255) edges
+    row, rowptr, col, val = skewed_csr(900, 300, seed=K, long_rows=(0, 450), long_deg=700)
+    row2, rowptr2, col2, val2 = skewed_csr(900, 300, seed=K + 1, long_rows=(3, 899), long_deg=200)
+    for rp, c, v in ((rowptr, col, val), (rowptr2, col2, val2)):
+        B = np.random.default_rng(K).standard_normal((300, K)).astype(np.float32)
+        out, arg, ab = ops._spmm(reduce, dev(rp), dev(c), dev(v), dev(B), want_arg_bytes=True)
+        ref_out, ref_arg = oracle.spmm(reduce, rp, c, v, B)
+        assert np.array_equal(arg.cpu().numpy(), ref_arg)
+        deg = rp[1:] - rp[:-1]
+        live = deg > 0
+        want = np.where((deg > 255)[:, None], 255, ref_arg - rp[:-1, None]).astype(np.uint8)
+        assert ab.dtype == torch.uint8 and np.array_equal(ab.cpu().numpy()[live], want[live])
+        # the backward gives the same bits with the bytes handed in or derived inside
+        st = SparseStorage(rowptr=dev(rp), col=dev(c), value=dev(v), sparse_sizes=(900, 300), is_sorted=True)
+        G = torch.randn(900, K, device="cuda")
+        args = (st.rowptr(), st.colptr(), st._row_in_csc_order(), st.csr2csc(), st._csc_edge_tags(), st.value(),
+                dev(B), G, arg)
+        gv1, gm1 = ops.spmm_minmax_bw_csc(*args, csc2csr=st.csc2csr(), arg_bytes=ab)
+        gv2, gm2 = ops.spmm_minmax_bw_csc(*args, csc2csr=st.csc2csr())
+        assert torch.equal(gv1, gv2) and torch.equal(gm1, gm2)
+
+
 def test_minmax_bw_over_csc_rejects_unaligned_k():
     from paddle_sparse_amd import ops
     from paddle_sparse_amd._lib import HipCoreError
