@@ -264,3 +264,62 @@ PD_BUILD_OP(sample_adj)
     .Attrs({"num_neighbors: int64_t", "replace: bool"})
     .SetKernelFn(PD_KERNEL(sample_adj))
     .SetInferDtypeFn(PD_INFER_DTYPE(sample_adj_infer_dtype));
+
+// ---- coalesce as ONE op (seam: paddle_sparse/coalesce.py:25-29) ----------------------
+// The Python layer of this repository composes the chain call by call (and pays
+// ~10 us of interpreter per call); inside a custom op the same chain is plain
+// C++.  index int64[2, nnz] + optional value [nnz, ...] -> coalesced pair.
+// `reduce`: psa_reduce.  One device -> host read (the number of distinct entries).
+std::vector<paddle::Tensor> coalesce(paddle::Tensor& index, const paddle::optional<paddle::Tensor>& value,
+                                     int64_t m, int64_t n, int64_t reduce) {
+  CHECK_GPU(index);
+  CHECK_I64(index);
+  PD_CHECK(index.shape().size() == 2 && index.shape()[0] == 2, "index must be [2, nnz]");
+  const int64_t nnz = index.shape()[1];
+  void* s = stream_of(index);
+  const auto place = index.place();
+  auto i64_empty = [&](std::vector<int64_t> shape) { return paddle::empty(shape, paddle::DataType::INT64, place); };
+  auto bytes = [&](size_t b) { return paddle::empty({static_cast<int64_t>(b > 0 ? b : 1)}, paddle::DataType::UINT8, place); };
+  const int64_t* row = i64(index);            // index is contiguous [2, nnz]: row, then col
+  const int64_t* col = i64(index) + nnz;
+  if (nnz == 0) return {index, value ? value.get() : paddle::empty({0}, paddle::DataType::FLOAT32, place)};
+
+  auto keys = i64_empty({nnz}), sorted = i64_empty({nnz}), perm = i64_empty({nnz}), count = i64_empty({1});
+  PSA_CALL(psa_make_keys(row, col, n, nnz, keys.data<int64_t>(), nullptr, s));
+  auto sort_ws = bytes(psa_index_sort_workspace_bytes(nnz, m * n));
+  PSA_CALL(psa_index_sort(i64(keys), nnz, m * n, sorted.data<int64_t>(), perm.data<int64_t>(),
+                          sort_ws.data<uint8_t>(), psa_index_sort_workspace_bytes(nnz, m * n), s));
+  auto uniq_ws = bytes(psa_unique_workspace_bytes(nnz));
+  PSA_CALL(psa_unique_count(i64(sorted), nnz, uniq_ws.data<uint8_t>(), psa_unique_workspace_bytes(nnz),
+                            count.data<int64_t>(), s));
+  const int64_t distinct = count.copy_to(paddle::CPUPlace(), true).data<int64_t>()[0];
+  auto out_index = i64_empty({2, distinct});
+  auto ptr = i64_empty({distinct + 1});
+  PSA_CALL(psa_unique_write(i64(sorted), nnz, n, uniq_ws.data<uint8_t>(), i64(count), ptr.data<int64_t>(),
+                            out_index.data<int64_t>(), out_index.data<int64_t>() + distinct, s));
+  if (!value) return {out_index, paddle::empty({0}, paddle::DataType::FLOAT32, place)};
+  const paddle::Tensor& v = value.get();
+  int dtype = -1;
+  switch (v.dtype()) {
+    case paddle::DataType::FLOAT32: dtype = PSA_F32; break;
+    case paddle::DataType::FLOAT64: dtype = PSA_F64; break;
+    case paddle::DataType::INT32: dtype = PSA_I32; break;
+    case paddle::DataType::INT64: dtype = PSA_I64; break;
+    case paddle::DataType::FLOAT16: dtype = PSA_F16; break;
+    case paddle::DataType::BFLOAT16: dtype = PSA_BF16; break;
+    default: PD_THROW("coalesce: unsupported value dtype");
+  }
+  auto shape = v.shape();
+  int64_t D = 1;
+  for (size_t i = 1; i < shape.size(); ++i) D *= shape[i];
+  shape[0] = distinct;
+  auto out_value = paddle::empty(shape, v.dtype(), place);
+  PSA_CALL(psa_segment_reduce(static_cast<int>(reduce), dtype, v.data(), i64(perm), i64(ptr), distinct, D, nnz,
+                              out_value.data(), s));
+  return {out_index, out_value};
+}
+PD_BUILD_OP(coalesce)
+    .Inputs({"index", paddle::Optional("value")})
+    .Outputs({"out_index", "out_value"})
+    .Attrs({"m: int64_t", "n: int64_t", "reduce: int64_t"})
+    .SetKernelFn(PD_KERNEL(coalesce));
