@@ -1,0 +1,114 @@
+// A client of the C-ABI with no framework in the process: plain HIP runtime +
+// libpaddle_sparse_hip.so, as the Paddle custom-op shim would use it.  Built and
+// run by tests/test_cabi_client_gpu.py.  Exit code 0 = every check passed.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+
+#include "paddle_sparse_hip.h"
+
+#define HIP_OK(x)                                                          \
+  do {                                                                     \
+    hipError_t e_ = (x);                                                   \
+    if (e_ != hipSuccess) {                                                \
+      std::printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      return 2;                                                            \
+    }                                                                      \
+  } while (0)
+#define PSA_OK_(x)                                                         \
+  do {                                                                     \
+    if ((x) != PSA_OK) {                                                   \
+      std::printf("psa error: %s (%s:%d)\n", psa_last_error(), __FILE__, __LINE__); \
+      return 3;                                                            \
+    }                                                                      \
+  } while (0)
+
+template <typename T>
+T* to_device(const std::vector<T>& h) {
+  T* d = nullptr;
+  if (hipMalloc(&d, sizeof(T) * (h.empty() ? 1 : h.size())) != hipSuccess) return nullptr;
+  if (hipMemcpy(d, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  return d;
+}
+
+int main() {
+  if (psa_abi_version() != PSA_ABI_VERSION || psa_sparse_cuda_version() != -1) return 1;
+  hipStream_t stream;
+  HIP_OK(hipStreamCreate(&stream));
+
+  // README.md:293-305: index [[0,0,1,2,2],[0,2,1,0,1]], value [1,2,4,1,3], B [[1,4],[2,5],[3,6]]
+  const int64_t M = 3, N = 3, K = 2, nnz = 5;
+  std::vector<int64_t> row = {0, 0, 1, 2, 2}, col = {0, 2, 1, 0, 1};
+  std::vector<float> val = {1, 2, 4, 1, 3}, B = {1, 4, 2, 5, 3, 6};
+  int64_t *d_row = to_device(row), *d_col = to_device(col);
+  float *d_val = to_device(val), *d_B = to_device(B);
+  int64_t* d_rowptr;
+  float* d_out;
+  HIP_OK(hipMalloc(&d_rowptr, sizeof(int64_t) * (M + 1)));
+  HIP_OK(hipMalloc(&d_out, sizeof(float) * M * K));
+  PSA_OK_(psa_ind2ptr(d_row, nnz, M, d_rowptr, stream));
+  PSA_OK_(psa_spmm(PSA_SUM, d_rowptr, d_col, d_val, d_B, M, N, K, nnz, d_out, nullptr, nullptr, nullptr, 0, stream));
+  std::vector<int64_t> rowptr(M + 1);
+  std::vector<float> out(M * K);
+  HIP_OK(hipStreamSynchronize(stream));
+  HIP_OK(hipMemcpy(rowptr.data(), d_rowptr, sizeof(int64_t) * (M + 1), hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(out.data(), d_out, sizeof(float) * M * K, hipMemcpyDeviceToHost));
+  const int64_t want_ptr[] = {0, 2, 3, 5};
+  const float want_out[] = {7, 16, 8, 20, 7, 19};
+  for (int i = 0; i <= M; ++i)
+    if (rowptr[i] != want_ptr[i]) return std::printf("rowptr[%d] = %lld\n", i, (long long)rowptr[i]), 4;
+  for (int i = 0; i < M * K; ++i)
+    if (out[i] != want_out[i]) return std::printf("out[%d] = %f\n", i, out[i]), 5;
+
+  // test/test_coalesce.py:7-34 through make_keys -> index_sort -> unique -> segment_reduce
+  std::vector<int64_t> crow = {1, 0, 1, 0, 2, 1}, ccol = {0, 1, 1, 1, 0, 0};
+  std::vector<float> cval = {1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7};  // [6, 2]
+  const int64_t cn = 6, cm = 3, cN = 2;
+  int64_t *d_crow = to_device(crow), *d_ccol = to_device(ccol), *d_keys, *d_sorted, *d_perm, *d_count;
+  float* d_cval = to_device(cval);
+  HIP_OK(hipMalloc(&d_keys, 8 * cn));
+  HIP_OK(hipMalloc(&d_sorted, 8 * cn));
+  HIP_OK(hipMalloc(&d_perm, 8 * cn));
+  HIP_OK(hipMalloc(&d_count, 8));
+  void *sort_ws, *uniq_ws;
+  const size_t sort_b = psa_index_sort_workspace_bytes(cn, cm * cN), uniq_b = psa_unique_workspace_bytes(cn);
+  HIP_OK(hipMalloc(&sort_ws, sort_b));
+  HIP_OK(hipMalloc(&uniq_ws, uniq_b));
+  PSA_OK_(psa_make_keys(d_crow, d_ccol, cN, cn, d_keys, nullptr, stream));
+  PSA_OK_(psa_index_sort(d_keys, cn, cm * cN, d_sorted, d_perm, sort_ws, sort_b, stream));
+  PSA_OK_(psa_unique_count(d_sorted, cn, uniq_ws, uniq_b, d_count, stream));
+  int64_t count = 0;
+  HIP_OK(hipMemcpyAsync(&count, d_count, 8, hipMemcpyDeviceToHost, stream));
+  HIP_OK(hipStreamSynchronize(stream));
+  if (count != 4) return std::printf("count = %lld\n", (long long)count), 6;
+  int64_t *d_ptr, *d_orow, *d_ocol;
+  float* d_oval;
+  HIP_OK(hipMalloc(&d_ptr, 8 * (count + 1)));
+  HIP_OK(hipMalloc(&d_orow, 8 * count));
+  HIP_OK(hipMalloc(&d_ocol, 8 * count));
+  HIP_OK(hipMalloc(&d_oval, 4 * count * 2));
+  PSA_OK_(psa_unique_write(d_sorted, cn, cN, uniq_ws, d_count, d_ptr, d_orow, d_ocol, stream));
+  PSA_OK_(psa_segment_reduce(PSA_SUM, PSA_F32, d_cval, d_perm, d_ptr, count, 2, cn, d_oval, stream));
+  std::vector<int64_t> orow(count), ocol(count);
+  std::vector<float> oval(count * 2);
+  HIP_OK(hipStreamSynchronize(stream));
+  HIP_OK(hipMemcpy(orow.data(), d_orow, 8 * count, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(ocol.data(), d_ocol, 8 * count, hipMemcpyDeviceToHost));
+  HIP_OK(hipMemcpy(oval.data(), d_oval, 4 * count * 2, hipMemcpyDeviceToHost));
+  const int64_t want_r[] = {0, 1, 1, 2}, want_c[] = {1, 0, 1, 0};
+  const float want_v[] = {6, 8, 7, 9, 3, 4, 5, 6};
+  for (int i = 0; i < 4; ++i)
+    if (orow[i] != want_r[i] || ocol[i] != want_c[i]) return std::printf("coalesced index %d wrong\n", i), 7;
+  for (int i = 0; i < 8; ++i)
+    if (oval[i] != want_v[i]) return std::printf("coalesced value[%d] = %f\n", i, oval[i]), 8;
+
+  // error reporting: a bad enum comes back as a status + message, not a crash
+  if (psa_spmm(17, d_rowptr, d_col, d_val, d_B, M, N, K, nnz, d_out, nullptr, nullptr, nullptr, 0, stream) != PSA_ERR_INVALID_ARG)
+    return 9;
+  if (psa_last_error()[0] == '\0') return 10;
+  std::printf("C-ABI client: ind2ptr, spmm (README KAT), coalesce chain (test_coalesce KAT), error path OK\n");
+  return 0;
+}
