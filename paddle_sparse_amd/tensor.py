@@ -399,6 +399,14 @@ class SparseTensor(object):
             value = torch.ones(self.nnz(), dtype=dtype, device=self.device())
         return torch.sparse_csr_tensor(rowptr, col, value, self.sizes())
 
+    def to_torch_sparse_csc_tensor(self, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+        """The reference's to_paddle_sparse_csc_tensor raises (Paddle has no CSC
+        layout, tensor.py:587-591); torch has one, so the CSC view is handed over."""
+        colptr, row, value = self.csc()
+        if value is None:
+            value = torch.ones(self.nnz(), dtype=dtype, device=self.device())
+        return torch.sparse_csc_tensor(colptr, row, value, self.sizes())
+
     @classmethod
     def from_scipy(cls, mat, has_value: bool = True, device=None):
         colptr = None

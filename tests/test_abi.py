@@ -67,3 +67,21 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "nope.so")
     with pytest.raises(ImportError, match="no CPU fallback"):
         _lib.load()
+
+
+def test_convert_round_trips_on_the_host():
+    """test/test_convert.py:9-33 (no kernels involved): scipy and framework
+    sparse tensors in and out of the (index, value) form."""
+    import torch
+    from paddle_sparse_amd import eye, from_scipy, from_torch_sparse, to_scipy, to_torch_sparse
+
+    index = torch.tensor([[0, 0, 1, 2, 2], [0, 2, 1, 0, 1]])
+    value = torch.tensor([1, 2, 4, 1, 3])
+    out = from_scipy(to_scipy(index, value, 3, 3))
+    assert out[0].tolist() == index.tolist() and out[1].tolist() == value.tolist()
+    out = from_torch_sparse(to_torch_sparse(index, value, 3, 3).coalesce())
+    assert out[0].tolist() == index.tolist() and out[1].tolist() == value.tolist()
+    idx, val = eye(4, dtype=torch.float32)
+    assert idx.tolist() == [[0, 1, 2, 3]] * 2 and val.tolist() == [1.0] * 4
+    with pytest.raises(ValueError):
+        to_scipy(index[0], value, 3, 3)

@@ -283,6 +283,10 @@ def test_csr_csc_coo_and_scipy_roundtrip():
     assert np.array_equal(r_csc.cpu().numpy(), row[perm]) and np.array_equal(v_csc.cpu().numpy(), val[perm])
     dense = SparseTensor.from_dense(t.to_dense())
     assert dense == t
+    for sparse in (t.to_torch_sparse_coo_tensor(), t.to_torch_sparse_csr_tensor(), t.to_torch_sparse_csc_tensor()):
+        assert torch.equal(sparse.to_dense(), t.to_dense())
+    assert SparseTensor.from_torch_sparse_coo_tensor(t.to_torch_sparse_coo_tensor()) == t
+    assert SparseTensor.from_torch_sparse_csr_tensor(t.to_torch_sparse_csr_tensor()) == t
 
 
 def test_eye_caches():
