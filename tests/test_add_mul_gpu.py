@@ -137,3 +137,16 @@ def test_mul_requires_coalesced_operands():
     ok = SparseTensor(row=idx([0]), col=idx([1]), value=torch.ones(1, device="cuda"))
     with pytest.raises(ValueError, match="not coalesced"):
         dup * ok
+
+
+def test_overload():
+    """test/test_overload.py:6-21: both operand orders, column and row vectors."""
+    from paddle_sparse_amd import SparseTensor
+
+    mat = SparseTensor(row=idx([0, 1, 1, 2, 2]), col=idx([1, 0, 2, 1, 2]))
+    dense = mat.to_dense(dtype=torch.int64)
+    for other in (torch.tensor([1, 2, 3], device="cuda").view(3, 1), torch.tensor([1, 2, 3], device="cuda").view(1, 3)):
+        for got in (other + mat, mat + other):
+            assert torch.equal(got.to_dense(), torch.where(dense != 0, dense + other, 0))
+        for got in (other * mat, mat * other):
+            assert torch.equal(got.to_dense(), dense * other)
