@@ -385,3 +385,23 @@ def test_cpu_tensors_are_rejected_by_the_hot_path():
     t = SparseTensor(row=torch.tensor([0, 1]), col=torch.tensor([1, 0]), is_sorted=True)
     with pytest.raises(RuntimeError, match="GPU tensor"):
         t.storage.rowptr()
+
+
+def test_equal_and_to():
+    """test/test_tensor.py:91-124."""
+    from paddle_sparse_amd import SparseTensor
+
+    row, value = idx([0, 0, 0, 1, 1]), torch.arange(1, 6, device=DEV)
+    a = SparseTensor(row=row, col=idx([0, 1, 2, 0, 2]), value=value)
+    b = SparseTensor(row=row, col=idx([0, 1, 2, 0, 2]), value=value)
+    c = SparseTensor(row=row, col=idx([0, 1, 2, 0, 1]), value=value)
+    assert a is not b and a == b
+    assert a is not c and a != c
+
+    assert value.dtype == torch.int64
+    mat = a.to(torch.float32)
+    assert mat.storage.value().dtype == torch.float32 and mat.storage.value().is_cuda
+    mat = mat.to("cpu", torch.float32)
+    assert not mat.storage.value().is_cuda and not mat.storage.row().is_cuda and not mat.storage.col().is_cuda
+    back = mat.to(value)  # device and dtype of a tensor
+    assert back.storage.value().dtype == torch.int64 and back.storage.col().is_cuda and back == a
