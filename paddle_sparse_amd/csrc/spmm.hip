@@ -679,7 +679,7 @@ spmm_multirow_kernel(const int64_t* __restrict__ rowptr,
                      float* __restrict__ out, int64_t* __restrict__ arg_out,
                      int64_t M, int64_t K, int64_t nnz, int mean,
                      unsigned long long* __restrict__ long_ctr,
-                     LongEntry* __restrict__ long_list) {
+                     LongEntry* __restrict__ long_list, uint8_t* __restrict__ arg_bytes) {
   constexpr int G = 64 / LPR;
   const int lane = threadIdx.x & 63;
   const int g = lane / LPR;
@@ -748,6 +748,15 @@ spmm_multirow_kernel(const int64_t* __restrict__ rowptr,
     }
 #pragma unroll
     for (int i = 0; i < VEC; ++i) arg_out[row * K + k0 + i] = arg[i];
+    if (VEC == 4 && arg_bytes) {  // row-local byte form for the one-pass backward (see MaskArgs)
+      uint32_t packed = 0;
+#pragma unroll
+      for (int i = 0; i < VEC; ++i) {
+        const uint32_t b = deg > 255 ? 255u : static_cast<uint32_t>((arg[i] - s) & 255);
+        packed |= b << (8 * i);
+      }
+      *reinterpret_cast<uint32_t*>(arg_bytes + row * K + k0) = packed;
+    }
   }
   store_vec<VEC>(out + row * K + k0, acc);
 }
@@ -787,7 +796,7 @@ LongScratch carve(void* workspace, bool minmax, int64_t K, int64_t nnz) {
 template <int VEC, int LPR, int U>
 int launch_long(int red, const int64_t* rowptr, const int64_t* col, const float* val,
                 const float* mat, float* out, int64_t* arg_out, int64_t K, int64_t nnz,
-                int mean, const LongScratch& w, hipStream_t s) {
+                int mean, const LongScratch& w, hipStream_t s, uint8_t* arg_bytes = nullptr) {
   const dim3 grid(kLongBlocks), block(psa::kLongThreads);
 #define PSA_LONG(R)                                                                        \
   do {                                                                                     \
@@ -795,7 +804,7 @@ int launch_long(int red, const int64_t* rowptr, const int64_t* col, const float*
                        col, val, mat, K, nnz, w.ctr, w.list, w.part_val, w.part_arg);      \
     hipLaunchKernelGGL((spmm_long_combine_kernel<R>), grid, block, 0, s, rowptr, K,         \
                        mean, w.ctr, w.list, w.part_val, w.part_arg, out, arg_out,          \
-                       static_cast<uint8_t*>(nullptr));                                    \
+                       arg_bytes);                                                         \
   } while (0)
   if (red == R_SUM) PSA_LONG(R_SUM);
   else if (red == R_MIN) PSA_LONG(R_MIN);
@@ -897,24 +906,26 @@ template <int VEC, int LPR, int U>
 int launch_multirow(int red, const int64_t* rowptr, const int64_t* col,
                     const float* val, const float* mat, float* out,
                     int64_t* arg_out, int64_t M, int64_t K, int64_t nnz, int mean,
-                    const LongScratch& w, hipStream_t s) {
+                    const LongScratch& w, hipStream_t s, uint8_t* arg_bytes = nullptr) {
   const int64_t gx = psa::ceil_div(M, static_cast<int64_t>(kWaves) * (64 / LPR));
   PSA_REQUIRE(gx <= 0x7fffffff, "M too large for one launch");
   const dim3 grid(static_cast<unsigned>(gx)), block(kThreads);
   if (red == R_SUM) {
     hipLaunchKernelGGL((spmm_multirow_kernel<VEC, LPR, R_SUM, U>), grid, block, 0, s,
-                       rowptr, col, val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list);
+                       rowptr, col, val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list,
+                       static_cast<uint8_t*>(nullptr));
   } else if (red == R_MIN) {
     hipLaunchKernelGGL((spmm_multirow_kernel<VEC, LPR, R_MIN, U>), grid, block, 0, s,
-                       rowptr, col, val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list);
+                       rowptr, col, val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list, arg_bytes);
   } else {
     hipLaunchKernelGGL((spmm_multirow_kernel<VEC, LPR, R_MAX, U>), grid, block, 0, s,
-                       rowptr, col, val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list);
+                       rowptr, col, val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list, arg_bytes);
   }
   PSA_LAUNCH_CHECK();
   // chunk waves split a row's edges over the 64/LPR lane groups: 8 edges per step
   constexpr int UL = (64 / LPR) >= 8 ? 1 : 8 / (64 / LPR);
-  if (w.list) return launch_long<VEC, LPR, UL>(red, rowptr, col, val, mat, out, arg_out, K, nnz, mean, w, s);
+  if (w.list)
+    return launch_long<VEC, LPR, UL>(red, rowptr, col, val, mat, out, arg_out, K, nnz, mean, w, s, arg_bytes);
   return PSA_OK;
 }
 
@@ -1146,8 +1157,12 @@ int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* col,
     if (g_variant == 3 && q >= 32) PSA_ROW(4, 32, 8);
     if (g_variant == 4 && K % 128 == 0) PSA_ROW(2, 64, 16);
 #define PSA_MULTI(VEC, LPR, U)                                                     \
-  return launch_multirow<VEC, LPR, U>(red, rowptr, col, value, mat, out, arg_out, \
-                                      M, K, nnz, mean, w, s)
+  do {                                                                             \
+    *bytes_done = arg_bytes != nullptr && minmax;                                  \
+    return launch_multirow<VEC, LPR, U>(red, rowptr, col, value, mat, out, arg_out, \
+                                        M, K, nnz, mean, w, s,                     \
+                                        minmax ? arg_bytes : nullptr);             \
+  } while (0)
     // K <= 64: several rows per wave (multirow, 8 gathers in flight per row)
     // measured at 2M rows / 20M edges: K=16 0.58 -> 0.41 ms, K=32 0.69 -> 0.45,
     // K=64 1.01 -> 0.88 (variant 1 forces the one-row-per-wave kernel back)
