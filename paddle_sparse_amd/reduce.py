@@ -12,6 +12,7 @@ from typing import Optional
 import torch
 
 from . import ops
+from .storage import _SORT_BEATS_ATOMICS
 from .tensor import SparseTensor
 
 _DENSE = {"sum": "sum", "add": "sum", "mean": "mean", "min": "amin", "max": "amax"}
@@ -38,7 +39,7 @@ def reduction(src: SparseTensor, dim: Optional[int] = None, reduce: str = "sum")
     if dim == 0:
         if value is not None:
             st = src.storage
-            if st.has_csr2csc() and st.has_colptr():
+            if (st.has_csr2csc() and st.has_colptr()) or st.col().numel() >= _SORT_BEATS_ATOMICS:
                 # Same sums as the scatter of reduce.py:42, taken column by
                 # column in CSC order: no atomics (scattered device atomics
                 # run ~20 G/s on this chip), and reproducible bit for bit.

@@ -178,15 +178,15 @@ report("a7", "rowcount() from rowptr", ms, (M + 1) * 8 + M * 8)
 
 # ---- a8 / a9 -----------------------------------------------------------------------
 ms = gpu_ms(lambda: fresh().colcount())
-report("a8", "colcount() (bincount over col)", ms, E * 8 + N * 8)
+report("a8", "colcount() cold (3-pass stable sort of col + ind2ptr)", ms, E * 8 + N * 8)
 ms = gpu_ms(lambda: fresh().colptr())
-report("a8", "colptr() (colcount + scan)", ms, E * 8 + N * 8 + (N + 1) * 16)
+report("a8", "colptr() cold (same; leaves csr2csc behind)", ms, E * 8 + (N + 1) * 8)
 key_csc = col_sh * M + row_sh
 if not args.no_cpu:
     c1 = cpu_ms(lambda: oracle.index_sort_c(key_csc, M * N, 1))
     cT = cpu_ms(lambda: oracle.index_sort_c(key_csc, M * N, T))
 ms = gpu_ms(lambda: fresh().csr2csc(), reps=5)
-report("a9", "csr2csc() = index_sort(M*col + row)", ms, E * 16 + E * 8, c1, cT)
+report("a9", "csr2csc() = stable index_sort of col alone", ms, E * 8 + E * 8, c1, cT)
 st = fresh()
 st.csr2csc()
 
@@ -202,7 +202,7 @@ report("a9", "csc2csr() = inverse permutation (scatter)", ms, E * 16)
 # ---- a10 / a12 -----------------------------------------------------------------------
 A = SparseTensor.from_storage(fresh())
 ms = gpu_ms(lambda: SparseTensor.from_storage(fresh()).t(), reps=5)
-report("a10", "SparseTensor.t() cold (sort, key split, value gather)", ms, E * 24 + E * (8 + 16) + E * 16)
+report("a10", "SparseTensor.t() cold (col sort, row + value gathers)", ms, E * 16 + E * 24 + E * 16)
 A.storage.csr2csc()
 A.storage.colptr()
 ms = gpu_ms(lambda: A.t())
@@ -223,7 +223,7 @@ for reduce in ("sum", "max"):
     report("a11", f"reduction(dim=0, {reduce}) CSC cached: segment path", ms, E * 12 + (N + 1) * 8 + N * 4)
     cold = SparseTensor.from_storage(fresh())
     ms = gpu_ms(lambda: reduction(cold, 0, reduce))
-    report("a11", f"reduction(dim=0, {reduce}) no cache: atomic scatter", ms, E * 12 + N * 4)
+    report("a11", f"reduction(dim=0, {reduce}) cold: col sort + segment path", ms, E * 12 + N * 4)
 ms = gpu_ms(lambda: reduction(A, None, "sum"))
 report("a11", "reduction(dim=None, sum)", ms, E * 4)
 
