@@ -254,6 +254,19 @@ int psa_sort_pairs_u32(const int64_t* keys, const void* payload, int64_t n,
                        int64_t max_value, int64_t* sorted_out, void* payload_out,
                        void* workspace, size_t workspace_bytes, psa_stream_t stream);
 
+/* psa_sort_pairs_u32 on a BIT FIELD of the keys: stable order by
+ * (keys[i] >> first_bit), which must be < max_value; the bits below first_bit
+ * are not looked at and travel inside the key.  With keys packed as
+ * (hi << 32) | lo this orders by `hi` alone in ceil(log2(max_value) / 8) passes
+ * while `lo` comes along for free — e.g. products grouped by output column
+ * (lo) brought into (row, col) order by ONE sort on the row field.  Workspace:
+ * psa_index_sort_workspace_bytes(n, max_value). */
+int psa_sort_pairs_u32_field(const int64_t* keys, const void* payload, int64_t n,
+                             int first_bit, int64_t max_value,
+                             int64_t* sorted_out, void* payload_out,
+                             void* workspace, size_t workspace_bytes,
+                             psa_stream_t stream);
+
 /* Small inputs (n <= psa_coalesce_small_max(), 40960): the sort by (row, col)
  * AND the run-length structure of a coalesce (storage.py:158-171 + 455-470) in
  * one launch of one workgroup — at BASELINE config 1 (10 k entries) the
@@ -376,7 +389,12 @@ int psa_spspmm_count(const int64_t* colA, int64_t nnzA, const int64_t* rowptrB,
 
 /* For product p in [0, total): e = owner[p], q = rowptrB[colA[e]] + p -
  * offsets[e]; keys[p] = rowA[e] * n + colB[q]; vals[p] = valA[e] * valB[q]
- * (a NULL value array counts as ones; vals may be NULL).  dtype: f32, f64,
+ * (a NULL value array counts as ones; vals may be NULL).  With n < 0 the key
+ * is packed instead: keys[p] = (colB[q] << 32) | rowA[e] — the form used when
+ * the walk runs over the CSC views of both operands (outer = entries of B by
+ * column, inner = a column of A), so that products come out grouped by output
+ * column and ONE stable sort on the row field (psa_sort_pairs_u32_field, half
+ * the passes of a sort on row * n + col) finishes the order.  dtype: f32, f64,
  * i32 or i64.  Products of one C entry keep the order in which a sequential
  * row-by-row product meets them, so a stable sort + psa_segment_reduce's
  * in-order kernel (runs averaging < 32 products) reproduces that sum bit for

@@ -560,7 +560,7 @@ __device__ __forceinline__ uint64_t os_pack(uint32_t flag, uint32_t value) {
 }
 
 __global__ void __launch_bounds__(kThreads)
-os_hist_kernel(const uint64_t* __restrict__ keys, int64_t n, int passes,
+os_hist_kernel(const uint64_t* __restrict__ keys, int64_t n, int passes, int first_bit,
                uint32_t* __restrict__ ghist /*[kOsMaxPasses][256]*/) {
   __shared__ uint32_t hist[kOsMaxPasses][kRadix];
   const int tid = threadIdx.x;
@@ -569,7 +569,7 @@ os_hist_kernel(const uint64_t* __restrict__ keys, int64_t n, int passes,
   const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + tid; i < n; i += stride) {
     const uint64_t k = keys[i];
-    for (int p = 0; p < passes; ++p) atomicAdd(&hist[p][digit_of(k, 8 * p)], 1u);
+    for (int p = 0; p < passes; ++p) atomicAdd(&hist[p][digit_of(k, first_bit + 8 * p)], 1u);
   }
   __syncthreads();
   for (int i = tid; i < passes * kRadix; i += kThreads) {
@@ -1056,7 +1056,9 @@ size_t psa_index_sort_workspace_bytes(int64_t n, int64_t max_value) {
 static int sort_impl(const char* who, const int64_t* keys, const uint32_t* pay_in,
                      int64_t n, int64_t max_value, int64_t* sorted_out,
                      int64_t* perm_out, uint32_t* pay_out, void* workspace,
-                     size_t workspace_bytes, hipStream_t s) {
+                     size_t workspace_bytes, hipStream_t s, int first_bit = 0) {
+  // first_bit > 0: order by the bit field (key >> first_bit) < max_value only;
+  // the bits below ride along inside the key (stable, like any other payload)
   const SortPlan p = make_plan(n, max_value);
   if (p.passes == 0) {  // all keys equal: the stable order is the input order
     if (perm_out) {
@@ -1105,12 +1107,12 @@ static int sort_impl(const char* who, const int64_t* keys, const uint32_t* pay_i
     PSA_ZERO(os, p.os_bytes, s);
     const int hist_blocks = static_cast<int>(psa::ceil_div(n, kThreads * 16) < 2048
                                                  ? psa::ceil_div(n, kThreads * 16) : 2048);
-    hipLaunchKernelGGL(os_hist_kernel, dim3(hist_blocks), block, 0, s, kin, n, p.passes, ghist);
+    hipLaunchKernelGGL(os_hist_kernel, dim3(hist_blocks), block, 0, s, kin, n, p.passes, first_bit, ghist);
     hipLaunchKernelGGL(os_scan_kernel, dim3(p.passes), block, 0, s, ghist, gbase_all);
     const bool narrow = variant == 0;  // 512 threads x 16 keys, 2 blocks / CU
     const dim3 os_grid(static_cast<unsigned>(os_tiles)), os_block(narrow ? 512 : 1024);
     for (int pass = 0; pass < p.passes; ++pass) {
-      const int shift = 8 * pass;
+      const int shift = first_bit + 8 * pass;
       const bool last = pass == p.passes - 1;
       const bool iota_payload = pass == 0 && pay_in == nullptr;
       const bool widen = last && perm_out != nullptr;
@@ -1139,7 +1141,7 @@ static int sort_impl(const char* who, const int64_t* keys, const uint32_t* pay_i
   }
 
   for (int pass = 0; pass < p.passes; ++pass) {
-    const int shift = 8 * pass;
+    const int shift = first_bit + 8 * pass;
     const bool last = pass == p.passes - 1;
     const bool iota_payload = pass == 0 && pay_in == nullptr;
     const bool widen = last && perm_out != nullptr;  // int64 permutation output
@@ -1216,6 +1218,24 @@ int psa_sort_pairs_u32(const int64_t* keys, const void* payload, int64_t n,
   return sort_impl("psa_sort_pairs_u32", keys, static_cast<const uint32_t*>(payload), n,
                    max_value, sorted_out, nullptr, static_cast<uint32_t*>(payload_out),
                    workspace, workspace_bytes, psa::as_stream(stream));
+}
+
+int psa_sort_pairs_u32_field(const int64_t* keys, const void* payload, int64_t n, int first_bit,
+                             int64_t max_value, int64_t* sorted_out, void* payload_out,
+                             void* workspace, size_t workspace_bytes, psa_stream_t stream) {
+  PSA_REQUIRE(n >= 0, "negative size");
+  if (n == 0) return PSA_OK;
+  PSA_REQUIRE(keys && payload && sorted_out && payload_out, "NULL pointer");
+  PSA_REQUIRE(max_value >= 0 && first_bit >= 0 && first_bit < 64, "bad bit field");
+  PSA_REQUIRE(first_bit + bits_for(max_value) <= 64, "bit field runs past bit 63");
+  PSA_REQUIRE(psa::aligned(payload, 4) && psa::aligned(payload_out, 4), "payload must be 4-byte aligned");
+  if (n >= (1ll << 31)) {
+    psa::set_error("psa_sort_pairs_u32_field: n >= 2^31 not supported by this build");
+    return PSA_ERR_UNSUPPORTED;
+  }
+  return sort_impl("psa_sort_pairs_u32_field", keys, static_cast<const uint32_t*>(payload), n,
+                   max_value, sorted_out, nullptr, static_cast<uint32_t*>(payload_out),
+                   workspace, workspace_bytes, psa::as_stream(stream), first_bit);
 }
 
 }  // extern "C"

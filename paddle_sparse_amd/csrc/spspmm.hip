@@ -41,7 +41,8 @@ spspmm_expand_kernel(const int64_t* __restrict__ rowA, const int64_t* __restrict
   if (p >= total) return;
   const int64_t e = owner[p];
   const int64_t q = rowptrB[colA[e]] + (p - offsets[e]);
-  keys[p] = rowA[e] * n + colB[q];
+  // n < 0: packed form (inner << 32) | outer, for the walk over the CSC views
+  keys[p] = n < 0 ? ((colB[q] << 32) | rowA[e]) : rowA[e] * n + colB[q];
   if (vals) vals[p] = (valA ? valA[e] : T(1)) * (valB ? valB[q] : T(1));
 }
 
@@ -82,7 +83,7 @@ int psa_spspmm_expand(int dtype, const int64_t* rowA, const int64_t* colA,
                       const void* valB, const int64_t* offsets, const int64_t* owner,
                       int64_t total, int64_t n, int64_t* keys, void* vals,
                       psa_stream_t stream) {
-  PSA_REQUIRE(total >= 0 && n >= 0, "negative size");
+  PSA_REQUIRE(total >= 0, "negative size");
   if (total == 0) return PSA_OK;
   PSA_REQUIRE(rowA && colA && rowptrB && colB && offsets && owner && keys, "NULL pointer");
   hipStream_t s = psa::as_stream(stream);

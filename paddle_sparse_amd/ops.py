@@ -216,6 +216,25 @@ def sort_pairs(keys: torch.Tensor, payload: torch.Tensor, max_value: Optional[in
     return out_keys, out_pay
 
 
+def sort_pairs_field(keys: torch.Tensor, payload: torch.Tensor, first_bit: int, max_value: int
+                     ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Stable sort of (key, 4-byte payload) pairs by the bit field
+    (key >> first_bit) < max_value only; the low bits ride inside the key."""
+    keys = _index(keys, "keys")
+    _gpu(payload, "payload")
+    if payload.dim() != 1 or payload.element_size() != 4 or payload.numel() != keys.numel():
+        raise ValueError("payload must be 1-D, 4 bytes per element, same length as keys")
+    payload = payload.contiguous()
+    n, max_value = keys.numel(), max(int(max_value), 1)
+    out_keys, out_pay = torch.empty_like(keys), torch.empty_like(payload)
+    lib = _lib.load()
+    ws = _workspace(lib.psa_index_sort_workspace_bytes(n, max_value), keys.device)
+    with torch.cuda.device(keys.device):
+        check(lib.psa_sort_pairs_u32_field(_ptr(keys), _ptr(payload), n, int(first_bit), max_value,
+                                           _ptr(out_keys), _ptr(out_pay), _ptr(ws), ws.numel(), _stream()))
+    return out_keys, out_pay
+
+
 def coalesce_small_max() -> int:
     return int(_lib.load().psa_coalesce_small_max())
 

@@ -60,6 +60,22 @@ print(f"A @ A, A = {M} x {M} with {E} entries: {total} products -> {idxC.shape[1
 for name, t in (("count", t_cnt), ("offsets (scan)", t_scan), ("owner (ptr2ind)", t_own), ("expand", t_exp),
                 ("sort_pairs", t_sort), ("unique", t_uniq), ("segment sum", t_seg)):
     print(f"  {name:18s} {t:8.3f} ms")
+print("  (the row-order walk above sorts on row * n + col; the production path for 4-byte values walks the")
+print("   CSC views and sorts on the row field of (row << 32 | col) only:)")
+from paddle_sparse_amd import SparseTensor  # noqa: E402
+
+A = SparseTensor(row=row, col=col, value=val, sparse_sizes=(M, M), is_sorted=True, trust_data=True)
+t_csc, (colptr, row_csc, val_csc) = gpu_ms(lambda: SparseTensor(row=row, col=col, value=val, sparse_sizes=(M, M),
+                                                                 is_sorted=True, trust_data=True).csc())
+col_of = ops.ptr2ind(colptr, E)
+t_exp2, (keys2, vals2) = gpu_ms(lambda: ops.spspmm_expand(col_of, row_csc, val_csc, colptr, row_csc, val_csc, offsets,
+                                                          ops.ptr2ind(ops.count2ptr(ops.spspmm_count(row_csc, colptr)), total),
+                                                          total, -1, torch.float32))
+t_sort2, (skeys2, _) = gpu_ms(lambda: ops.sort_pairs_field(keys2, vals2, 32, M))
+t_uniq2, _ = gpu_ms(lambda: ops.unique_sorted(skeys2, 1 << 32))
+for name, t in (("CSC view of A", t_csc), ("count+scan+owner+expand", t_exp2), ("sort on row field", t_sort2),
+                ("unique (packed)", t_uniq2)):
+    print(f"  {name:24s} {t:8.3f} ms")
 print(f"spspmm total: {t_all:8.3f} ms  {total / t_all / 1e6:8.2f} GProducts/s")
 
 # CPU oracle on the first rows of A (x the full B), single thread

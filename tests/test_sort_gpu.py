@@ -83,6 +83,30 @@ def test_sort_pairs_matches_perm_gather(n, max_value, dtype):
     assert torch.equal(spay.cpu(), pay.cpu()[torch.from_numpy(ref)])
 
 
+@pytest.mark.parametrize("n,first_bit,max_value", [(1, 32, 7), (5000, 32, 1), (100000, 32, 1 << 20), (2000003, 32, 2_000_000),
+                                                   (300001, 20, 1 << 30), (300001, 0, 1 << 40), (70000, 40, 1 << 24)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.int32])
+def test_sort_pairs_on_a_bit_field(n, first_bit, max_value, dtype):
+    """psa_sort_pairs_u32_field: stable order by (key >> first_bit); the low bits
+    ride along unsorted.  first_bit = 0 is sort_pairs."""
+    from paddle_sparse_amd import ops
+
+    rng = np.random.default_rng(n + first_bit)
+    hi = rng.integers(0, max_value, n, dtype=np.int64)
+    lo = rng.integers(0, 1 << first_bit, n, dtype=np.int64) if first_bit else np.zeros(n, np.int64)
+    keys = (hi << first_bit) | lo
+    pay = torch.from_numpy(rng.integers(-1000, 1000, n).astype(np.int32)).cuda().to(dtype)
+    skeys, spay = ops.sort_pairs_field(dev(keys), pay, first_bit, max_value)
+    ref = np.argsort(hi, kind="stable")
+    assert np.array_equal(skeys.cpu().numpy(), keys[ref])
+    assert torch.equal(spay.cpu(), pay.cpu()[torch.from_numpy(ref)])
+    if first_bit == 0:
+        k2, p2 = ops.sort_pairs(dev(keys), pay, max_value)
+        assert torch.equal(k2, skeys) and torch.equal(p2, spay)
+    with pytest.raises(Exception):
+        ops.sort_pairs_field(dev(keys), pay, 60, 1 << 10)
+
+
 def test_single_sweep_lookback_under_uneven_load():
     """The production sort hands digit counts between workgroups inside one
     launch (decoupled look-back).  Exercise it with a second stream keeping the
