@@ -39,7 +39,8 @@ _PUBLIC = (
     ("mul", ("mul", "mul_", "mul_nnz", "mul_nnz_")),
     ("reduce", ("sum", "mean", "min", "max")),
     ("cat", ("cat",)),
-    ("convert", ("to_torch_sparse", "from_torch_sparse", "to_scipy", "from_scipy", "eye")),
+    ("convert", ("to_torch_sparse", "from_torch_sparse", "to_paddle_sparse", "from_paddle_sparse", "to_scipy",
+                 "from_scipy", "eye")),
     ("coalesce", ("coalesce",)),
     ("transpose", ("transpose", "t")),
     ("matmul", ("spmm", "matmul")),

@@ -39,6 +39,12 @@ def from_torch_sparse(A: torch.Tensor) -> IndexValue:
     return A.indices().detach(), A.values()
 
 
+# The reference names these after its host framework's sparse COO type
+# (convert.py:9-14); callers written against it keep working.
+to_paddle_sparse = to_torch_sparse
+from_paddle_sparse = from_torch_sparse
+
+
 def to_scipy(index: torch.Tensor, value: torch.Tensor, m: int, n: int) -> scipy.sparse.coo_matrix:
     """Host tensors only, as in the reference (convert.py:18): move GPU data to
     the CPU first."""

@@ -81,6 +81,10 @@ def test_convert_round_trips_on_the_host():
     assert out[0].tolist() == index.tolist() and out[1].tolist() == value.tolist()
     out = from_torch_sparse(to_torch_sparse(index, value, 3, 3).coalesce())
     assert out[0].tolist() == index.tolist() and out[1].tolist() == value.tolist()
+    import paddle_sparse_amd as psa
+
+    # the reference's names for the host framework's COO type (convert.py:9-14)
+    assert psa.to_paddle_sparse is to_torch_sparse and psa.from_paddle_sparse is from_torch_sparse
     idx, val = eye(4, dtype=torch.float32)
     assert idx.tolist() == [[0, 1, 2, 3]] * 2 and val.tolist() == [1.0] * 4
     with pytest.raises(ValueError):
