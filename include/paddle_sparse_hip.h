@@ -267,6 +267,20 @@ int psa_sort_pairs_u32_field(const int64_t* keys, const void* payload, int64_t n
                              void* workspace, size_t workspace_bytes,
                              psa_stream_t stream);
 
+/* Stable merge of two SORTED key arrays: merged_out[na + nb] is what a stable
+ * sort of the concatenation [a; b] would give (a's entry first on equal keys)
+ * — the "cat, then argsort" of add.py:30-47, mul.py:57-73 and tensor.py:415-451
+ * when both halves are sorted already, in one streaming launch (merge path)
+ * instead of ceil(bits / 8) radix passes.  source_out (or NULL) receives the index into
+ * the concatenation every merged key came from (i for a[i], na + j for b[j]) —
+ * the permutation psa_index_sort would return; payload_out (or NULL; then
+ * payload_a / payload_b are ignored) receives the 4-byte payloads in merged
+ * order.  Unsorted inputs give an unspecified (memory-safe) order. */
+int psa_merge_sorted(const int64_t* a, int64_t na, const int64_t* b, int64_t nb,
+                     const void* payload_a, const void* payload_b,
+                     int64_t* merged_out, int64_t* source_out, void* payload_out,
+                     psa_stream_t stream);
+
 /* Small inputs (n <= psa_coalesce_small_max(), 40960): the sort by (row, col)
  * AND the run-length structure of a coalesce (storage.py:158-171 + 455-470) in
  * one launch of one workgroup — at BASELINE config 1 (10 k entries) the

@@ -57,6 +57,8 @@ SIGNATURES = {
                                    c_void_p, c_size_t, c_void_p]),
     "psa_sort_pairs_u32_field": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p, c_void_p,
                                          c_void_p, c_size_t, c_void_p]),
+    "psa_merge_sorted": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p]),
     "psa_sort_set_variant": (c_int, [c_int]),
     "psa_coalesce_small_max": (c_int64, []),
     "psa_coalesce_small_workspace_bytes": (c_size_t, [c_int64]),

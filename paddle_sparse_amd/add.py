@@ -1,8 +1,9 @@
 """add — paddle_sparse/add.py:12-100.
 
-sparse + sparse is "concatenate and coalesce" in the reference (add.py:30-47);
-here the concatenation feeds the fused sort / run-length / segmented-add chain
-of coalesce.py directly.  sparse + dense vector broadcasts along rows or
+sparse + sparse is "concatenate and coalesce" in the reference (add.py:30-47).
+Both operands are in (row, col) order already, so the two key streams are
+MERGED (ops.merge_sorted) instead of sorted, then run lengths + segmented add
+as in coalesce.py; tiny inputs take the one-workgroup coalesce instead.  sparse + dense vector broadcasts along rows or
 columns through the HIP row gather (elementwise.py).
 """
 from __future__ import annotations
@@ -10,7 +11,7 @@ from __future__ import annotations
 import torch
 
 from . import elementwise as ew
-from .coalesce import _coalesce_sorted_stream
+from .coalesce import _ONE_WORKGROUP_BELOW, _coalesce_sorted_stream, _coalesce_two_sorted
 from .tensor import SparseTensor
 
 _add_dense = ew.dense_variant("add", inplace=False)
@@ -24,9 +25,13 @@ def _add_sparse(a: SparseTensor, b: SparseTensor) -> SparseTensor:
     has values only when both operands do (add.py:37-39)."""
     shape = (max(a.size(0), b.size(0)), max(a.size(1), b.size(1)))
     (ra, ca, va), (rb, cb, vb) = a.coo(), b.coo()
-    both = None if va is None or vb is None else torch.cat([va, vb], dim=0)
-    row, col, both = _coalesce_sorted_stream(torch.cat([ra, rb]), torch.cat([ca, cb]), both,
-                                             shape[0], shape[1], "sum")
+    if ra.numel() + rb.numel() > _ONE_WORKGROUP_BELOW:
+        # both operands are in (row, col) order: merge, don't sort
+        row, col, both = _coalesce_two_sorted(ra, ca, va, rb, cb, vb, shape[1], "sum")
+    else:
+        both = None if va is None or vb is None else torch.cat([va, vb], dim=0)
+        row, col, both = _coalesce_sorted_stream(torch.cat([ra, rb]), torch.cat([ca, cb]), both,
+                                                 shape[0], shape[1], "sum")
     return SparseTensor(row=row, col=col, value=both, sparse_sizes=shape, is_sorted=True, trust_data=True)
 
 

@@ -59,6 +59,32 @@ def _coalesce_sorted_stream(row, col, value, m: int, n: int, op: str):
     return new_row, new_col, value
 
 
+def _coalesce_two_sorted(row_a, col_a, value_a, row_b, col_b, value_b, n: int, op: str):
+    """Coalesce of the concatenation [A; B] when A and B are each in (row, col)
+    order already (add.py:30-47, tensor.py:415-451): a stable merge of the two
+    key streams (ops.merge_sorted, two streaming launches) stands in for the
+    radix sort; run lengths and the segmented reduce are the usual ones, and
+    the terms of every entry keep the order a stable sort would give them.
+    The result has values only when both operands do."""
+    keys_a, _ = ops.make_keys(row_a, col_a, n)
+    keys_b, _ = ops.make_keys(row_b, col_b, n)
+    total = keys_a.numel() + keys_b.numel()
+    has_value = value_a is not None and value_b is not None
+    rides = (has_value and value_a.dim() == 1 and value_b.dim() == 1 and value_a.element_size() == 4
+             and value_a.dtype == value_b.dtype)
+    keys, source, value = ops.merge_sorted(keys_a, keys_b, value_a.contiguous() if rides else None,
+                                           value_b.contiguous() if rides else None,
+                                           want_source=has_value and not rides)
+    count, ptr, row, col = ops.unique_sorted(keys, n)
+    if not has_value:
+        return row, col, None
+    if rides:
+        return row, col, (ops.segment_csr(value, ptr, op) if count < total else value)
+    both = torch.cat([value_a, value_b], dim=0)
+    return row, col, (ops.segment_csr(both, ptr, op, perm=source) if count < total
+                      else ops.gather_rows(both, source))
+
+
 def _stack_index(row: torch.Tensor, col: torch.Tensor) -> torch.Tensor:
     """stack([row, col]) (coalesce.py:29) without the copy when row and col are
     already the two rows of one [2, nnz] buffer (ops.unique_sorted writes them

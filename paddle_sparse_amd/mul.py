@@ -2,8 +2,9 @@
 
 sparse * sparse keeps the entries present in BOTH (coalesced) operands: the
 reference concatenates, argsorts the keys and multiplies neighbours with equal
-keys (mul.py:57-73).  Same steps here on the HIP radix sort; with both inputs
-coalesced a key occurs at most twice, and the stable sort puts A's entry first.
+keys (mul.py:57-73).  Both key streams are sorted already, so a stable merge
+(ops.merge_sorted) replaces the sort; with both inputs coalesced a key occurs
+at most twice, and the merge puts A's entry first.
 """
 from __future__ import annotations
 
@@ -27,9 +28,13 @@ def _mul_sparse(a: SparseTensor, b: SparseTensor) -> SparseTensor:
     if va is None or vb is None:
         raise ValueError("Both sparse tensors must contain values")
     M, N = max(a.size(0), b.size(0)), max(a.size(1), b.size(1))
-    keys, _ = ops.make_keys(torch.cat([ra, rb]), torch.cat([ca, cb]), N)
-    keys, perm = ops.index_sort(keys, M * N, with_sorted_inputs=True)
-    value = ops.gather_rows(torch.cat([va, vb], dim=0), perm)
+    keys_a, _ = ops.make_keys(ra, ca, N)
+    keys_b, _ = ops.make_keys(rb, cb, N)
+    rides = va.dim() == 1 and vb.dim() == 1 and va.element_size() == 4 and va.dtype == vb.dtype
+    keys, source, value = ops.merge_sorted(keys_a, keys_b, va.contiguous() if rides else None,
+                                           vb.contiguous() if rides else None, want_source=not rides)
+    if not rides:
+        value = ops.gather_rows(torch.cat([va, vb], dim=0), source)
     first = (keys[1:] == keys[:-1]).nonzero().view(-1)  # A's entry of every key both operands hold
     row, col = ops.split_keys(keys[first], N)
     return SparseTensor(row=row, col=col, value=value[first] * value[first + 1], sparse_sizes=(M, N),

@@ -235,6 +235,33 @@ def sort_pairs_field(keys: torch.Tensor, payload: torch.Tensor, first_bit: int, 
     return out_keys, out_pay
 
 
+def merge_sorted(a: torch.Tensor, b: torch.Tensor, payload_a: Optional[torch.Tensor] = None,
+                 payload_b: Optional[torch.Tensor] = None, want_source: bool = True):
+    """Stable merge of two SORTED int64 key arrays (a's entry first on ties):
+    what index_sort(cat([a, b])) returns, without the sort.  Returns (merged,
+    source | None, payload | None); source indexes the concatenation, payload
+    (when both 4-byte 1-D payload arrays are given) is cat([pa, pb])[source]."""
+    a, b = _index(a, "a"), _index(b, "b")
+    na, nb = a.numel(), b.numel()
+    pay_out = None
+    if payload_a is not None or payload_b is not None:
+        for name, p, n in (("payload_a", payload_a, na), ("payload_b", payload_b, nb)):
+            if p is None:
+                raise ValueError("merge_sorted: give both payloads or neither")
+            _gpu(p, name)
+            if p.dim() != 1 or p.element_size() != 4 or p.numel() != n or not p.is_contiguous():
+                raise ValueError(f"{name} must be contiguous, 1-D, 4 bytes per element, one per key")
+        if payload_a.dtype != payload_b.dtype:
+            raise ValueError("merge_sorted: payload dtypes differ")
+        pay_out = torch.empty(na + nb, dtype=payload_a.dtype, device=a.device)
+    merged = torch.empty(na + nb, dtype=torch.int64, device=a.device)
+    source = torch.empty(na + nb, dtype=torch.int64, device=a.device) if want_source else None
+    with torch.cuda.device(a.device):
+        check(_lib.load().psa_merge_sorted(_ptr(a), na, _ptr(b), nb, _ptr(payload_a), _ptr(payload_b),
+                                           _ptr(merged), _ptr(source), _ptr(pay_out), _stream()))
+    return merged, source, pay_out
+
+
 def coalesce_small_max() -> int:
     return int(_lib.load().psa_coalesce_small_max())
 

@@ -19,6 +19,9 @@ import torch
 from . import ops
 from .storage import SparseStorage, get_layout
 
+# to_symmetric: above this many keys the two sorted halves are merged, below they are sorted
+_MERGE_ABOVE = 1 << 16
+
 
 class SparseTensor(object):
     storage: SparseStorage
@@ -254,6 +257,16 @@ class SparseTensor(object):
         N = max(self.size(0), self.size(1))
         row, col, value = self.coo()
         n = row.numel()
+        if 2 * n > _MERGE_ABOVE:
+            # A is in (row, col) order and its CSC view is A^T in (row, col)
+            # order: merge the two sorted streams instead of sorting 2n keys
+            from .coalesce import _coalesce_two_sorted
+
+            colptr, row_csc, value_csc = self.csc()
+            new_row, new_col, value = _coalesce_two_sorted(row, col, value, ops.ptr2ind(colptr, n), row_csc,
+                                                          value_csc, N, reduce)
+            return SparseTensor(row=new_row, col=new_col, value=value, sparse_sizes=(N, N),
+                                is_sorted=True, trust_data=True)
         both_r, both_c = torch.cat([row, col]), torch.cat([col, row])
         keys, _ = ops.make_keys(both_r, both_c, N)
         sorted_keys, perm = ops.index_sort(keys, N * N, with_sorted_inputs=True)

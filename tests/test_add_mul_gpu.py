@@ -96,6 +96,80 @@ def test_add_mul_symmetric_vs_oracle():
         same(A.to_symmetric(reduce), so.to_symmetric(to_oracle(A), reduce))
 
 
+@pytest.mark.parametrize("na,nb,span,seed", [(0, 0, 10, 0), (0, 5, 10, 1), (7, 0, 10, 2), (1, 1, 1, 3), (5000, 3000, 50, 4),
+                                             (100000, 250000, 1 << 40, 5), (300000, 300000, 1000, 6), (2049, 4097, 1 << 20, 7)])
+def test_merge_sorted_is_the_stable_sort_of_the_concatenation(na, nb, span, seed):
+    from paddle_sparse_amd import ops
+
+    rng = np.random.default_rng(seed)
+    a = np.sort(rng.integers(0, span, na, dtype=np.int64))
+    b = np.sort(rng.integers(0, span, nb, dtype=np.int64))
+    pa = torch.from_numpy(rng.standard_normal(na).astype(np.float32)).cuda()
+    pb = torch.from_numpy(rng.standard_normal(nb).astype(np.float32)).cuda()
+    cat = np.concatenate([a, b])
+    ref = np.argsort(cat, kind="stable")
+    merged, source, pay = ops.merge_sorted(idx(a), idx(b), pa, pb)
+    assert np.array_equal(merged.cpu().numpy(), cat[ref])
+    assert np.array_equal(source.cpu().numpy(), ref)
+    assert torch.equal(pay.cpu(), torch.cat([pa, pb]).cpu()[torch.from_numpy(ref)])
+    merged, source, pay = ops.merge_sorted(idx(a), idx(b), want_source=False)
+    assert source is None and pay is None and np.array_equal(merged.cpu().numpy(), cat[ref])
+
+
+def test_merge_sorted_one_sided_and_unsorted_inputs():
+    """All of one stream before / after the other (tiles made of one stream
+    only), long runs of one key, and unsorted input: order unspecified then,
+    but the call must stay inside its buffers and return."""
+    from paddle_sparse_amd import ops
+
+    lo, hi = np.arange(0, 50000, dtype=np.int64), np.arange(10 ** 6, 10 ** 6 + 70001, dtype=np.int64)
+    for a, b in ((lo, hi), (hi, lo), (np.full(30000, 7, np.int64), np.full(41000, 7, np.int64)),
+                 (np.repeat(np.arange(10, dtype=np.int64), 5000), np.repeat(np.arange(5, 15, dtype=np.int64), 3000))):
+        cat = np.concatenate([a, b])
+        ref = np.argsort(cat, kind="stable")
+        merged, source, _ = ops.merge_sorted(idx(a), idx(b))
+        assert np.array_equal(merged.cpu().numpy(), cat[ref]) and np.array_equal(source.cpu().numpy(), ref)
+    rng = np.random.default_rng(0)
+    a, b = rng.integers(0, 1 << 40, 100000, dtype=np.int64), rng.integers(0, 1 << 40, 77777, dtype=np.int64)
+    pa, pb = torch.ones(a.size, device="cuda"), torch.ones(b.size, device="cuda")
+    merged, source, pay = ops.merge_sorted(idx(a), idx(b), pa, pb)
+    torch.cuda.synchronize()
+    assert merged.numel() == a.size + b.size and bool(((pay == 0) | (pay == 1)).all())
+
+
+@pytest.mark.parametrize("dtype,tail", [(torch.float64, ()), (torch.float32, (3,)), (torch.int64, ()), (torch.float16, ())])
+def test_add_mul_symmetric_merge_path_other_value_types(dtype, tail):
+    """Values that cannot ride the merge as a 4-byte payload go through the
+    source index; same results as the numpy oracle, bit for bit."""
+    from oracle import storage_oracle as so
+    from paddle_sparse_amd import SparseTensor
+
+    def make(seed, nnz):
+        rng = np.random.default_rng(seed)
+        key = np.unique(rng.integers(0, 3000 * 2500, nnz))
+        val = rng.integers(-4, 5, (key.size,) + tail).astype(np.float64)
+        val[val == 0] = 1
+        v = torch.from_numpy(val).to(dtype)
+        t = SparseTensor(row=idx(key // 2500), col=idx(key % 2500), value=v.cuda(), sparse_sizes=(3000, 2500))
+        return t, so.Storage(key // 2500, key % 2500, v.numpy() if dtype != torch.float16 else v.float().numpy(),
+                             (3000, 2500), is_sorted=True)
+
+    def same(t, o):
+        row, col, value = t.coo()
+        assert np.array_equal(row.cpu().numpy(), o.row) and np.array_equal(col.cpu().numpy(), o.col)
+        assert np.array_equal(value.cpu().double().numpy(), np.asarray(o.value, dtype=np.float64))
+
+    (A, oa), (B, ob) = make(21, 90000), make(22, 70000)
+    same(A + B, so.add(oa, ob))
+    if not tail:
+        same(A * B, so.mul(oa, ob))
+    for reduce in ("sum", "max"):
+        same(A.to_symmetric(reduce), so.to_symmetric(oa, reduce))
+    # a value-less operand: the union has no values (add.py:37-39)
+    C = A + B.set_value(None, layout="coo")
+    assert not C.has_value() and C.nnz() == so.add(oa, ob).row.size
+
+
 def test_to_symmetric_kat(kats):
     from paddle_sparse_amd import SparseTensor
 
