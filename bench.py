@@ -123,9 +123,10 @@ def main() -> None:
     ap.add_argument("--op", default="spmm_sum", choices=["spmm_sum", "spmm_mean", "spmm_max", "spmm_min"])
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    ap.add_argument("--feature-chunks", type=int, default=1,
+    ap.add_argument("--feature-chunks", type=int, default=0,
                     help="N > 1: all-gather B in this many column slices and run the SpMM of a "
-                         "slice under the exchange of the next ones (default 1: one all-gather)")
+                         "slice under the exchange of the next ones (1: one all-gather, then the SpMM; "
+                         "default 0: time both forms during warmup and keep the faster one)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -169,11 +170,13 @@ def main() -> None:
     B_local = torch.randn(M, F, generator=g, device=device)
     ops.spmm_set_variant(args.variant)
 
+    chunks = 1
     if use_dist:
         from paddle_sparse_amd.distributed import RowPartitionedSpMM, RowShard
 
         op = RowPartitionedSpMM(RowShard(rowptr, col, val, rank * M, (rank + 1) * M, N), reduce=reduce)
-        step = lambda: op(B_local, feature_chunks=args.feature_chunks)  # noqa: E731  all-gather(B) + local HIP SpMM
+        chunks = args.feature_chunks
+        step = lambda: op(B_local, feature_chunks=chunks)  # noqa: E731  all-gather(B) + local HIP SpMM
         B_full = op.gather(B_local)
     else:
         fn = getattr(ops, args.op)
@@ -188,6 +191,29 @@ def main() -> None:
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
+
+    # Two forms of the same step exist (one all-gather then the SpMM; or column
+    # slices whose exchanges overlap the SpMM of earlier slices).  Which is faster
+    # depends on the fabric, so — untimed, before the warmup — both run a few
+    # steps, the slowest rank's times decide, and every rank keeps the same form.
+    overlap_chunks = 4
+    tune_ms = {}
+    if use_dist and chunks == 0:
+        candidates = [1] + ([overlap_chunks] if F % overlap_chunks == 0 else [])
+        spent = []
+        for c in candidates:
+            op(B_local, feature_chunks=c)
+            sync_all()
+            t_c = time.perf_counter()
+            for _ in range(3):
+                op(B_local, feature_chunks=c)
+            sync_all()
+            spent.append((time.perf_counter() - t_c) / 3)
+        spent_t = torch.tensor(spent, dtype=torch.float64, device=device)
+        dist.all_reduce(spent_t, op=dist.ReduceOp.MAX)
+        spent = [float(x) for x in spent_t]
+        chunks = candidates[spent.index(min(spent))]
+        tune_ms = {str(c): round(x * 1e3, 4) for c, x in zip(candidates, spent)}
 
     for _ in range(args.warmup):
         step()
@@ -205,24 +231,24 @@ def main() -> None:
     kern_ms = event_ms(local_kernel, args.steps)
     gather_ms = event_ms(lambda: op.gather(B_local), max(3, args.steps // 5)) if use_dist else 0.0
 
-    # Third figure SURVEY.md §8(e) asks for: the same step with B cut into column
-    # slices whose all-gathers are queued up front, so the SpMM of slice c runs
-    # under the exchange of the later slices.  Reported beside `value`, never as it.
-    overlap_s, overlap_steps, overlap_chunks = 0.0, 0, 4
-    if use_dist and args.feature_chunks <= 1 and F % overlap_chunks == 0:
-        overlap_steps = max(3, args.steps // 5)
-        op(B_local, feature_chunks=overlap_chunks)
+    # SURVEY.md §8(e) asks for both end-to-end figures: the form that was NOT
+    # timed above runs a few steps here, so the line carries serial and overlapped.
+    other_chunks = overlap_chunks if chunks <= 1 else 1
+    other_s, other_steps = 0.0, 0
+    if use_dist and F % overlap_chunks == 0:
+        other_steps = max(3, args.steps // 5)
+        op(B_local, feature_chunks=other_chunks)
         sync_all()
         t1 = time.perf_counter()
-        for _ in range(overlap_steps):
-            op(B_local, feature_chunks=overlap_chunks)
+        for _ in range(other_steps):
+            op(B_local, feature_chunks=other_chunks)
         sync_all()
-        overlap_s = time.perf_counter() - t1
+        other_s = time.perf_counter() - t1
 
-    t = torch.tensor([elapsed, kern_ms, gather_ms, overlap_s], dtype=torch.float64, device=device)
+    t = torch.tensor([elapsed, kern_ms, gather_ms, other_s], dtype=torch.float64, device=device)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, kern_ms, gather_ms, overlap_s = (float(x) for x in t)
+    elapsed, kern_ms, gather_ms, other_s = (float(x) for x in t)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -249,7 +275,9 @@ def main() -> None:
             "config": {
                 "workload": f"{args.op} fwd, uniform random CSR {M}x{N} per GPU, nnz={nnz} per GPU, "
                             f"dense F={F} fp32 (BASELINE config 3 per GPU)"
-                            + (f"; + RCCL all-gather of B ({N}x{F}) every step" if use_dist else ""),
+                            + (f"; + RCCL all-gather of B ({N}x{F}) every step"
+                               + (f", in {chunks} column slices overlapped with the SpMM" if chunks > 1 else "")
+                               if use_dist else ""),
                 "rows_per_gpu": M, "nnz_per_gpu": nnz, "feat": F, "index_dtype": "int64",
                 "variant": args.variant,
             },
@@ -267,18 +295,21 @@ def main() -> None:
             },
         }
         if use_dist:
+            other = round(world * nnz / (other_s / other_steps) / 1e9, 4) if other_steps else None
+            serial, overlapped = (value, other) if chunks <= 1 else (other, value)
             line["multi_gpu"] = {
                 "allgather_ms": round(gather_ms, 4),
-                "feature_chunks": args.feature_chunks,
+                "feature_chunks": chunks,
+                "feature_chunks_chosen_by": "flag" if args.feature_chunks else "warmup timing (ms per step by form)",
+                "warmup_ms_per_step_by_feature_chunks": tune_ms or None,
                 "allgather_bytes_received_per_rank": (world - 1) * M * F * 4,
                 "spmm_only_aggregate_gedges_per_s": round(world * nnz / (kern_ms * 1e-3) / 1e9, 4),
-                "end_to_end_serial_gedges_per_s": round(value, 4),
-                "end_to_end_overlapped_gedges_per_s": (
-                    round(world * nnz / (overlap_s / overlap_steps) / 1e9, 4) if overlap_steps else None),
-                "overlapped_ms_per_step": round(overlap_s / overlap_steps * 1e3, 4) if overlap_steps else None,
-                "overlapped_feature_chunks": overlap_chunks if overlap_steps else None,
-                "note": "value counts the all-gather of B inside every step; spmm_only_* is the "
-                        "local-kernel rate with B already assembled",
+                "end_to_end_serial_gedges_per_s": None if serial is None else round(serial, 4),
+                "end_to_end_overlapped_gedges_per_s": None if overlapped is None else round(overlapped, 4),
+                "overlapped_feature_chunks": overlap_chunks,
+                "note": "value counts the exchange of B inside every step, in the form named by feature_chunks "
+                        "(1 = one all-gather then the SpMM); spmm_only_* is the local-kernel rate with B "
+                        "already assembled",
             }
         if not args.no_cpu and args.op == "spmm_sum" and world == 1:  # CPU leg: N = 1 only
             info, ref, rows = cpu_baseline(rowptr, col, val, B_full)
