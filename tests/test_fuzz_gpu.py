@@ -139,3 +139,39 @@ def test_sample_adj_and_spspmm_random_shapes(seed):
     ref_i, ref_v = oracle.spspmm(iA, vA, iB, vB, M, N, P)
     got_i, got_v = ps.spspmm(idx(iA), torch.from_numpy(vA).cuda(), idx(iB), torch.from_numpy(vB).cuda(), M, N, P)
     assert np.array_equal(got_i.cpu().numpy(), ref_i) and np.array_equal(got_v.cpu().numpy(), ref_v), (M, N, P)
+
+
+@pytest.mark.parametrize("seed", range(12 * SCALE))
+def test_add_mul_to_symmetric_random_shapes(seed):
+    """A + B, A * B and to_symmetric against the numpy oracle, bit for bit —
+    sizes on both sides of the one-workgroup / merge-path switch, operands of
+    different shapes, empty operands, overlapping and disjoint patterns."""
+    from paddle_sparse_amd import SparseTensor
+
+    rng = np.random.default_rng(4000 + seed)
+    dtype = [np.float32, np.float64, np.int32, np.int64][seed % 4]
+
+    def make():
+        M, N, row, col = random_graph(rng)
+        if seed % 3 == 0:  # bigger operands: past the merge-path threshold for to_symmetric too
+            extra = np.unique(rng.integers(0, M * N, 60_000))
+            key = np.union1d(row * N + col, extra)
+            row, col = key // N, key % N
+        val = rng.integers(-3, 4, row.size).astype(dtype)
+        val[val == 0] = 1
+        t = SparseTensor(row=idx(row), col=idx(col), value=torch.from_numpy(val).cuda(), sparse_sizes=(M, N))
+        return t, so.Storage(row, col, val, (M, N), is_sorted=True)
+
+    def same(t, o, what):
+        row, col, value = t.coo()
+        assert t.sparse_sizes() == (o.M, o.N), what
+        assert np.array_equal(row.cpu().numpy(), o.row) and np.array_equal(col.cpu().numpy(), o.col), what
+        assert np.array_equal(value.cpu().numpy(), o.value), what
+
+    (A, oa), (B, ob) = make(), make()
+    same(A + B, so.add(oa, ob), "add")
+    same(A + A, so.add(oa, oa), "add self")
+    same(A * B, so.mul(oa, ob), "mul")
+    same(A * A, so.mul(oa, oa), "mul self")
+    for reduce in ("sum", "min", "max"):
+        same(A.to_symmetric(reduce), so.to_symmetric(oa, reduce), f"to_symmetric {reduce}")
