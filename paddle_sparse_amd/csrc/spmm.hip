@@ -57,6 +57,38 @@ __device__ __forceinline__ void store_vec(float* p, const float (&src)[VEC]) {
   *reinterpret_cast<T*>(p) = v;
 }
 
+// Non-temporal stores for the outputs (out, arg_out, arg_bytes, grad_value): they
+// are written once and never read by the writing kernel, and marking them so
+// keeps them from displacing rows of the dense operand in L2 / the Infinity
+// Cache.  Measured on config 3 (one process, interleaved, variant 17 = ordinary
+// stores): spmm_sum 1.780 -> 1.660 ms (0.81 -> 0.87 of the HBM peak); marking
+// the col / value loads the same way changed nothing (1.780 vs 1.781 ms).
+template <int VEC>
+__device__ __forceinline__ void store_vec_nt(float* p, const float (&src)[VEC]) {
+  if constexpr (VEC == 1) {
+    __builtin_nontemporal_store(src[0], p);
+  } else {
+    typedef float V __attribute__((ext_vector_type(VEC)));
+    V v;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = src[i];
+    __builtin_nontemporal_store(v, reinterpret_cast<V*>(p));
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_arg_nt(int64_t* p, const int64_t (&src)[VEC]) {
+  if constexpr (VEC == 1) {
+    __builtin_nontemporal_store(src[0], p);
+  } else {
+    typedef long V __attribute__((ext_vector_type(VEC)));
+    V v;
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) v[i] = src[i];
+    __builtin_nontemporal_store(v, reinterpret_cast<V*>(p));
+  }
+}
+
 __device__ __forceinline__ int64_t shfl_i64(int64_t x, int src) {
   return __shfl(static_cast<long long>(x), src);
 }
@@ -115,6 +147,7 @@ struct MaskArgs {
   uint8_t* arg_bytes_out = nullptr;  // M_PLAIN min/max: also store arg_out as row-local bytes (see M_MASK)
   const float* row_scale = nullptr;  // M_CSC, mean: 1 / max(deg(r), 1) per CSR row, folded into both gradients
   int xcd_rows = 0;                  // row role: give each XCD one contiguous eighth of the rows
+  int temporal_out = 0;              // A/B hook (variant 17): ordinary instead of non-temporal output stores
 };
 
 // Reduce edges [s, e) of one row into acc/arg: LPR lanes x VEC floats cover the
@@ -231,7 +264,7 @@ __device__ __forceinline__ void reduce_edge_range(
           // 20 M edges than this store plus the caller's gather through csc2csr.)
           const int slot = j + (l % U) * G + g;  // < 64
           const float scale = MODE == M_CSC ? __shfl(s_l, slot) : 1.f;
-          if (l < U && slot < n) m.grad_value[base + slot] = dot[0] * scale;
+          if (l < U && slot < n) __builtin_nontemporal_store(dot[0] * scale, m.grad_value + base + slot);
         }
       }
 #pragma unroll
@@ -323,10 +356,9 @@ spmm_row_kernel(const int64_t* __restrict__ rowptr,
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
       }
-#pragma unroll
-      for (int i = 0; i < VEC; ++i) arg_out[row * K + k0 + i] = arg[i];
+      store_arg_nt<VEC>(arg_out + row * K + k0, arg);
     }
-    store_vec<VEC>(out + row * K + k0, acc);
+    store_vec_nt<VEC>(out + row * K + k0, acc);
   }
 }
 
@@ -455,10 +487,9 @@ spmm_rows_kernel(const int64_t* __restrict__ rowptr,
 #pragma unroll
           for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
         }
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) arg_out[row * K + k0 + i] = arg[i];
+        store_arg_nt<VEC>(arg_out + row * K + k0, arg);
       }
-      store_vec<VEC>(out + row * K + k0, acc);
+      store_vec_nt<VEC>(out + row * K + k0, acc);
     }
   }
 }
@@ -597,8 +628,12 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
       }
+      if (mask.temporal_out) {
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) arg_out[row * K + k0 + i] = arg[i];
+        for (int i = 0; i < VEC; ++i) arg_out[row * K + k0 + i] = arg[i];
+      } else {
+        store_arg_nt<VEC>(arg_out + row * K + k0, arg);
+      }
       if (VEC == 4 && mask.arg_bytes_out) {  // the backward's 1-byte form, for free while arg is in registers
         uint32_t packed = 0;
 #pragma unroll
@@ -606,10 +641,11 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
           const uint32_t b = deg > 255 ? 255u : static_cast<uint32_t>((arg[i] - s) & 255);
           packed |= b << (8 * i);
         }
-        *reinterpret_cast<uint32_t*>(mask.arg_bytes_out + row * K + k0) = packed;
+        __builtin_nontemporal_store(packed, reinterpret_cast<uint32_t*>(mask.arg_bytes_out + row * K + k0));
       }
     }
-    store_vec<VEC>(out + row * K + k0, acc);
+    if (mask.temporal_out) store_vec<VEC>(out + row * K + k0, acc);
+    else store_vec_nt<VEC>(out + row * K + k0, acc);
   }
 }
 
@@ -654,11 +690,11 @@ spmm_long_combine_kernel(const int64_t* __restrict__ rowptr, int64_t K, int mean
       if (RED == R_SUM) {
         if (mean) acc = acc / static_cast<float>(deg);
       } else {
-        arg_out[ent.row * K + k] = arg;
+        __builtin_nontemporal_store(arg, arg_out + ent.row * K + k);
         if (arg_bytes)
           arg_bytes[ent.row * K + k] = deg > 255 ? uint8_t{255} : static_cast<uint8_t>(arg - rowptr[ent.row]);
       }
-      out[ent.row * K + k] = acc;
+      __builtin_nontemporal_store(acc, out + ent.row * K + k);
     }
   }
 }
@@ -746,8 +782,7 @@ spmm_multirow_kernel(const int64_t* __restrict__ rowptr,
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
     }
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) arg_out[row * K + k0 + i] = arg[i];
+    store_arg_nt<VEC>(arg_out + row * K + k0, arg);
     if (VEC == 4 && arg_bytes) {  // row-local byte form for the one-pass backward (see MaskArgs)
       uint32_t packed = 0;
 #pragma unroll
@@ -755,10 +790,10 @@ spmm_multirow_kernel(const int64_t* __restrict__ rowptr,
         const uint32_t b = deg > 255 ? 255u : static_cast<uint32_t>((arg[i] - s) & 255);
         packed |= b << (8 * i);
       }
-      *reinterpret_cast<uint32_t*>(arg_bytes + row * K + k0) = packed;
+      __builtin_nontemporal_store(packed, reinterpret_cast<uint32_t*>(arg_bytes + row * K + k0));
     }
   }
-  store_vec<VEC>(out + row * K + k0, acc);
+  store_vec_nt<VEC>(out + row * K + k0, acc);
 }
 
 int g_variant = 0;
@@ -828,6 +863,7 @@ int launch_fused(int red, const int64_t* rowptr, const int64_t* col, const float
   const dim3 cgrid(kLongBlocks), cblock(psa::kLongThreads);
   MaskArgs plain;
   plain.xcd_rows = g_variant == 16;
+  plain.temporal_out = g_variant == 17;
   plain.arg_bytes_out = arg_bytes;
 #define PSA_FUSED(R)                                                                          \
   do {                                                                                        \
@@ -1185,7 +1221,7 @@ int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* col,
     // 64 < K <= 256 with a workspace: fused roles (R-MAT scale 21: 2.55 -> 2.34 ms
     // against chunk and row launches back to back; uniform graphs unchanged);
     // variant 15 forces the separate launches
-    if ((g_variant == 0 || g_variant == 14 || g_variant == 16) && w.list && q > 16 && q <= 64) {
+    if ((g_variant == 0 || g_variant == 14 || g_variant == 16 || g_variant == 17) && w.list && q > 16 && q <= 64) {
       *bytes_done = arg_bytes != nullptr && minmax;
       if (q <= 32)
         return launch_fused<4, 32, 4>(red, rowptr, col, value, mat, out, arg_out, M, K, nnz, mean, w, s,

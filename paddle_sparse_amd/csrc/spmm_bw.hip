@@ -121,7 +121,7 @@ __device__ __forceinline__ void value_bw_range(const int64_t* __restrict__ col,
       }
       if (l < U) {
         const int idx = j + l * G + g;
-        if (idx < n) out[base + idx] = dot[0] / denom;
+        if (idx < n) __builtin_nontemporal_store(dot[0] / denom, out + base + idx);  // written once: keep it out of the caches
       }
     }
   }
