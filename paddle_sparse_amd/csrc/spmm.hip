@@ -58,11 +58,12 @@ __device__ __forceinline__ void store_vec(float* p, const float (&src)[VEC]) {
 }
 
 // Non-temporal stores for the outputs (out, arg_out, arg_bytes, grad_value): they
-// are written once and never read by the writing kernel, and marking them so
-// keeps them from displacing rows of the dense operand in L2 / the Infinity
-// Cache.  Measured on config 3 (one process, interleaved, variant 17 = ordinary
-// stores): spmm_sum 1.780 -> 1.660 ms (0.81 -> 0.87 of the HBM peak); marking
-// the col / value loads the same way changed nothing (1.780 vs 1.781 ms).
+// are written once and never read by the writing kernel.  Measured on config 3
+// (one process, interleaved, variant 17 = ordinary stores): spmm_sum 1.684 ->
+// 1.606 ms (0.86 -> 0.90 of the HBM peak), spmm_max 2.157 -> 2.036 ms.  The PMC
+// traffic is the same both ways (9.09 GB fetched, 1.02 GB written, TCC hit rate
+// 8.5 %): the write stream travels better beside the gathers, B is not cached
+// any better.  Marking the col / value loads the same way changed nothing.
 template <int VEC>
 __device__ __forceinline__ void store_vec_nt(float* p, const float (&src)[VEC]) {
   if constexpr (VEC == 1) {
