@@ -65,6 +65,18 @@ __device__ __forceinline__ void store_vec(float* p, const float (&src)[VEC]) {
 // 8.5 %): the write stream travels better beside the gathers, B is not cached
 // any better.  Marking the col / value loads the same way changed nothing.
 template <int VEC>
+__device__ __forceinline__ void load_vec_nt(const float* p, float (&dst)[VEC]) {
+  if constexpr (VEC == 1) {
+    dst[0] = __builtin_nontemporal_load(p);
+  } else {
+    typedef float V __attribute__((ext_vector_type(VEC)));
+    const V v = __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) dst[i] = v[i];
+  }
+}
+
+template <int VEC>
 __device__ __forceinline__ void store_vec_nt(float* p, const float (&src)[VEC]) {
   if constexpr (VEC == 1) {
     __builtin_nontemporal_store(src[0], p);
@@ -149,6 +161,7 @@ struct MaskArgs {
   const float* row_scale = nullptr;  // M_CSC, mean: 1 / max(deg(r), 1) per CSR row, folded into both gradients
   int xcd_rows = 0;                  // row role: give each XCD one contiguous eighth of the rows
   int temporal_out = 0;              // A/B hook (variant 17): ordinary instead of non-temporal output stores
+  int nt_gather = 0;                 // non-temporal loads for the gathered dense rows (operands >> Infinity Cache; variant 18 forces it)
 };
 
 // Reduce edges [s, e) of one row into acc/arg: LPR lanes x VEC floats cover the
@@ -209,7 +222,10 @@ __device__ __forceinline__ void reduce_edge_range(
         ok[u] = (idx < n) && kact;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) b[u][i] = 0.f;
-        if (ok[u]) load_vec<VEC>(matk + c * K, b[u]);
+        if (ok[u]) {
+          if (m.nt_gather) load_vec_nt<VEC>(matk + c * K, b[u]);
+          else load_vec<VEC>(matk + c * K, b[u]);
+        }
         if (MASK) {
           mb[u] = 0;
           if (ok[u]) mb[u] = *reinterpret_cast<const uint32_t*>(m.bytes + c * K);
@@ -851,11 +867,13 @@ int launch_long(int red, const int64_t* rowptr, const int64_t* col, const float*
 }
 
 // Fused long-row path: pre-pass list, one launch with both roles, combine.
+constexpr int64_t kNtGatherBytes = 6ll << 30;  // dense operand size from which its rows are gathered non-temporally
+
 template <int VEC, int LPR, int U>
 int launch_fused(int red, const int64_t* rowptr, const int64_t* col, const float* val,
                  const float* mat, float* out, int64_t* arg_out, int64_t M, int64_t K,
                  int64_t nnz, int mean, const LongScratch& w, hipStream_t s,
-                 uint8_t* arg_bytes = nullptr) {
+                 uint8_t* arg_bytes = nullptr, bool nt_gather = false) {
   const int64_t gx = psa::ceil_div(psa::ceil_div(M, kWaves), 8) * 8 + kFusedChunkBlocks;
   PSA_REQUIRE(gx <= 0x7fffffff, "M too large for one launch");
   const dim3 block(kThreads), grid(static_cast<unsigned>(gx));
@@ -865,6 +883,7 @@ int launch_fused(int red, const int64_t* rowptr, const int64_t* col, const float
   MaskArgs plain;
   plain.xcd_rows = g_variant == 16;
   plain.temporal_out = g_variant == 17;
+  plain.nt_gather = nt_gather;
   plain.arg_bytes_out = arg_bytes;
 #define PSA_FUSED(R)                                                                          \
   do {                                                                                        \
@@ -1222,13 +1241,18 @@ int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* col,
     // 64 < K <= 256 with a workspace: fused roles (R-MAT scale 21: 2.55 -> 2.34 ms
     // against chunk and row launches back to back; uniform graphs unchanged);
     // variant 15 forces the separate launches
-    if ((g_variant == 0 || g_variant == 14 || g_variant == 16 || g_variant == 17) && w.list && q > 16 && q <= 64) {
+    if ((g_variant == 0 || g_variant == 14 || g_variant == 16 || g_variant == 17 || g_variant == 18) && w.list && q > 16 && q <= 64) {
       *bytes_done = arg_bytes != nullptr && minmax;
+      // A dense operand far beyond the 256 MiB Infinity Cache is gathered with
+      // non-temporal loads: nothing of it will be hit again, and not allocating
+      // the lines is worth 4-5 % at 8-16 GiB (tools/nt_gather_sweep.py: break-even
+      // at ~4 GiB, 0.85x at 1 GiB where a quarter of B does stay cached).
+      const bool nt_gather = g_variant == 18 || (g_variant == 0 && N * K * 4 >= kNtGatherBytes);
       if (q <= 32)
         return launch_fused<4, 32, 4>(red, rowptr, col, value, mat, out, arg_out, M, K, nnz, mean, w, s,
-                                      minmax ? arg_bytes : nullptr);
+                                      minmax ? arg_bytes : nullptr, nt_gather);
       return launch_fused<4, 64, 8>(red, rowptr, col, value, mat, out, arg_out, M, K, nnz, mean, w, s,
-                                    minmax ? arg_bytes : nullptr);
+                                    minmax ? arg_bytes : nullptr, nt_gather);
     }
     if (g_variant == 11) { if (q <= 32) PSA_ROWS(4, 32, 4, 4); PSA_ROWS(4, 64, 8, 4); }
     if (g_variant == 12) { if (q <= 32) PSA_ROWS(4, 32, 4, 8); PSA_ROWS(4, 64, 8, 8); }

@@ -106,7 +106,7 @@ def test_ties_pick_first_edge():
         assert np.all(out == 5.0) and np.all(arg == 0)
 
 
-@pytest.mark.parametrize("variant", [0, 2, 3, 4])
+@pytest.mark.parametrize("variant", [0, 2, 3, 4, 16, 17, 18])  # 17: ordinary stores, 18: non-temporal gathers
 def test_variants_k128(variant):
     from paddle_sparse_amd import ops
 
@@ -116,6 +116,11 @@ def test_variants_k128(variant):
     try:
         for reduce in ("sum", "mean", "max"):
             check(reduce, rowptr, col, val, B)
+        if variant >= 16:  # memory-path variants of the production kernel: same arithmetic, same bits
+            got = run_gpu("max", rowptr, col, val, B)
+            ops.spmm_set_variant(0)
+            ref = run_gpu("max", rowptr, col, val, B)
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1])
     finally:
         ops.spmm_set_variant(prev)
 
