@@ -102,15 +102,20 @@ int psa_ptr2ind(const int64_t* ptr, int64_t M, int64_t E, int64_t* out,
  * upstream pytorch_sparse spmm (README.md:267-306 holds the API and one KAT).
  *
  * rowptr int64[M+1], col int64[nnz] (values in [0, N)), value f32[nnz] or
- * NULL, mat f32[N,K] row-major, out f32[M,K], arg_out int64[M,K] (required
- * for MIN/MAX, ignored otherwise; may be NULL for SUM/MEAN).
+ * NULL, mat f32[N,K] row-major, out f32[M,K], arg_out int64[M,K] (MIN/MAX;
+ * ignored for SUM/MEAN).  arg_out may be NULL for MIN/MAX too: it is then not
+ * stored — 2 GB fewer writes at M = 2 M, K = 128, 2.07 -> 1.7 ms — which is
+ * what a caller wants that needs `out` only (inference), or whose backward
+ * reads arg_bytes alone (complete when no row has more than 255 entries).
  * nnz is passed explicitly because rowptr lives on the device.
  *
  * arg_bytes: uint8[M,K] or NULL (MIN/MAX only, needs K % 4 == 0): arg_out once
  * more as the winner's index INSIDE its row, one byte per element (255 for
  * rows of more than 255 edges) — the form psa_spmm_minmax_bw_csc reads.  The
  * forward has it in registers, so writing it here (0.26 GB at M = 2 M, K = 128)
- * saves the backward a pass that re-reads all of arg_out (2 GB).
+ * saves the backward a pass that re-reads all of arg_out (2 GB).  With
+ * arg_out == NULL the bytes must come from the kernel itself (K % 4 == 0 and
+ * K <= 256); other K tiles return PSA_ERR_INVALID_ARG then.
  *
  * workspace (psa_spmm_workspace_bytes(reduce, K, nnz) bytes, 16-byte aligned)
  * enables the long-row path: rows with more than 128 edges are split into
@@ -171,7 +176,9 @@ int psa_spmm_minmax_bw(const int64_t* col, const float* value, const float* mat,
  * tag: uint8[nnz] from psa_csc_edge_tags (depends on the sparsity structure
  * only: cache it with csr2csc).  value: f32[nnz] in CSR order, or NULL.
  * arg_bytes: what psa_spmm left behind (see there), or NULL — the call then
- * derives it from arg_out itself in a first pass.
+ * derives it from arg_out itself in a first pass.  arg_out may be NULL when
+ * arg_bytes is given and no row has more than 255 entries (entries of longer
+ * rows need the exact test against arg_out; without it they count as no hit).
  * grad_value_csc: f32[nnz] or NULL (then mat may be NULL too); it is written in
  * CSC order, contiguously — psa_gather_rows(grad_value_csc, csc2csr, nnz, 4, ..)
  * puts it into the CSR order the API returns (a 4-byte scatter from inside the

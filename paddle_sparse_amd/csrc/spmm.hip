@@ -245,7 +245,7 @@ __device__ __forceinline__ void reduce_edge_range(
             const uint32_t byte = (mb[u] >> (8 * i)) & 255u;
             bool hit = byte == tag;
             if (hit && tag == 255u && ok[u])  // a row of more than 255 edges: exact test
-              hit = m.arg[r * K + i] == (id & 0x00ffffffffffffffll);
+              hit = m.arg != nullptr && m.arg[r * K + i] == (id & 0x00ffffffffffffffll);
             if (!hit) b[u][i] = 0.f;
           }
         }
@@ -373,7 +373,7 @@ spmm_row_kernel(const int64_t* __restrict__ rowptr,
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
       }
-      store_arg_nt<VEC>(arg_out + row * K + k0, arg);
+      if (arg_out) store_arg_nt<VEC>(arg_out + row * K + k0, arg);
     }
     store_vec_nt<VEC>(out + row * K + k0, acc);
   }
@@ -504,7 +504,7 @@ spmm_rows_kernel(const int64_t* __restrict__ rowptr,
 #pragma unroll
           for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
         }
-        store_arg_nt<VEC>(arg_out + row * K + k0, arg);
+        if (arg_out) store_arg_nt<VEC>(arg_out + row * K + k0, arg);
       }
       store_vec_nt<VEC>(out + row * K + k0, acc);
     }
@@ -645,7 +645,9 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
       }
-      if (mask.temporal_out) {
+      if (arg_out == nullptr) {
+        // caller wants `out` (and maybe the byte form) only
+      } else if (mask.temporal_out) {
 #pragma unroll
         for (int i = 0; i < VEC; ++i) arg_out[row * K + k0 + i] = arg[i];
       } else {
@@ -707,7 +709,7 @@ spmm_long_combine_kernel(const int64_t* __restrict__ rowptr, int64_t K, int mean
       if (RED == R_SUM) {
         if (mean) acc = acc / static_cast<float>(deg);
       } else {
-        __builtin_nontemporal_store(arg, arg_out + ent.row * K + k);
+        if (arg_out) __builtin_nontemporal_store(arg, arg_out + ent.row * K + k);
         if (arg_bytes)
           arg_bytes[ent.row * K + k] = deg > 255 ? uint8_t{255} : static_cast<uint8_t>(arg - rowptr[ent.row]);
       }
@@ -799,7 +801,7 @@ spmm_multirow_kernel(const int64_t* __restrict__ rowptr,
 #pragma unroll
       for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
     }
-    store_arg_nt<VEC>(arg_out + row * K + k0, arg);
+    if (arg_out) store_arg_nt<VEC>(arg_out + row * K + k0, arg);
     if (VEC == 4 && arg_bytes) {  // row-local byte form for the one-pass backward (see MaskArgs)
       uint32_t packed = 0;
 #pragma unroll
@@ -1081,7 +1083,8 @@ int psa_spmm_minmax_bw_csc(const int64_t* rowptr, const int64_t* colptr,
     return PSA_ERR_UNSUPPORTED;
   }
   PSA_REQUIRE(colptr && grad_mat, "NULL pointer");
-  PSA_REQUIRE(nnz == 0 || (rowptr && row_csc && csr2csc && tag && grad && arg_out), "NULL pointer");
+  PSA_REQUIRE(nnz == 0 || (rowptr && row_csc && csr2csc && tag && grad), "NULL pointer");
+  PSA_REQUIRE(nnz == 0 || arg_out != nullptr || arg_bytes != nullptr, "arg_out and arg_bytes are both NULL");
   PSA_REQUIRE(grad_value == nullptr || mat != nullptr || nnz == 0, "grad_value needs mat");
   PSA_REQUIRE(max_long_chunks(nnz) < (1ll << 32), "too many chunks");
   if (workspace == nullptr || workspace_bytes < psa_spmm_minmax_bw_csc_workspace_bytes(M, K, nnz)) {
@@ -1184,7 +1187,6 @@ int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* col,
   PSA_REQUIRE(nnz == 0 || (col != nullptr && mat != nullptr),
               "col/mat is NULL");
   const bool minmax = reduce == PSA_MIN || reduce == PSA_MAX;
-  PSA_REQUIRE(!minmax || arg_out != nullptr, "arg_out required for min/max");
   const int red = reduce == PSA_MIN ? R_MIN : (reduce == PSA_MAX ? R_MAX : R_SUM);
   const int mean = reduce == PSA_MEAN;
 
@@ -1289,6 +1291,7 @@ int psa_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
                                workspace_bytes, s, arg_bytes, &bytes_done);
   if (st != PSA_OK || arg_bytes == nullptr || !minmax || bytes_done || M == 0 || K == 0) return st;
   // the kernel that ran keeps arg_out only: one more pass turns it into bytes
+  PSA_REQUIRE(arg_out != nullptr, "arg_bytes without arg_out needs a K tile whose kernel writes the bytes itself (K % 4 == 0, K <= 256)");
   PSA_REQUIRE(psa::aligned(arg_out, 16) && psa::aligned(arg_bytes, 4), "arg_out / arg_bytes alignment");
   const int64_t blocks = psa::ceil_div(M * (K / 4), kThreads);
   PSA_REQUIRE(blocks <= 0x7fffffff, "M*K too large for one launch");

@@ -111,7 +111,7 @@ def all_gather_dense(b_local: torch.Tensor, num_rows: int, group=None,
 def _hip_spmm(reduce: str, rowptr, col, value, mat):
     from . import ops  # the HIP core; loads (or fails loudly) on first use
 
-    return ops._spmm(reduce, rowptr, col, value, mat)[0]
+    return ops._spmm(reduce, rowptr, col, value, mat, want_arg=False)[0]  # `out` only: min/max skip arg_out
 
 
 class RowPartitionedSpMM:

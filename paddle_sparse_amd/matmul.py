@@ -43,13 +43,25 @@ def _csc_weights(st: SparseStorage, value: Optional[torch.Tensor], csr2csc, row_
 class _SpMM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, value: Optional[torch.Tensor], mat: torch.Tensor,
-                storage: SparseStorage, reduce: str):
+                storage: SparseStorage, reduce: str, track: bool = True):
         rowptr, col = storage.rowptr(), storage.col()
-        # min/max: the forward also leaves arg_out as row-local bytes (the form
-        # the one-pass backward reads) when the K tile allows that backward
-        want_bytes = reduce in ("min", "max") and ops.minmax_bw_csc_supported(mat.shape[1])
-        out, arg, arg_bytes = ops._spmm(reduce, rowptr, col, value, mat, want_arg_bytes=True) if want_bytes \
-            else (*ops._spmm(reduce, rowptr, col, value, mat), None)
+        arg = arg_bytes = None
+        if reduce in ("min", "max"):
+            # What the backward will read decides what the forward stores.  The
+            # int64 arg_out is two thirds of the forward's output traffic (2 GB of
+            # 3.3 at 2 M x 128): it is skipped when nothing will be differentiated,
+            # and when the one-pass backward over the CSC view will run (grad of
+            # mat wanted, K tile supported) on a matrix whose rows all have at most
+            # 255 entries — the one-byte row-local form is then the whole answer.
+            need_value = track and value is not None and ctx.needs_input_grad[0]
+            need_mat = track and ctx.needs_input_grad[1]
+            csc_bw = need_mat and ops.minmax_bw_csc_supported(mat.shape[1])
+            bytes_only = csc_bw and storage._longest_row() <= 255
+            want_arg = (need_value or need_mat) and not bytes_only
+            res = ops._spmm(reduce, rowptr, col, value, mat, want_arg_bytes=csc_bw, want_arg=want_arg)
+            out, arg, arg_bytes = res if csc_bw else (*res, None)
+        else:
+            out = ops._spmm(reduce, rowptr, col, value, mat)[0]
         ctx.storage, ctx.reduce = storage, reduce
         ctx.save_for_backward(value, mat, arg, arg_bytes)
         return out
@@ -89,7 +101,7 @@ class _SpMM(torch.autograd.Function):
                 grad_value, grad_mat = ops.spmm_sum_bw_csc(st.colptr(), st._row_in_csc_order(), csr2csc,
                                                            value, mat, grad_out, True, csc2csr=st.csc2csr(),
                                                            row_scale=scale)
-                return grad_value, grad_mat, None, None
+                return grad_value, grad_mat, None, None, None
             if need_value:
                 grad_value = ops.spmm_value_bw(None, st.rowptr(), st.col(), mat, grad_out,
                                                "mean" if mean else "sum")
@@ -100,7 +112,7 @@ class _SpMM(torch.autograd.Function):
                 if value is not None or mean:
                     w = _csc_weights(st, value, csr2csc, row_csc, mean)
                 grad_mat = ops.spmm_sum(st.colptr(), row_csc, w, grad_out)
-        return grad_value, grad_mat, None, None
+        return grad_value, grad_mat, None, None, None
 
 
 def spmm_sparse(src: SparseTensor, other: torch.Tensor, reduce: str = "sum") -> torch.Tensor:
@@ -114,7 +126,9 @@ def spmm_sparse(src: SparseTensor, other: torch.Tensor, reduce: str = "sum") -> 
     value = src.storage.value()
     if value is not None and value.dim() != 1:
         raise ValueError("spmm needs scalar edge values")
-    return _SpMM.apply(value, other, src.storage, reduce)
+    # forward() runs with grad mode off and sees requires_grad flags only: whether a
+    # backward can follow at all is decided here
+    return _SpMM.apply(value, other, src.storage, reduce, torch.is_grad_enabled())
 
 
 def matmul(src: SparseTensor, other, reduce: str = "sum") -> torch.Tensor:

@@ -73,9 +73,14 @@ def ptr2ind(ptr: torch.Tensor, E: int) -> torch.Tensor:
 
 
 def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
-          value: Optional[torch.Tensor], mat: torch.Tensor, want_arg_bytes: bool = False):
+          value: Optional[torch.Tensor], mat: torch.Tensor, want_arg_bytes: bool = False,
+          want_arg: bool = True):
     """(out, arg_out | None) — and, with want_arg_bytes (min/max, K % 4 == 0), a
-    third result: arg_out as row-local byte indices for spmm_minmax_bw_csc."""
+    third result: arg_out as row-local byte indices for spmm_minmax_bw_csc.
+    want_arg=False (min/max) skips the int64 arg_out altogether: the kernel then
+    stores `out` (and the bytes, if asked for) only — two thirds of the output
+    traffic gone; for callers that need no backward, or whose backward is served
+    by the bytes alone (no row longer than 255 entries)."""
     rowptr = _index(rowptr, "rowptr")
     col = _index(col, "col")
     _gpu(mat, "mat")
@@ -95,10 +100,11 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
     rid = REDUCE_ID[reduce]
     out = torch.empty((M, K), dtype=torch.float32, device=mat.device)
     arg = None
-    if rid in (_lib.MIN, _lib.MAX):
+    minmax = rid in (_lib.MIN, _lib.MAX)
+    if minmax and want_arg:
         arg = torch.empty((M, K), dtype=torch.int64, device=mat.device)
     arg_bytes = None
-    if want_arg_bytes and arg is not None and K % 4 == 0:
+    if want_arg_bytes and minmax and K % 4 == 0 and (want_arg or K <= 256):
         arg_bytes = torch.empty((M, K), dtype=torch.uint8, device=mat.device)
     lib = _lib.load()
     ws_bytes = lib.psa_spmm_workspace_bytes(rid, K, nnz)  # long-row scratch (0 if no row can be long)
@@ -487,15 +493,18 @@ def spmm_minmax_bw_csc(rowptr, colptr, row_csc, csr2csc, tag, value, mat, grad, 
     rowptr, colptr = _index(rowptr, "rowptr"), _index(colptr, "colptr")
     row_csc, csr2csc = _index(row_csc, "row_csc"), _index(csr2csc, "csr2csc")
     grad = _f32(grad, "grad")
-    _gpu(arg_out, "arg_out")
-    arg_out = arg_out.contiguous()
+    if arg_out is None and arg_bytes is None:
+        raise ValueError("spmm_minmax_bw_csc needs arg_out or arg_bytes")
+    if arg_out is not None:
+        _gpu(arg_out, "arg_out")
+        arg_out = arg_out.contiguous()
     if value is not None:
         value = _f32(value, "value")
     _gpu(tag, "tag")
     if tag.dtype != torch.uint8 or tag.numel() != csr2csc.numel():
         raise ValueError("tag must be uint8[nnz] (ops.csc_edge_tags)")
     (M, K), N, nnz = grad.shape, colptr.numel() - 1, csr2csc.numel()
-    if arg_out.shape != grad.shape or arg_out.dtype != torch.int64:
+    if arg_out is not None and (arg_out.shape != grad.shape or arg_out.dtype != torch.int64):
         raise ValueError("arg_out must be int64[M, K] like grad")
     if arg_bytes is not None:
         _gpu(arg_bytes, "arg_bytes")

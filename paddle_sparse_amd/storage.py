@@ -118,6 +118,7 @@ class SparseStorage(object):
         self._csr2csc, self._csc2csr = csr2csc, csc2csr
         self._row_csc: Optional[torch.Tensor] = None  # row[csr2csc], private
         self._edge_tags: Optional[torch.Tensor] = None  # uint8 per CSC edge, private (min/max backward)
+        self._max_rowcount: Optional[int] = None  # longest row, private (structure only; one host read)
 
         # storage.py:158-171 — sort by (row, col) unless told it is sorted
         if not is_sorted and nnz > 0:
@@ -305,6 +306,13 @@ class SparseStorage(object):
             self._row_csc = ops.gather_rows(self.row(), self.csr2csc())
         return self._row_csc
 
+    def _longest_row(self) -> int:
+        """Entries of the longest row (memoised; the min/max forward asks whether
+        the one-byte form of arg_out is complete, i.e. no row above 255)."""
+        if self._max_rowcount is None:
+            self._max_rowcount = int(self.rowcount().max().item()) if self._sparse_sizes[0] > 0 else 0
+        return self._max_rowcount
+
     def _csc_edge_tags(self) -> torch.Tensor:
         """Position of every CSC-ordered edge inside its CSR row, one byte each
         (ops.csc_edge_tags): structure only, memoised for the min/max backward."""
@@ -353,6 +361,7 @@ class SparseStorage(object):
             setattr(self, "_" + k, None)
         self._row_csc = None
         self._edge_tags = None
+        self._max_rowcount = None
         return self
 
     def cached_keys(self) -> List[str]:
@@ -370,6 +379,7 @@ class SparseStorage(object):
         out = SparseStorage(is_sorted=True, trust_data=True, **args)
         if not (set(kw) - {"value"}):  # same sparsity structure: the private CSC helpers carry over
             out._row_csc, out._edge_tags = self._row_csc, self._edge_tags
+            out._max_rowcount = self._max_rowcount
         return out
 
     def _map(self, fn: Callable[[torch.Tensor], torch.Tensor]):

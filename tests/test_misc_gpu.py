@@ -247,6 +247,109 @@ def test_forward_leaves_arg_out_as_row_local_bytes(reduce, K):
         assert torch.equal(gv1, gv2) and torch.equal(gm1, gm2)
 
 
+@pytest.mark.parametrize("reduce", ["min", "max"])
+@pytest.mark.parametrize("K", [4, 32, 64, 100, 128, 256, 130, 384])
+def test_minmax_forward_without_arg_out(reduce, K):
+    """psa_spmm(arg_out=NULL): `out` (and the byte form, where the kernel writes
+    it itself) without the int64 arg_out — same bits as the full call, on every
+    kernel (multirow, fused roles + long-row combine, row kernel, scalar lanes)."""
+    from paddle_sparse_amd import SparseStorage, ops
+    from paddle_sparse_amd._lib import HipCoreError
+
+    for long_deg in (200, 700):  # chunked rows; rows past the byte form's reach
+        row, rowptr, col, val = skewed_csr(900, 300, seed=K + long_deg, long_rows=(0, 450), long_deg=long_deg)
+        B = np.random.default_rng(K).standard_normal((300, K)).astype(np.float32)
+        full = ops._spmm(reduce, dev(rowptr), dev(col), dev(val), dev(B), want_arg_bytes=True)
+        out_only = ops._spmm(reduce, dev(rowptr), dev(col), dev(val), dev(B), want_arg=False)
+        assert out_only[1] is None and torch.equal(out_only[0], full[0])
+        if not ops.minmax_bw_csc_supported(K):
+            # no kernel writes the bytes itself for this K tile: the wrapper does not ask for them ...
+            res = ops._spmm(reduce, dev(rowptr), dev(col), dev(val), dev(B), want_arg_bytes=True, want_arg=False)
+            assert res[1] is None and res[2] is None and torch.equal(res[0], full[0])
+            continue
+        out, arg, ab = ops._spmm(reduce, dev(rowptr), dev(col), dev(val), dev(B), want_arg_bytes=True, want_arg=False)
+        assert arg is None and torch.equal(out, full[0]) and torch.equal(ab, full[2])
+        # the backward served by the bytes alone: exact when no row is longer than 255
+        st = SparseStorage(rowptr=dev(rowptr), col=dev(col), value=dev(val), sparse_sizes=(900, 300), is_sorted=True)
+        assert st._longest_row() == long_deg
+        G = torch.randn(900, K, device="cuda")
+        head = (st.rowptr(), st.colptr(), st._row_in_csc_order(), st.csr2csc(), st._csc_edge_tags(), st.value(),
+                dev(B), G)
+        gv_ref, gm_ref = ops.spmm_minmax_bw_csc(*head, full[1], csc2csr=st.csc2csr(), arg_bytes=full[2])
+        gv, gm = ops.spmm_minmax_bw_csc(*head, None, csc2csr=st.csc2csr(), arg_bytes=ab)
+        if long_deg <= 255:
+            assert torch.equal(gv, gv_ref) and torch.equal(gm, gm_ref)
+        else:  # documented: entries of rows past 255 count as no hit without arg_out (and nothing faults)
+            short = torch.from_numpy(((rowptr[1:] - rowptr[:-1]) <= 255)[row]).cuda()
+            assert torch.equal(gv[short], gv_ref[short])
+    if ops.minmax_bw_csc_supported(K):
+        with pytest.raises(ValueError, match="arg_out or arg_bytes"):
+            ops.spmm_minmax_bw_csc(*head, None, csc2csr=st.csc2csr())
+    with pytest.raises(HipCoreError, match="arg_bytes without arg_out"):
+        # straight through the C-ABI: bytes asked for, no arg_out, a K tile whose kernel cannot write them
+        from paddle_sparse_amd import _lib
+        Bw = torch.randn(300, 260, device="cuda")
+        o = torch.empty(900, 260, device="cuda")
+        byt = torch.empty(900, 260, dtype=torch.uint8, device="cuda")
+        _lib.check(_lib.load().psa_spmm(_lib.REDUCE_ID[reduce], dev(rowptr).data_ptr(), dev(col).data_ptr(), None,
+                                        Bw.data_ptr(), 900, 300, 260, col.size, o.data_ptr(), None, byt.data_ptr(),
+                                        None, 0, torch.cuda.current_stream().cuda_stream))
+
+
+@pytest.mark.parametrize("reduce", ["min", "max"])
+def test_autograd_minmax_skips_arg_out_when_the_bytes_suffice(reduce):
+    """matmul.py: short rows + grad of the dense operand -> the forward keeps the
+    byte form only; long rows or value-only gradients keep arg_out; no gradient
+    at all keeps neither.  Gradients are the same bits as with arg_out kept."""
+    import sys
+
+    from paddle_sparse_amd import SparseTensor, ops
+
+    mm_mod = sys.modules["paddle_sparse_amd.matmul"]  # the package exports a function of the same name
+
+    seen = []
+    real = ops._spmm
+
+    def spy(*a, **k):
+        seen.append((k.get("want_arg_bytes", False), k.get("want_arg", True)))
+        return real(*a, **k)
+
+    for long_deg, expect in ((100, (True, False)), (400, (True, True))):
+        row, rowptr, col, val = skewed_csr(700, 300, seed=long_deg, long_rows=(5,), long_deg=long_deg)
+        B = torch.randn(300, 64, device="cuda")
+        grads = []
+        for patched in (False, True):
+            A = SparseTensor(rowptr=dev(rowptr), col=dev(col), value=dev(val).requires_grad_(True),
+                             sparse_sizes=(700, 300), is_sorted=True)
+            Bg = B.clone().requires_grad_(True)
+            if patched:  # reference run: force the full arg_out
+                ops._spmm = lambda *a, **k: real(*a, **{**k, "want_arg": True})
+            else:
+                ops._spmm = spy
+            try:
+                out = mm_mod.spmm_sparse(A, Bg, reduce)
+                out.backward(torch.ones_like(out))
+            finally:
+                ops._spmm = real
+            grads.append((A.storage.value().grad.clone(), Bg.grad.clone(), out.detach()))
+        assert seen[-1] == expect
+        for x, y in zip(*grads):
+            assert torch.equal(x, y)
+    # value gradient only -> the atomics backward needs arg_out; no gradient -> nothing is kept
+    A = SparseTensor(rowptr=dev(rowptr), col=dev(col), value=dev(val).requires_grad_(True), sparse_sizes=(700, 300),
+                     is_sorted=True)
+    ops._spmm = spy
+    try:
+        mm_mod.spmm_sparse(A, B, reduce).sum().backward()
+        assert seen[-1] == (False, True) and A.storage.value().grad is not None
+        with torch.no_grad():
+            ref = real(reduce, dev(rowptr), dev(col), dev(val), B)[0]
+            got = mm_mod.spmm_sparse(A, B, reduce)
+        assert seen[-1] == (False, False) and torch.equal(got, ref)
+    finally:
+        ops._spmm = real
+
+
 def test_minmax_bw_over_csc_rejects_unaligned_k():
     from paddle_sparse_amd import ops
     from paddle_sparse_amd._lib import HipCoreError
