@@ -101,14 +101,20 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
     out = torch.empty((M, K), dtype=torch.float32, device=mat.device)
     arg = None
     minmax = rid in (_lib.MIN, _lib.MAX)
+    lib = _lib.load()
+    ws_bytes = lib.psa_spmm_workspace_bytes(rid, K, nnz)  # long-row scratch (0 if no row can be long)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=mat.device) if ws_bytes else None
+    # the kernels that write the byte form themselves: K <= 64 (multirow) and the
+    # fused-roles kernel (64 < K <= 256, taken when there is a workspace); behind
+    # the others the bytes are derived from arg_out, which must then exist
+    bytes_in_kernel = K % 4 == 0 and (K <= 64 or (K <= 256 and ws_bytes > 0))
+    if minmax and want_arg_bytes and K % 4 == 0 and K <= 256 and not bytes_in_kernel:
+        want_arg = True
     if minmax and want_arg:
         arg = torch.empty((M, K), dtype=torch.int64, device=mat.device)
     arg_bytes = None
     if want_arg_bytes and minmax and K % 4 == 0 and (want_arg or K <= 256):
         arg_bytes = torch.empty((M, K), dtype=torch.uint8, device=mat.device)
-    lib = _lib.load()
-    ws_bytes = lib.psa_spmm_workspace_bytes(rid, K, nnz)  # long-row scratch (0 if no row can be long)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=mat.device) if ws_bytes else None
     with torch.cuda.device(mat.device):
         check(lib.psa_spmm(rid, _ptr(rowptr), _ptr(col), _ptr(value), _ptr(mat),
                            M, N, K, nnz, _ptr(out), _ptr(arg), _ptr(arg_bytes), _ptr(ws), ws_bytes,
