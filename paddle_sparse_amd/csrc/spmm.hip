@@ -146,8 +146,10 @@ using psa::push_long_row;
 //   M_PLAIN  the forward (and grad_mat of sum/mean with ready-made CSC weights);
 //   M_MASK   min/max backward over the CSC view (byte test described above);
 //   M_CSC    sum/mean backward over the CSC view: the same indirection (value
-//            read through edge_id) and the same grad_value dot, every term on.
-enum { M_PLAIN = 0, M_MASK = 1, M_CSC = 2 };
+//            read through edge_id) and the same grad_value dot, every term on;
+//   M_NOARG  min/max forward whose caller wants `out` only: the winners' edge
+//            ids are not tracked (8 VGPRs and the 64-bit shuffles of the fold less).
+enum { M_PLAIN = 0, M_MASK = 1, M_CSC = 2, M_NOARG = 3 };
 
 struct MaskArgs {
   const uint8_t* bytes = nullptr;    // [M, K] at the lane's k0
@@ -173,8 +175,9 @@ __device__ __forceinline__ void reduce_edge_range(
     const float* __restrict__ matk, int64_t K, bool kact, int64_t s, int64_t e,
     int64_t nnz, int lane, float (&acc)[VEC], int64_t (&arg)[VEC],
     const MaskArgs& m = MaskArgs{}) {
-  static_assert(MODE == M_PLAIN || (RED == R_SUM && VEC == 4), "CSC forms: sum over float4 tiles");
-  constexpr bool INDIRECT = MODE != M_PLAIN;
+  static_assert(MODE == M_PLAIN || MODE == M_NOARG || (RED == R_SUM && VEC == 4), "CSC forms: sum over float4 tiles");
+  constexpr bool INDIRECT = MODE == M_MASK || MODE == M_CSC;
+  constexpr bool TRACK = MODE != M_NOARG;
   constexpr bool MASK = MODE == M_MASK;
   constexpr int G = 64 / LPR;
   static_assert(64 % (G * U) == 0, "edge batch must divide the wave");
@@ -297,7 +300,7 @@ __device__ __forceinline__ void reduce_edge_range(
             const bool better = RED == R_MAX ? (x > acc[i]) : (x < acc[i]);
             if (better) {
               acc[i] = x;
-              arg[i] = eid;
+              if (TRACK) arg[i] = eid;
             }
           }
         }
@@ -312,6 +315,9 @@ __device__ __forceinline__ void reduce_edge_range(
       const float o = __shfl_xor(acc[i], off);
       if (RED == R_SUM) {
         acc[i] += o;
+      } else if (!TRACK) {
+        const bool better = RED == R_MAX ? (o > acc[i]) : (o < acc[i]);
+        if (better) acc[i] = o;
       } else {
         const int64_t oa = shfl_i64(arg[i], lane ^ off);
         // first winner in edge order: ties go to the smaller edge id
@@ -602,11 +608,11 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
       const int64_t rs = rowptr[ent.row], re = rowptr[ent.row + 1];
       const int64_t s = rs + static_cast<int64_t>(c - ent.first_chunk) * kLongChunk;
       const int64_t e = s + kLongChunk < re ? s + kLongChunk : re;
-      if (MODE != M_PLAIN && mask.mat) mask.mrow = mask.mat + ent.row * K + k0;
+      if ((MODE == M_MASK || MODE == M_CSC) && mask.mat) mask.mrow = mask.mat + ent.row * K + k0;
       reduce_edge_range<VEC, LPR, RED, U, MODE>(col, val, mat + k0, K, kact, s, e, nnz, lane, acc, arg, mask);
       if (g == 0 && kact) {
         store_vec<VEC>(part_val + static_cast<int64_t>(c) * K + k0, acc);
-        if (RED != R_SUM) {
+        if (RED != R_SUM && MODE != M_NOARG) {
 #pragma unroll
           for (int i = 0; i < VEC; ++i) part_arg[static_cast<int64_t>(c) * K + k0 + i] = arg[i];
         }
@@ -630,7 +636,7 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
   const int64_t s = rowptr[row];
   const int64_t e = rowptr[row + 1];
   if (e - s > kLongRow) return;  // on the list: chunk role + combine write it
-  if (MODE != M_PLAIN && mask.mat) mask.mrow = mask.mat + row * K + k0;
+  if ((MODE == M_MASK || MODE == M_CSC) && mask.mat) mask.mrow = mask.mat + row * K + k0;
   reduce_edge_range<VEC, LPR, RED, U, MODE>(col, val, mat + k0, K, kact, s, e, nnz, lane, acc, arg, mask);
   if (g == 0 && kact) {
     const int64_t deg = e - s;
@@ -645,7 +651,7 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
 #pragma unroll
         for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
       }
-      if (arg_out == nullptr) {
+      if (MODE == M_NOARG || arg_out == nullptr) {
         // caller wants `out` (and maybe the byte form) only
       } else if (mask.temporal_out) {
 #pragma unroll
@@ -653,7 +659,7 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
       } else {
         store_arg_nt<VEC>(arg_out + row * K + k0, arg);
       }
-      if (VEC == 4 && mask.arg_bytes_out) {  // the backward's 1-byte form, for free while arg is in registers
+      if (MODE != M_NOARG && VEC == 4 && mask.arg_bytes_out) {  // the backward's 1-byte form, for free while arg is in registers
         uint32_t packed = 0;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
@@ -887,8 +893,17 @@ int launch_fused(int red, const int64_t* rowptr, const int64_t* col, const float
   plain.temporal_out = g_variant == 17;
   plain.nt_gather = nt_gather;
   plain.arg_bytes_out = arg_bytes;
+  // min/max with neither arg_out nor arg_bytes wanted: the instantiation that does
+  // not track the winners' edge ids (the combine still folds chunk partials by
+  // value; ids it reads there only break ties between equal values)
+  const bool no_arg = red != R_SUM && arg_out == nullptr && arg_bytes == nullptr && g_variant != 19;
 #define PSA_FUSED(R)                                                                          \
   do {                                                                                        \
+    if (R != R_SUM && no_arg)                                                                 \
+      hipLaunchKernelGGL((spmm_fused_kernel<VEC, LPR, R, U, (R == R_SUM ? M_PLAIN : M_NOARG)>), grid, block, 0, s, \
+                         rowptr, col, val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list, \
+                         w.part_val, w.part_arg, plain);                                      \
+    else                                                                                      \
     hipLaunchKernelGGL((spmm_fused_kernel<VEC, LPR, R, U>), grid, block, 0, s, rowptr, col,   \
                        val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list, w.part_val,    \
                        w.part_arg, plain);                                                    \
@@ -1243,7 +1258,7 @@ int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* col,
     // 64 < K <= 256 with a workspace: fused roles (R-MAT scale 21: 2.55 -> 2.34 ms
     // against chunk and row launches back to back; uniform graphs unchanged);
     // variant 15 forces the separate launches
-    if ((g_variant == 0 || g_variant == 14 || g_variant == 16 || g_variant == 17 || g_variant == 18) && w.list && q > 16 && q <= 64) {
+    if ((g_variant == 0 || g_variant == 14 || g_variant == 16 || g_variant == 17 || g_variant == 18 || g_variant == 19) && w.list && q > 16 && q <= 64) {
       *bytes_done = arg_bytes != nullptr && minmax;
       // A dense operand far beyond the 256 MiB Infinity Cache is gathered with
       // non-temporal loads: nothing of it will be hit again, and not allocating

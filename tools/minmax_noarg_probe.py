@@ -34,6 +34,11 @@ for name, kw in (("out + arg_out (int64)", {}), ("out + arg_out + arg_bytes", {"
                  ("out + arg_bytes", {"want_arg_bytes": True, "want_arg": False}), ("out only", {"want_arg": False})):
     print(f"spmm_max forward, {name:28s} {ms(lambda: ops._spmm('max', rowptr, col, val, B, **kw)):7.3f} ms")
 
+ops.spmm_set_variant(19)  # out only, but with the kernel that tracks the winners' ids
+print(f"spmm_max forward, out only, ids tracked anyway   {ms(lambda: ops._spmm('max', rowptr, col, val, B, want_arg=False)):7.3f} ms")
+ops.spmm_set_variant(0)
+print(f"spmm_sum forward (for scale)                     {ms(lambda: ops._spmm('sum', rowptr, col, val, B)):7.3f} ms")
+
 v = val.clone().requires_grad_(True)
 Bt = B.clone().requires_grad_(True)
 A = SparseTensor(rowptr=rowptr, col=col, value=v, sparse_sizes=(M, M), is_sorted=True, trust_data=True)
