@@ -151,6 +151,8 @@ using psa::push_long_row;
 //            ids are not tracked (8 VGPRs and the 64-bit shuffles of the fold less).
 enum { M_PLAIN = 0, M_MASK = 1, M_CSC = 2, M_NOARG = 3 };
 
+constexpr int kFusedChunkBlocksDefault = 768;
+
 struct MaskArgs {
   const uint8_t* bytes = nullptr;    // [M, K] at the lane's k0
   const uint8_t* tag = nullptr;      // [nnz], CSC order
@@ -163,6 +165,7 @@ struct MaskArgs {
   const float* row_scale = nullptr;  // M_CSC, mean: 1 / max(deg(r), 1) per CSR row, folded into both gradients
   int xcd_rows = 0;                  // row role: give each XCD one contiguous eighth of the rows
   int temporal_out = 0;              // A/B hook (variant 17): ordinary instead of non-temporal output stores
+  int chunk_blocks = kFusedChunkBlocksDefault;  // workgroups in the chunk role (variants 20-22 for A/B)
   int nt_gather = 0;                 // non-temporal loads for the gathered dense rows (operands >> Infinity Cache; variant 18 forces it)
 };
 
@@ -567,15 +570,87 @@ spmm_long_chunk_kernel(const int64_t* __restrict__ rowptr,
 // graphs, where most rows are empty or tiny) — so the two overlap instead of
 // running back to back.  Roles are told apart by blockIdx only.
 // ---------------------------------------------------------------------------
-constexpr int kFusedChunkBlocks = 768;  // x 4 waves: ~3/8 of the chip's wave slots
+// (kFusedChunkBlocksDefault = 768, x 4 waves: ~3/8 of the chip's wave slots)
 
+constexpr int kFindIters = 4;   // x 256 rows per workgroup of find_long_rows_kernel
+
+// Builds the long-row list {row, first chunk, chunks}, list order = chunk order =
+// row order inside a workgroup.  ONE atomic per workgroup of 1024 rows reserves
+// {long rows, chunks} for all of them: atomics on the single counter complete
+// one after the other (~3 ns each), and a power-law graph has tens of thousands
+// of long rows (R-MAT scale 21: 63 us with one atomic per row or per wave).
+// Pass 1 counts per (trip, wave), lane 0 of the block scans those 64 pairs and
+// reserves; pass 2 recomputes the (L2-hot) degrees and writes the entries.
 __global__ void __launch_bounds__(kThreads)
 find_long_rows_kernel(const int64_t* __restrict__ rowptr, int64_t M,
                       unsigned long long* __restrict__ ctr, LongEntry* __restrict__ list) {
-  const int64_t r = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
-  if (r >= M) return;
-  const int64_t deg = rowptr[r + 1] - rowptr[r];
-  if (deg > kLongRow) push_long_row(ctr, list, r, deg);
+  __shared__ uint32_t s_rows[kFindIters][kWaves];
+  __shared__ uint32_t s_chunks[kFindIters][kWaves];
+  __shared__ uint32_t s_any;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * (kThreads * kFindIters);
+  if (threadIdx.x == 0) s_any = 0;
+  __syncthreads();
+  bool any = false;
+  for (int it = 0; it < kFindIters; ++it) {
+    const int64_t r = base + it * kThreads + threadIdx.x;
+    const int64_t deg = r < M ? rowptr[r + 1] - rowptr[r] : 0;
+    const bool is_long = deg > kLongRow;
+    uint32_t chunks = is_long ? static_cast<uint32_t>((deg + kLongChunk - 1) / kLongChunk) : 0u;
+    const unsigned long long mask = __ballot(is_long);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) chunks += __shfl_xor(chunks, off);
+    if (lane == 0) {
+      s_rows[it][wave] = static_cast<uint32_t>(__popcll(mask));
+      s_chunks[it][wave] = chunks;
+    }
+    any |= mask != 0;
+  }
+  if (any && lane == 0) s_any = 1;
+  __syncthreads();
+  if (s_any == 0) return;  // block-uniform: no atomic at all for blocks of short rows
+  if (threadIdx.x == 0) {
+    uint32_t nrows = 0, nchunks = 0;
+    for (int it = 0; it < kFindIters; ++it) {
+      for (int w = 0; w < kWaves; ++w) {  // exclusive prefixes in (trip, wave) = row order
+        const uint32_t a = s_rows[it][w], b = s_chunks[it][w];
+        s_rows[it][w] = nrows;
+        s_chunks[it][w] = nchunks;
+        nrows += a;
+        nchunks += b;
+      }
+    }
+    const unsigned long long old = atomicAdd(ctr, (static_cast<unsigned long long>(nrows) << 32) | nchunks);
+    for (int it = 0; it < kFindIters; ++it) {
+      for (int w = 0; w < kWaves; ++w) {
+        s_rows[it][w] += static_cast<uint32_t>(old >> 32);
+        s_chunks[it][w] += static_cast<uint32_t>(old & 0xffffffffull);
+      }
+    }
+  }
+  __syncthreads();
+  for (int it = 0; it < kFindIters; ++it) {
+    const int64_t r = base + it * kThreads + threadIdx.x;
+    const int64_t deg = r < M ? rowptr[r + 1] - rowptr[r] : 0;
+    const bool is_long = deg > kLongRow;
+    const unsigned long long mask = __ballot(is_long);
+    if (mask == 0) continue;  // wave-uniform
+    const uint32_t chunks = is_long ? static_cast<uint32_t>((deg + kLongChunk - 1) / kLongChunk) : 0u;
+    uint32_t incl = chunks;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    if (is_long) {
+      LongEntry e;
+      e.row = r;
+      e.first_chunk = s_chunks[it][wave] + incl - chunks;
+      e.num_chunks = chunks;
+      list[s_rows[it][wave] + __popcll(mask & ((1ull << lane) - 1ull))] = e;
+    }
+  }
 }
 
 template <int VEC, int LPR, int RED, int U, int MODE = M_PLAIN>
@@ -599,6 +674,7 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
     mask.bytes += k0;
     mask.arg += k0;
   }
+  const int kFusedChunkBlocks = mask.chunk_blocks;
   if (blockIdx.x < kFusedChunkBlocks) {  // ---- chunk role ----
     const unsigned long long ctr = *long_ctr;
     const uint32_t total = static_cast<uint32_t>(ctr & 0xffffffffull);
@@ -690,36 +766,57 @@ spmm_long_combine_kernel(const int64_t* __restrict__ rowptr, int64_t K, int mean
   for (int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < nrows; r += num_waves) {
     const LongEntry ent = long_list[r];
     const int64_t deg = rowptr[ent.row + 1] - rowptr[ent.row];
-    for (int64_t k = lane; k < K; k += 64) {
-      const int64_t p0 = static_cast<int64_t>(ent.first_chunk) * K + k;
-      float acc = part_val[p0];
-      int64_t arg = RED == R_SUM ? 0 : part_arg[p0];
-      // 8 partials requested per step (a 40 000-edge row has > 300 chunks; one
-      // dependent load per chunk made this kernel 0.3 ms), folded in chunk order
+    // two K positions per lane and trip (k and k + 64): the chunk loop of a hub row
+    // (a 40 000-edge row has > 300 chunks) is the kernel's critical path, and
+    // K = 128 would otherwise walk it twice, one after the other
+    for (int64_t kb = lane; kb < K; kb += 128) {
+      const int64_t p0 = static_cast<int64_t>(ent.first_chunk) * K + kb;
+      const bool two = kb + 64 < K;
+      float acc[2];
+      int64_t arg[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bool on = t == 0 || two;
+        acc[t] = on ? part_val[p0 + 64 * t] : 0.f;
+        arg[t] = (RED == R_SUM || !on) ? 0 : part_arg[p0 + 64 * t];
+      }
+      // 8 partials per K position requested per step, folded in chunk order
       for (uint32_t c = 1; c < ent.num_chunks; c += 8) {
-        float x[8];
+        float x[2][8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-          x[i] = c + i < ent.num_chunks ? part_val[p0 + static_cast<int64_t>(c + i) * K] : 0.f;
+        for (int t = 0; t < 2; ++t) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          if (c + i >= ent.num_chunks) break;
-          if (RED == R_SUM) {
-            acc += x[i];
-          } else if (RED == R_MAX ? (x[i] > acc) : (x[i] < acc)) {
-            acc = x[i];
-            arg = part_arg[p0 + static_cast<int64_t>(c + i) * K];
+          for (int i = 0; i < 8; ++i)
+            x[t][i] = (c + i < ent.num_chunks && (t == 0 || two))
+                          ? part_val[p0 + 64 * t + static_cast<int64_t>(c + i) * K] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            if (c + i >= ent.num_chunks || (t == 1 && !two)) break;
+            if (RED == R_SUM) {
+              acc[t] += x[t][i];
+            } else if (RED == R_MAX ? (x[t][i] > acc[t]) : (x[t][i] < acc[t])) {
+              acc[t] = x[t][i];
+              arg[t] = part_arg[p0 + 64 * t + static_cast<int64_t>(c + i) * K];
+            }
           }
         }
       }
-      if (RED == R_SUM) {
-        if (mean) acc = acc / static_cast<float>(deg);
-      } else {
-        if (arg_out) __builtin_nontemporal_store(arg, arg_out + ent.row * K + k);
-        if (arg_bytes)
-          arg_bytes[ent.row * K + k] = deg > 255 ? uint8_t{255} : static_cast<uint8_t>(arg - rowptr[ent.row]);
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (t == 1 && !two) break;
+        const int64_t k = kb + 64 * t;
+        if (RED == R_SUM) {
+          if (mean) acc[t] = acc[t] / static_cast<float>(deg);
+        } else {
+          if (arg_out) __builtin_nontemporal_store(arg[t], arg_out + ent.row * K + k);
+          if (arg_bytes)
+            arg_bytes[ent.row * K + k] = deg > 255 ? uint8_t{255} : static_cast<uint8_t>(arg[t] - rowptr[ent.row]);
+        }
+        __builtin_nontemporal_store(acc[t], out + ent.row * K + k);
       }
-      __builtin_nontemporal_store(acc, out + ent.row * K + k);
     }
   }
 }
@@ -882,16 +979,18 @@ int launch_fused(int red, const int64_t* rowptr, const int64_t* col, const float
                  const float* mat, float* out, int64_t* arg_out, int64_t M, int64_t K,
                  int64_t nnz, int mean, const LongScratch& w, hipStream_t s,
                  uint8_t* arg_bytes = nullptr, bool nt_gather = false) {
+  const int kFusedChunkBlocks = g_variant == 20 ? 512 : g_variant == 21 ? 1024 : g_variant == 22 ? 1536 : kFusedChunkBlocksDefault;
   const int64_t gx = psa::ceil_div(psa::ceil_div(M, kWaves), 8) * 8 + kFusedChunkBlocks;
   PSA_REQUIRE(gx <= 0x7fffffff, "M too large for one launch");
   const dim3 block(kThreads), grid(static_cast<unsigned>(gx));
-  hipLaunchKernelGGL(find_long_rows_kernel, dim3(static_cast<unsigned>(psa::ceil_div(M, kThreads))),
+  hipLaunchKernelGGL(find_long_rows_kernel, dim3(static_cast<unsigned>(psa::ceil_div(M, kThreads * kFindIters))),
                      block, 0, s, rowptr, M, w.ctr, w.list);
   const dim3 cgrid(kLongBlocks), cblock(psa::kLongThreads);
   MaskArgs plain;
   plain.xcd_rows = g_variant == 16;
   plain.temporal_out = g_variant == 17;
   plain.nt_gather = nt_gather;
+  plain.chunk_blocks = kFusedChunkBlocks;
   plain.arg_bytes_out = arg_bytes;
   // min/max with neither arg_out nor arg_bytes wanted: the instantiation that does
   // not track the winners' edge ids (the combine still folds chunk partials by
@@ -924,10 +1023,11 @@ template <int LPR, int U, int MODE>
 int launch_fused_masked(const int64_t* colptr, const int64_t* row_csc, const float* value,
                         const float* grad, float* out, int64_t N, int64_t K, int64_t nnz,
                         const MaskArgs& mask, const LongScratch& w, hipStream_t s) {
+  const int kFusedChunkBlocks = kFusedChunkBlocksDefault;
   const int64_t gx = psa::ceil_div(N, kWaves) + kFusedChunkBlocks;
   PSA_REQUIRE(gx <= 0x7fffffff, "N too large for one launch");
   const dim3 block(kThreads), grid(static_cast<unsigned>(gx));
-  hipLaunchKernelGGL(find_long_rows_kernel, dim3(static_cast<unsigned>(psa::ceil_div(N, kThreads))),
+  hipLaunchKernelGGL(find_long_rows_kernel, dim3(static_cast<unsigned>(psa::ceil_div(N, kThreads * kFindIters))),
                      block, 0, s, colptr, N, w.ctr, w.list);
   hipLaunchKernelGGL((spmm_fused_kernel<4, LPR, R_SUM, U, MODE>), grid, block, 0, s, colptr, row_csc,
                      value, grad, out, static_cast<int64_t*>(nullptr), N, K, nnz, 0, w.ctr, w.list,
@@ -1258,7 +1358,7 @@ int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* col,
     // 64 < K <= 256 with a workspace: fused roles (R-MAT scale 21: 2.55 -> 2.34 ms
     // against chunk and row launches back to back; uniform graphs unchanged);
     // variant 15 forces the separate launches
-    if ((g_variant == 0 || g_variant == 14 || g_variant == 16 || g_variant == 17 || g_variant == 18 || g_variant == 19) && w.list && q > 16 && q <= 64) {
+    if ((g_variant == 0 || g_variant == 14 || g_variant == 16 || g_variant == 17 || g_variant == 18 || g_variant == 19 || (g_variant >= 20 && g_variant <= 22)) && w.list && q > 16 && q <= 64) {
       *bytes_done = arg_bytes != nullptr && minmax;
       // A dense operand far beyond the 256 MiB Infinity Cache is gathered with
       // non-temporal loads: nothing of it will be hit again, and not allocating

@@ -33,7 +33,9 @@ c = index[1].contiguous()
 for variant, label in ((10, "one wave per row, any length"), (15, "long rows chunked, separate launches"),
                        (0, "production: long rows chunked, roles fused"),
                        (13, "2 rows per wave"), (11, "4 rows per wave"), (12, "8 rows per wave"),
-                       (14, "fused roles: chunks + rows in one launch")):
+                       (14, "fused roles: chunks + rows in one launch"),
+                       (20, "fused roles, 512 chunk workgroups"), (21, "fused roles, 1024 chunk workgroups"),
+                       (22, "fused roles, 1536 chunk workgroups")):
     ops.spmm_set_variant(variant)
     for op in ("spmm_sum", "spmm_max"):
         fn = getattr(ops, op)
