@@ -35,7 +35,8 @@ for variant, label in ((10, "one wave per row, any length"), (15, "long rows chu
                        (13, "2 rows per wave"), (11, "4 rows per wave"), (12, "8 rows per wave"),
                        (14, "fused roles: chunks + rows in one launch"),
                        (20, "fused roles, 512 chunk workgroups"), (21, "fused roles, 1024 chunk workgroups"),
-                       (22, "fused roles, 1536 chunk workgroups")):
+                       (22, "fused roles, 1536 chunk workgroups"),
+                       (7, "two rows per wave side by side (multirow kernel at K = 128)")):
     ops.spmm_set_variant(variant)
     for op in ("spmm_sum", "spmm_max"):
         fn = getattr(ops, op)
