@@ -194,7 +194,10 @@ __device__ __forceinline__ void reduce_edge_range(
 #pragma unroll
   for (int i = 0; i < VEC; ++i) mr[i] = 0.f;
   const bool want_gv = INDIRECT && m.grad_value != nullptr;  // wave-uniform
-  if (want_gv && kact) load_vec<VEC>(m.mrow, mr);
+  if (want_gv && kact) {  // the column's own row of `mat`: read once, streamed past the caches
+    if (m.temporal_out) load_vec<VEC>(m.mrow, mr);
+    else load_vec_nt<VEC>(m.mrow, mr);
+  }
   for (int64_t base = s; base < e; base += 64) {
     const int n = (e - base) < 64 ? static_cast<int>(e - base) : 64;
     int64_t c_l = 0;
@@ -1218,6 +1221,7 @@ int psa_spmm_minmax_bw_csc(const int64_t* rowptr, const int64_t* colptr,
                        s, rowptr, arg_out, M, K, bytes);
   }
   MaskArgs mask;
+  mask.temporal_out = g_variant == 17;
   mask.bytes = arg_bytes != nullptr ? arg_bytes : bytes;
   mask.tag = tag;
   mask.edge_id = csr2csc;
@@ -1264,6 +1268,7 @@ int psa_spmm_sum_bw_csc(const int64_t* colptr, const int64_t* row_csc, const int
   const LongScratch w = carve(workspace, false, K, nnz > 0 ? nnz : 1);
   PSA_ZERO(w.ctr, 8, s);
   MaskArgs mask;
+  mask.temporal_out = g_variant == 17;
   mask.edge_id = csr2csc;
   mask.row_scale = row_scale;
   if (grad_value != nullptr && nnz > 0) {

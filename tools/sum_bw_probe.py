@@ -51,3 +51,10 @@ print("max |gm diff|", float((gm1 - gm3).abs().max()), "max |gv diff|", float((g
 
 csc2csr = st.csc2csr()
 print("one CSC pass + gather to CSR order", ms(lambda: ops.spmm_sum_bw_csc(colptr, row_csc, csr2csc, val_d, B, grad, True, csc2csr=csc2csr)))
+
+# memory-path A/B: variant 17 = ordinary stores and an ordinary load of the column's own mat row
+for v in (0, 17, 0, 17):
+    ops.spmm_set_variant(v)
+    t = ms(lambda: ops.spmm_sum_bw_csc(colptr, row_csc, csr2csc, val_d, B, grad, True, csc2csr=csc2csr))
+    print(f"variant {v}: one CSC pass + gather to CSR order {t:.3f} ms")
+ops.spmm_set_variant(0)
