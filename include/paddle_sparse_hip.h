@@ -107,12 +107,14 @@ int psa_ptr2ind(const int64_t* ptr, int64_t M, int64_t E, int64_t* out,
  * stored — 2 GB fewer writes at M = 2 M, K = 128; with arg_bytes NULL as well
  * the winners are not even tracked: 2.15 -> 1.60 ms, the sum's time — which is
  * what a caller wants that needs `out` only (inference), or whose backward
- * reads arg_bytes alone (complete when no row has more than 255 entries).
+ * reads arg_bytes alone (complete when no row has more than 128 entries).
  * nnz is passed explicitly because rowptr lives on the device.
  *
  * arg_bytes: uint8[M,K] or NULL (MIN/MAX only, needs K % 4 == 0): arg_out once
- * more as the winner's index INSIDE its row, one byte per element (255 for
- * rows of more than 255 edges) — the form psa_spmm_minmax_bw_csc reads.  The
+ * more as the winner's index INSIDE its row, one byte per element (index mod
+ * 128; bit 7 marks rows of more than 128 edges, where equal bytes name a
+ * candidate that the backward checks against arg_out) — the form
+ * psa_spmm_minmax_bw_csc reads.  The
  * forward has it in registers, so writing it here (0.26 GB at M = 2 M, K = 128)
  * saves the backward a pass that re-reads all of arg_out (2 GB).  With
  * arg_out == NULL the bytes must come from the kernel itself (K % 4 == 0 and
@@ -178,7 +180,7 @@ int psa_spmm_minmax_bw(const int64_t* col, const float* value, const float* mat,
  * only: cache it with csr2csc).  value: f32[nnz] in CSR order, or NULL.
  * arg_bytes: what psa_spmm left behind (see there), or NULL — the call then
  * derives it from arg_out itself in a first pass.  arg_out may be NULL when
- * arg_bytes is given and no row has more than 255 entries (entries of longer
+ * arg_bytes is given and no row has more than 128 entries (entries of longer
  * rows need the exact test against arg_out; without it they count as no hit).
  * grad_value_csc: f32[nnz] or NULL (then mat may be NULL too); it is written in
  * CSC order, contiguously — psa_gather_rows(grad_value_csc, csc2csr, nnz, 4, ..)

@@ -134,8 +134,13 @@ using psa::push_long_row;
 // edge_id[j] = (r, c); its term w * grad[r, k] counts for output column k only
 // where the forward's arg_out[r, k] named that edge.  bytes[r, k] holds
 // arg_out[r, k] as an index local to row r (one byte instead of eight), tag[j]
-// the local index of edge j in its row; 255 in either means "row r has more
-// than 255 edges, compare arg_out itself".  `val` is then the CSR-ordered value
+// the local index of edge j in its row.  The byte is (index & 127), plus bit 7
+// when row r has more than 128 edges: for short rows equal bytes ARE the hit; for
+// long rows they name a candidate (the winner, or one of the ~1/128 of the row's
+// edges whose index aliases it) that is then compared against arg_out itself.
+// (A first encoding marked long rows with one reserved value and tested EVERY
+// (edge, k) of such rows against arg_out: 8 K bytes more per edge — on an R-MAT
+// graph, 40 % of whose edges sit in rows above 255, the pass took 8.3 ms.)  `val` is then the CSR-ordered value
 // array (read through edge_id), `col` the CSR row of every CSC edge.
 // With grad_value set, the same pass also forms grad_value[e] = sum over the
 // hit columns k of mat[c, k] * grad[r, k]: the gathered grad row is already in
@@ -152,6 +157,7 @@ using psa::push_long_row;
 enum { M_PLAIN = 0, M_MASK = 1, M_CSC = 2, M_NOARG = 3 };
 
 constexpr int kFusedChunkBlocksDefault = 768;
+constexpr int kByteExact = 128;  // rows up to this many edges: the one-byte form of arg_out is exact
 
 struct MaskArgs {
   const uint8_t* bytes = nullptr;    // [M, K] at the lane's k0
@@ -241,21 +247,53 @@ __device__ __forceinline__ void reduce_edge_range(
         }
       }
       if (MASK) {
+        // Phase 1: byte compare.  hits bit i = (u, i) counts; need bit i = it is only a
+        // candidate (row of more than 128 edges) and must be checked against arg_out.
+        uint32_t hits[U], need[U];
+        bool any_need = false;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           // edge id / row are re-read from their lanes here rather than kept in
           // registers across the gathers (88 -> fewer VGPRs, one more wave per SIMD)
           const int idx = j + u * G + g;
-          const int64_t id = shfl_i64(id_l, idx);
-          const int64_t r = shfl_i64(c_l, idx);
-          const uint32_t tag = static_cast<uint32_t>(static_cast<uint64_t>(id) >> 56);
+          const uint32_t tag = static_cast<uint32_t>(static_cast<uint64_t>(shfl_i64(id_l, idx)) >> 56);
+          hits[u] = 0;
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) hits[u] |= static_cast<uint32_t>(((mb[u] >> (8 * i)) & 255u) == tag) << i;
+          need[u] = ((tag & 0x80u) && ok[u]) ? hits[u] : 0u;
+          any_need |= need[u] != 0;
+        }
+        // Phase 2 (power-law graphs only): ALL exact tests of the step are requested
+        // before any is consumed — one at a time, each a dependent memory round trip
+        // inside the gather loop, they made this pass 1.5x slower than float atomics
+        // on an R-MAT graph.  The low words decide: arg_out[r, k] is an edge of row r,
+        // and two edges of one row differ in their low 32 bits.
+        if (__any(any_need)) {
+          int32_t seen[U][VEC];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int64_t r = shfl_i64(c_l, j + u * G + g);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+              seen[u][i] = 0;
+              if (((need[u] >> i) & 1u) && m.arg != nullptr)
+                seen[u][i] = *reinterpret_cast<const int32_t*>(m.arg + r * K + i);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int32_t id_lo = static_cast<int32_t>(shfl_i64(id_l, j + u * G + g));
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) {
+              if (((need[u] >> i) & 1u) && (m.arg == nullptr || seen[u][i] != id_lo)) hits[u] &= ~(1u << i);
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
 #pragma unroll
           for (int i = 0; i < VEC; ++i) {
-            const uint32_t byte = (mb[u] >> (8 * i)) & 255u;
-            bool hit = byte == tag;
-            if (hit && tag == 255u && ok[u])  // a row of more than 255 edges: exact test
-              hit = m.arg != nullptr && m.arg[r * K + i] == (id & 0x00ffffffffffffffll);
-            if (!hit) b[u][i] = 0.f;
+            if (!((hits[u] >> i) & 1u)) b[u][i] = 0.f;
           }
         }
       }
@@ -742,7 +780,7 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
         uint32_t packed = 0;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) {
-          const uint32_t b = deg > 255 ? 255u : static_cast<uint32_t>((arg[i] - s) & 255);
+          const uint32_t b = static_cast<uint32_t>((arg[i] - s) & 127) | (deg > kByteExact ? 0x80u : 0u);
           packed |= b << (8 * i);
         }
         __builtin_nontemporal_store(packed, reinterpret_cast<uint32_t*>(mask.arg_bytes_out + row * K + k0));
@@ -816,7 +854,8 @@ spmm_long_combine_kernel(const int64_t* __restrict__ rowptr, int64_t K, int mean
         } else {
           if (arg_out) __builtin_nontemporal_store(arg[t], arg_out + ent.row * K + k);
           if (arg_bytes)
-            arg_bytes[ent.row * K + k] = deg > 255 ? uint8_t{255} : static_cast<uint8_t>(arg[t] - rowptr[ent.row]);
+            arg_bytes[ent.row * K + k] =
+                static_cast<uint8_t>(((arg[t] - rowptr[ent.row]) & 127) | (deg > kByteExact ? 0x80 : 0));
         }
         __builtin_nontemporal_store(acc[t], out + ent.row * K + k);
       }
@@ -912,7 +951,7 @@ spmm_multirow_kernel(const int64_t* __restrict__ rowptr,
       uint32_t packed = 0;
 #pragma unroll
       for (int i = 0; i < VEC; ++i) {
-        const uint32_t b = deg > 255 ? 255u : static_cast<uint32_t>((arg[i] - s) & 255);
+        const uint32_t b = static_cast<uint32_t>((arg[i] - s) & 127) | (deg > kByteExact ? 0x80u : 0u);
         packed |= b << (8 * i);
       }
       __builtin_nontemporal_store(packed, reinterpret_cast<uint32_t*>(arg_bytes + row * K + k0));
@@ -1042,8 +1081,8 @@ int launch_fused_masked(const int64_t* colptr, const int64_t* row_csc, const flo
   return PSA_OK;
 }
 
-// bytes[r, k] = arg_out[r, k] as an index local to row r; 255 for rows of more
-// than 255 edges (and for empty rows, which no edge ever asks about).  Four
+// bytes[r, k] = arg_out[r, k] as an index local to row r, mod 128, bit 7 set for
+// rows of more than 128 edges (empty rows: whatever, no edge ever asks).  Four
 // elements per thread: 32 B in, 4 B out.
 __global__ void __launch_bounds__(kThreads)
 minmax_compress_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ arg_out,
@@ -1053,20 +1092,20 @@ minmax_compress_kernel(const int64_t* __restrict__ rowptr, const int64_t* __rest
   if (q >= M * kq) return;
   const int64_t r = q / kq;
   const int64_t start = rowptr[r];
-  const bool big = rowptr[r + 1] - start > 255;
+  const bool big = rowptr[r + 1] - start > kByteExact;
   const longlong2 a01 = *reinterpret_cast<const longlong2*>(arg_out + 4 * q);
   const longlong2 a23 = *reinterpret_cast<const longlong2*>(arg_out + 4 * q + 2);
   const int64_t a[4] = {a01.x, a01.y, a23.x, a23.y};
   uint32_t packed = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const uint32_t b = big ? 255u : static_cast<uint32_t>((a[i] - start) & 255);
+    const uint32_t b = static_cast<uint32_t>((a[i] - start) & 127) | (big ? 0x80u : 0u);
     packed |= b << (8 * i);
   }
   *reinterpret_cast<uint32_t*>(bytes + 4 * q) = packed;
 }
 
-// tag[j] = index of CSC edge j inside its CSR row (255: row of more than 255 edges).
+// tag[j] = index of CSC edge j inside its CSR row, mod 128, bit 7 set for rows of more than 128 edges.
 __global__ void __launch_bounds__(kThreads)
 csc_edge_tags_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ row_csc,
                      const int64_t* __restrict__ csr2csc, int64_t nnz,
@@ -1075,7 +1114,7 @@ csc_edge_tags_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restri
   if (j >= nnz) return;
   const int64_t r = row_csc[j];
   const int64_t start = rowptr[r];
-  tag[j] = rowptr[r + 1] - start > 255 ? 255 : static_cast<uint8_t>(csr2csc[j] - start);
+  tag[j] = static_cast<uint8_t>(((csr2csc[j] - start) & 127) | (rowptr[r + 1] - start > kByteExact ? 0x80 : 0));
 }
 
 template <int VEC, int LPR, int U>

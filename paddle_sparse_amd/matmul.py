@@ -52,11 +52,11 @@ class _SpMM(torch.autograd.Function):
             # 3.3 at 2 M x 128): it is skipped when nothing will be differentiated,
             # and when the one-pass backward over the CSC view will run (grad of
             # mat wanted, K tile supported) on a matrix whose rows all have at most
-            # 255 entries — the one-byte row-local form is then the whole answer.
+            # 128 entries — the one-byte row-local form is then the whole answer.
             need_value = track and value is not None and ctx.needs_input_grad[0]
             need_mat = track and ctx.needs_input_grad[1]
             csc_bw = need_mat and ops.minmax_bw_csc_supported(mat.shape[1])
-            bytes_only = csc_bw and storage._longest_row() <= 255
+            bytes_only = csc_bw and storage._longest_row() <= ops.ARG_BYTES_EXACT_ROW
             want_arg = (need_value or need_mat) and not bytes_only
             res = ops._spmm(reduce, rowptr, col, value, mat, want_arg_bytes=csc_bw, want_arg=want_arg)
             out, arg, arg_bytes = res if csc_bw else (*res, None)

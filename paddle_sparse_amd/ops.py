@@ -80,7 +80,7 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
     want_arg=False (min/max) skips the int64 arg_out altogether: the kernel then
     stores `out` (and the bytes, if asked for) only — two thirds of the output
     traffic gone; for callers that need no backward, or whose backward is served
-    by the bytes alone (no row longer than 255 entries)."""
+    by the bytes alone (no row longer than ARG_BYTES_EXACT_ROW entries)."""
     rowptr = _index(rowptr, "rowptr")
     col = _index(col, "col")
     _gpu(mat, "mat")
@@ -122,6 +122,10 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
     if want_arg_bytes:
         return out, arg, arg_bytes
     return out, arg
+
+
+# rows up to this many entries: the one-byte form of arg_out (arg_bytes) needs no arg_out beside it
+ARG_BYTES_EXACT_ROW = 128
 
 
 def spmm_sum(rowptr, col, value, mat) -> torch.Tensor:
@@ -475,8 +479,8 @@ def spmm_minmax_bw(col, value, mat, grad, arg_out, want_value: bool = True, want
 
 
 def csc_edge_tags(rowptr, row_csc, csr2csc) -> torch.Tensor:
-    """uint8[nnz]: position of every CSC-ordered edge inside its CSR row (255 for
-    rows of more than 255 edges).  Structure only — cache it next to csr2csc."""
+    """uint8[nnz]: position of every CSC-ordered edge inside its CSR row (mod 128;
+    bit 7 marks rows of more than 128 edges).  Structure only — cache it next to csr2csc."""
     rowptr, row_csc, csr2csc = _index(rowptr, "rowptr"), _index(row_csc, "row_csc"), _index(csr2csc, "csr2csc")
     tag = torch.empty(csr2csc.numel(), dtype=torch.uint8, device=csr2csc.device)
     with torch.cuda.device(csr2csc.device):

@@ -308,7 +308,7 @@ class SparseStorage(object):
 
     def _longest_row(self) -> int:
         """Entries of the longest row (memoised; the min/max forward asks whether
-        the one-byte form of arg_out is complete, i.e. no row above 255)."""
+        the one-byte form of arg_out is complete, i.e. no row above 128)."""
         if self._max_rowcount is None:
             self._max_rowcount = int(self.rowcount().max().item()) if self._sparse_sizes[0] > 0 else 0
         return self._max_rowcount

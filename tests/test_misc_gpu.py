@@ -225,7 +225,7 @@ def test_forward_leaves_arg_out_as_row_local_bytes(reduce, K):
     combine) or by the compress pass behind the other kernels."""
     from paddle_sparse_amd import SparseStorage, ops
 
-    # rows of 0, a few, 200 (chunked: > 128) and 700 (> 255: marked 255) edges
+    # rows of 0, a few, 200 and 700 edges (> 128: chunked, and flagged in the byte form)
     row, rowptr, col, val = skewed_csr(900, 300, seed=K, long_rows=(0, 450), long_deg=700)
     row2, rowptr2, col2, val2 = skewed_csr(900, 300, seed=K + 1, long_rows=(3, 899), long_deg=200)
     for rp, c, v in ((rowptr, col, val), (rowptr2, col2, val2)):
@@ -235,7 +235,7 @@ def test_forward_leaves_arg_out_as_row_local_bytes(reduce, K):
         assert np.array_equal(arg.cpu().numpy(), ref_arg)
         deg = rp[1:] - rp[:-1]
         live = deg > 0
-        want = np.where((deg > 255)[:, None], 255, ref_arg - rp[:-1, None]).astype(np.uint8)
+        want = (((ref_arg - rp[:-1, None]) & 127) | np.where(deg > 128, 0x80, 0)[:, None]).astype(np.uint8)
         assert ab.dtype == torch.uint8 and np.array_equal(ab.cpu().numpy()[live], want[live])
         # the backward gives the same bits with the bytes handed in or derived inside
         st = SparseStorage(rowptr=dev(rp), col=dev(c), value=dev(v), sparse_sizes=(900, 300), is_sorted=True)
@@ -256,7 +256,7 @@ def test_minmax_forward_without_arg_out(reduce, K):
     from paddle_sparse_amd import SparseStorage, ops
     from paddle_sparse_amd._lib import HipCoreError
 
-    for long_deg in (200, 700):  # chunked rows; rows past the byte form's reach
+    for long_deg in (100, 200, 700):  # short rows only; chunked rows past the byte form's exact reach (128)
         row, rowptr, col, val = skewed_csr(900, 300, seed=K + long_deg, long_rows=(0, 450), long_deg=long_deg)
         B = np.random.default_rng(K).standard_normal((300, K)).astype(np.float32)
         full = ops._spmm(reduce, dev(rowptr), dev(col), dev(val), dev(B), want_arg_bytes=True)
@@ -277,10 +277,10 @@ def test_minmax_forward_without_arg_out(reduce, K):
                 dev(B), G)
         gv_ref, gm_ref = ops.spmm_minmax_bw_csc(*head, full[1], csc2csr=st.csc2csr(), arg_bytes=full[2])
         gv, gm = ops.spmm_minmax_bw_csc(*head, None, csc2csr=st.csc2csr(), arg_bytes=ab)
-        if long_deg <= 255:
+        if long_deg <= ops.ARG_BYTES_EXACT_ROW:
             assert torch.equal(gv, gv_ref) and torch.equal(gm, gm_ref)
-        else:  # documented: entries of rows past 255 count as no hit without arg_out (and nothing faults)
-            short = torch.from_numpy(((rowptr[1:] - rowptr[:-1]) <= 255)[row]).cuda()
+        else:  # documented: entries of rows past 128 count as no hit without arg_out (and nothing faults)
+            short = torch.from_numpy(((rowptr[1:] - rowptr[:-1]) <= 128)[row]).cuda()
             assert torch.equal(gv[short], gv_ref[short])
     if ops.minmax_bw_csc_supported(K):
         with pytest.raises(ValueError, match="arg_out or arg_bytes"):
@@ -314,7 +314,7 @@ def test_autograd_minmax_skips_arg_out_when_the_bytes_suffice(reduce):
         seen.append((k.get("want_arg_bytes", False), k.get("want_arg", True)))
         return real(*a, **k)
 
-    for long_deg, expect in ((100, (True, False)), (400, (True, True))):
+    for long_deg, expect in ((100, (True, False)), (200, (True, True))):
         row, rowptr, col, val = skewed_csr(700, 300, seed=long_deg, long_rows=(5,), long_deg=long_deg)
         B = torch.randn(300, 64, device="cuda")
         grads = []
