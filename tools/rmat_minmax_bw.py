@@ -58,3 +58,12 @@ gv2, gm2 = ops.spmm_minmax_bw(st.col(), val, B, G, arg)
 print("against the atomics backward: max |grad_mat diff| / max |grad_mat| =",
       float((gm - gm2).abs().max() / gm2.abs().max()), " grad_value equal:", bool(torch.equal(gv, gv2)))
 print(f"atomics backward, both gradients:     {ms(lambda: ops.spmm_minmax_bw(st.col(), val, B, G, arg)):.3f} ms")
+
+# the sum backward on the same graph: one pass over the CSC view against the three-kernel form
+w = ops.transpose_weights(val, st.csr2csc(), None, None, False)
+t3 = ms(lambda: (ops.spmm_value_bw(None, st.rowptr(), st.col(), B, G, "sum"),
+                 ops.transpose_weights(val, st.csr2csc(), None, None, False),
+                 ops.spmm_sum(st.colptr(), st._row_in_csc_order(), w, G)))
+t1 = ms(lambda: ops.spmm_sum_bw_csc(st.colptr(), st._row_in_csc_order(), st.csr2csc(), val, B, G, True, csc2csr=inv))
+print(f"sum backward, both gradients: one CSC pass {t1:.3f} ms; value_bw + weight gather + SpMM over CSC {t3:.3f} ms")
+print(f"spmm_sum forward: {ms(lambda: ops.spmm_sum(st.rowptr(), st.col(), val, B)):.3f} ms")
