@@ -7,6 +7,7 @@
           writes = M*4F.  Calibrates FETCH_SIZE / WRITE_SIZE for this access
           pattern (MI355X_MICROARCH.md §HBM says to).
   c3    : BASELINE config 3 (the bench workload), a few launches.
+  rmat  : the R-MAT scale-21 graph of tools/spmm_rmat.py.
 """
 import sys
 from pathlib import Path
@@ -27,6 +28,20 @@ if which == "calib":
     rowptr = torch.arange(M + 1, device=dev)
     col = torch.randperm(N, generator=g, device=dev)
     val = torch.randn(M, generator=g, device=dev)
+elif which == "rmat":  # the power-law graph of tools/spmm_rmat.py (scale 21, 20 M edges before coalescing)
+    from paddle_sparse_amd import coalesce
+
+    M = N = 1 << 21
+    g = torch.Generator(device=dev).manual_seed(4)
+    n = 20_000_000
+    row = torch.zeros(n, dtype=torch.int64, device=dev)
+    col = torch.zeros(n, dtype=torch.int64, device=dev)
+    for bit in range(21):
+        r = torch.rand(n, generator=g, device=dev)
+        row |= (r >= 0.76).to(torch.int64) << bit
+        col |= (((r >= 0.57) & (r < 0.76)) | (r >= 0.95)).to(torch.int64) << bit
+    index, val = coalesce(torch.stack([row, col]), torch.randn(n, generator=g, device=dev), N, N)
+    rowptr, col = ops.ind2ptr(index[0].contiguous(), M), index[1].contiguous()
 else:
     rowptr, col, val = make_workload(M, N, 20_000_000, F, 2, dev)
 B = torch.randn(N, F, device=dev)
