@@ -707,7 +707,7 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane / LPR;
   const int l = lane % LPR;
-  const int64_t k0 = l * VEC;
+  const int64_t k0 = (static_cast<int64_t>(blockIdx.y) * LPR + l) * VEC;  // K tiles of LPR * VEC floats over grid.y
   const bool kact = k0 < K;
   float acc[VEC];
   int64_t arg[VEC];
@@ -1020,11 +1020,12 @@ template <int VEC, int LPR, int U>
 int launch_fused(int red, const int64_t* rowptr, const int64_t* col, const float* val,
                  const float* mat, float* out, int64_t* arg_out, int64_t M, int64_t K,
                  int64_t nnz, int mean, const LongScratch& w, hipStream_t s,
-                 uint8_t* arg_bytes = nullptr, bool nt_gather = false) {
+                 uint8_t* arg_bytes = nullptr, bool nt_gather = false, int k_tiles = 1) {
   const int kFusedChunkBlocks = g_variant == 20 ? 512 : g_variant == 21 ? 1024 : g_variant == 22 ? 1536 : kFusedChunkBlocksDefault;
   const int64_t gx = psa::ceil_div(psa::ceil_div(M, kWaves), 8) * 8 + kFusedChunkBlocks;
   PSA_REQUIRE(gx <= 0x7fffffff, "M too large for one launch");
-  const dim3 block(kThreads), grid(static_cast<unsigned>(gx));
+  PSA_REQUIRE(k_tiles >= 1 && k_tiles <= 65535, "too many K tiles");
+  const dim3 block(kThreads), grid(static_cast<unsigned>(gx), static_cast<unsigned>(k_tiles));
   hipLaunchKernelGGL(find_long_rows_kernel, dim3(static_cast<unsigned>(psa::ceil_div(M, kThreads * kFindIters))),
                      block, 0, s, rowptr, M, w.ctr, w.list);
   const dim3 cgrid(kLongBlocks), cblock(psa::kLongThreads);
@@ -1402,16 +1403,23 @@ int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* col,
     // 64 < K <= 256 with a workspace: fused roles (R-MAT scale 21: 2.55 -> 2.34 ms
     // against chunk and row launches back to back; uniform graphs unchanged);
     // variant 15 forces the separate launches
-    if ((g_variant == 0 || g_variant == 14 || g_variant == 16 || g_variant == 17 || g_variant == 18 || g_variant == 19 || (g_variant >= 20 && g_variant <= 22)) && w.list && q > 16 && q <= 64) {
+    if ((g_variant == 0 || g_variant == 14 || g_variant == 16 || g_variant == 17 || g_variant == 18 || g_variant == 19 || (g_variant >= 20 && g_variant <= 22) || g_variant == 25) && w.list && q > 16 &&
+        (q <= 64 || K % 128 == 0)) {
       *bytes_done = arg_bytes != nullptr && minmax;
       // A dense operand far beyond the 256 MiB Infinity Cache is gathered with
       // non-temporal loads: nothing of it will be hit again, and not allocating
       // the lines is worth 4-5 % at 8-16 GiB (tools/nt_gather_sweep.py: break-even
       // at ~4 GiB, 0.85x at 1 GiB where a quarter of B does stay cached).
       const bool nt_gather = g_variant == 18 || (g_variant == 0 && N * K * 4 >= kNtGatherBytes);
-      if (q <= 32)
+      // Any multiple of 128 beyond 128 runs as K / 128 tiles of the K = 128 form
+      // (32 lanes x float4, two edges per gather instruction) over grid.y: K = 256
+      // 3.66 -> 3.30 ms (0.78 -> 0.86 of peak) against one tile of 64 lanes x float4,
+      // K = 512 7.49 -> 6.75 ms against the row kernel (variant 25 keeps the old
+      // choice for K = 256).  col / value are read once per tile: +1 % of the bytes.
+      if (q <= 32 || (K % 128 == 0 && (g_variant != 25 || q > 64)))
         return launch_fused<4, 32, 4>(red, rowptr, col, value, mat, out, arg_out, M, K, nnz, mean, w, s,
-                                      minmax ? arg_bytes : nullptr, nt_gather);
+                                      minmax ? arg_bytes : nullptr, nt_gather,
+                                      static_cast<int>(psa::ceil_div(K, 128)));
       return launch_fused<4, 64, 8>(red, rowptr, col, value, mat, out, arg_out, M, K, nnz, mean, w, s,
                                     minmax ? arg_bytes : nullptr, nt_gather);
     }

@@ -142,7 +142,7 @@ def test_multirow_variants_narrow_k(variant, K):
 
 
 @pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max"])
-@pytest.mark.parametrize("K", [4, 32, 64, 100, 128, 256, 300])
+@pytest.mark.parametrize("K", [4, 32, 64, 100, 128, 256, 300, 384, 512])
 def test_long_rows_take_the_chunked_path(reduce, K):
     """Rows above 512 edges are split into 256-edge chunks reduced by separate
     waves and folded in chunk order; results must match the single-wave path
@@ -159,7 +159,12 @@ def test_long_rows_take_the_chunked_path(reduce, K):
         separate = check(reduce, rowptr, col, val, B)
     finally:
         ops.spmm_set_variant(prev)
-    assert np.array_equal(separate, out)  # same chunking, same fold order
+    if K % 128 == 0 and K > 128:
+        # production runs these as K / 128 tiles of 32 lanes (two edges per gather step, folded
+        # across the two lane groups); the separate launches use one 64-lane tile: other order
+        assert np.all(np.abs(separate - out) <= RTOL * oracle.spmm_abs_sum(rowptr, col, val, B) + 1e-30)
+    else:
+        assert np.array_equal(separate, out)  # same chunking, same fold order
     prev = ops.spmm_set_variant(10)
     try:
         ref_out, ref_arg = run_gpu(reduce, rowptr, col, val, B)
