@@ -1410,7 +1410,7 @@ int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* col,
       // non-temporal loads: nothing of it will be hit again, and not allocating
       // the lines is worth 4-5 % at 8-16 GiB (tools/nt_gather_sweep.py: break-even
       // at ~4 GiB, 0.85x at 1 GiB where a quarter of B does stay cached).
-      const bool nt_gather = g_variant == 18 || (g_variant == 0 && N * K * 4 >= kNtGatherBytes);
+      const bool nt_gather = g_variant == 18 || ((g_variant == 0 || g_variant == 25) && N * K * 4 >= kNtGatherBytes);
       // Any multiple of 128 beyond 128 runs as K / 128 tiles of the K = 128 form
       // (32 lanes x float4, two edges per gather instruction) over grid.y: K = 256
       // 3.66 -> 3.30 ms (0.78 -> 0.86 of peak) against one tile of 64 lanes x float4,

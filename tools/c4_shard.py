@@ -45,7 +45,7 @@ alg = NNZ * (8 + 4 + 4 * F) + M_LOCAL * (8 + 4 * F)
 print(f"C4 shard: {M_LOCAL} rows x {N} cols, nnz {NNZ}, F {F}: spmm_sum {t:.3f} ms = {NNZ / t / 1e6:.2f} GEdges/s, "
       f"{alg / 1e9:.2f} GB algorithmic -> {alg / t / 1e9:.2f} TB/s = {100 * alg / t / 1e9 / 8:.1f}% of 8 TB/s")
 # the production path gathers an operand this far beyond the Infinity Cache non-temporally (spmm.hip, kNtGatherBytes)
-for variant, what in ((17, "ordinary output stores and ordinary gathers"),):
+for variant, what in ((17, "ordinary output stores and ordinary gathers"), (25, "one 64-lane K tile instead of two 32-lane tiles")):
     ops.spmm_set_variant(variant)
     tv = ms(lambda: ops.spmm_sum(rowptr, col, val, B))
     print(f"  variant {variant} ({what}): {tv:.3f} ms")
