@@ -1403,20 +1403,23 @@ int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* col,
     // 64 < K <= 256 with a workspace: fused roles (R-MAT scale 21: 2.55 -> 2.34 ms
     // against chunk and row launches back to back; uniform graphs unchanged);
     // variant 15 forces the separate launches
-    if ((g_variant == 0 || g_variant == 14 || g_variant == 16 || g_variant == 17 || g_variant == 18 || g_variant == 19 || (g_variant >= 20 && g_variant <= 22) || g_variant == 25) && w.list && q > 16 &&
-        (q <= 64 || K % 128 == 0)) {
+    if ((g_variant == 0 || g_variant == 14 || g_variant == 16 || g_variant == 17 || g_variant == 18 || g_variant == 19 || (g_variant >= 20 && g_variant <= 22) || g_variant == 25 || g_variant == 26) && w.list && q > 16 &&
+        (q <= 64 || g_variant != 25)) {
       *bytes_done = arg_bytes != nullptr && minmax;
       // A dense operand far beyond the 256 MiB Infinity Cache is gathered with
       // non-temporal loads: nothing of it will be hit again, and not allocating
       // the lines is worth 4-5 % at 8-16 GiB (tools/nt_gather_sweep.py: break-even
       // at ~4 GiB, 0.85x at 1 GiB where a quarter of B does stay cached).
       const bool nt_gather = g_variant == 18 || ((g_variant == 0 || g_variant == 25) && N * K * 4 >= kNtGatherBytes);
-      // Any multiple of 128 beyond 128 runs as K / 128 tiles of the K = 128 form
-      // (32 lanes x float4, two edges per gather instruction) over grid.y: K = 256
-      // 3.66 -> 3.30 ms (0.78 -> 0.86 of peak) against one tile of 64 lanes x float4,
-      // K = 512 7.49 -> 6.75 ms against the row kernel (variant 25 keeps the old
-      // choice for K = 256).  col / value are read once per tile: +1 % of the bytes.
-      if (q <= 32 || (K % 128 == 0 && (g_variant != 25 || q > 64)))
+      // K >= 192 runs as ceil(K / 128) tiles of the K = 128 form (32 lanes x float4,
+      // two edges per gather instruction) over grid.y; measured against one tile of
+      // 64 lanes x float4 (K <= 256) or the row kernel (K > 256), 2 M rows / 20 M edges:
+      // K = 192 2.67 -> 2.58 ms, 224 3.22 -> 2.88, 256 3.66 -> 3.30 (0.78 -> 0.86 of
+      // peak), 320 4.79 -> 4.20, 448 6.37 -> 5.85, 512 7.49 -> 6.75; K = 160 is better
+      // off as one tile (2.12 vs 2.45 ms).  col / value are read once per tile (+1 % of
+      // the bytes).  Variant 25 keeps the old choices, 26 tiles every K > 128.
+      const bool tiled = (K >= 192 && g_variant != 25) || (K > 128 && g_variant == 26);
+      if (q <= 32 || tiled)
         return launch_fused<4, 32, 4>(red, rowptr, col, value, mat, out, arg_out, M, K, nnz, mean, w, s,
                                       minmax ? arg_bytes : nullptr, nt_gather,
                                       static_cast<int>(psa::ceil_div(K, 128)));

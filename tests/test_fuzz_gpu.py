@@ -44,7 +44,7 @@ def test_spmm_forward_backward_random_shapes(seed):
 
     rng = np.random.default_rng(1000 + seed)
     M, N, row, col = random_graph(rng)
-    K = int(rng.choice([1, 2, 3, 4, 7, 8, 16, 20, 31, 32, 33, 64, 65, 100, 128, 130, 192, 256, 260, 300, 384, 512]))
+    K = int(rng.choice([1, 2, 3, 4, 7, 8, 16, 20, 31, 32, 33, 64, 65, 100, 128, 130, 160, 192, 224, 256, 260, 300, 320, 384, 512]))
     reduce = ["sum", "mean", "min", "max"][seed % 4]
     has_value = bool(rng.integers(0, 2))
     nnz = row.size
