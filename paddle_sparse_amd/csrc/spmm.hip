@@ -715,7 +715,7 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
     mask.bytes += k0;
     mask.arg += k0;
   }
-  const int kFusedChunkBlocks = mask.chunk_blocks;
+  const unsigned kFusedChunkBlocks = static_cast<unsigned>(mask.chunk_blocks);
   if (blockIdx.x < kFusedChunkBlocks) {  // ---- chunk role ----
     const unsigned long long ctr = *long_ctr;
     const uint32_t total = static_cast<uint32_t>(ctr & 0xffffffffull);
