@@ -19,6 +19,7 @@ LIB_PATH = Path(__file__).resolve().parent / "lib" / "libpaddle_sparse_hip.so"
 
 SUM, MEAN, MIN, MAX = 0, 1, 2, 3
 REDUCE_ID = {"sum": SUM, "add": SUM, "mean": MEAN, "min": MIN, "max": MAX}
+SPMM_ALGO_ID = {"auto": 0, "row_waves": 1, "edge_ranges": 2}
 
 # name -> (restype, argtypes); mirrors include/paddle_sparse_hip.h one to one
 # (tests/test_abi.py parses the header and checks this table against it).
@@ -32,6 +33,10 @@ SIGNATURES = {
     "psa_spmm": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                          c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                          c_size_t, c_void_p]),
+    "psa_spmm_coo": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                             c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                             c_size_t, c_void_p]),
+    "psa_csr_row_stats": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "psa_spmm_set_variant": (c_int, [c_int]),
     "psa_spmm_value_bw_workspace_bytes": (c_size_t, [c_int64]),
     "psa_spmm_value_bw": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,

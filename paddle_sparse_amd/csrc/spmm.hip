@@ -15,6 +15,8 @@
 //   * partial sums of the 64/LPR edge slots are folded with wave shuffles.
 #include "common.h"
 #include "long_rows.h"
+#include "spmm_eb.h"
+#include "vec_io.h"
 
 namespace {
 
@@ -23,88 +25,13 @@ constexpr int kWaves = kThreads / 64;
 
 enum { R_SUM = 0, R_MIN = 1, R_MAX = 2 };
 
-template <int VEC>
-struct Vec;
-template <>
-struct Vec<1> {
-  using T = float;
-};
-template <>
-struct Vec<2> {
-  using T = float2;
-};
-template <>
-struct Vec<4> {
-  using T = float4;
-};
-
-template <int VEC>
-__device__ __forceinline__ void load_vec(const float* p, float (&dst)[VEC]) {
-  using T = typename Vec<VEC>::T;
-  const T v = *reinterpret_cast<const T*>(p);
-  const float* f = reinterpret_cast<const float*>(&v);
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) dst[i] = f[i];
-}
-
-template <int VEC>
-__device__ __forceinline__ void store_vec(float* p, const float (&src)[VEC]) {
-  using T = typename Vec<VEC>::T;
-  T v;
-  float* f = reinterpret_cast<float*>(&v);
-#pragma unroll
-  for (int i = 0; i < VEC; ++i) f[i] = src[i];
-  *reinterpret_cast<T*>(p) = v;
-}
-
-// Non-temporal stores for the outputs (out, arg_out, arg_bytes, grad_value): they
-// are written once and never read by the writing kernel.  Measured on config 3
-// (one process, interleaved, variant 17 = ordinary stores): spmm_sum 1.684 ->
-// 1.606 ms (0.86 -> 0.90 of the HBM peak), spmm_max 2.157 -> 2.036 ms.  The PMC
-// traffic is the same both ways (9.09 GB fetched, 1.02 GB written, TCC hit rate
-// 8.5 %): the write stream travels better beside the gathers, B is not cached
-// any better.  Marking the col / value loads the same way changed nothing.
-template <int VEC>
-__device__ __forceinline__ void load_vec_nt(const float* p, float (&dst)[VEC]) {
-  if constexpr (VEC == 1) {
-    dst[0] = __builtin_nontemporal_load(p);
-  } else {
-    typedef float V __attribute__((ext_vector_type(VEC)));
-    const V v = __builtin_nontemporal_load(reinterpret_cast<const V*>(p));
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) dst[i] = v[i];
-  }
-}
-
-template <int VEC>
-__device__ __forceinline__ void store_vec_nt(float* p, const float (&src)[VEC]) {
-  if constexpr (VEC == 1) {
-    __builtin_nontemporal_store(src[0], p);
-  } else {
-    typedef float V __attribute__((ext_vector_type(VEC)));
-    V v;
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) v[i] = src[i];
-    __builtin_nontemporal_store(v, reinterpret_cast<V*>(p));
-  }
-}
-
-template <int VEC>
-__device__ __forceinline__ void store_arg_nt(int64_t* p, const int64_t (&src)[VEC]) {
-  if constexpr (VEC == 1) {
-    __builtin_nontemporal_store(src[0], p);
-  } else {
-    typedef long V __attribute__((ext_vector_type(VEC)));
-    V v;
-#pragma unroll
-    for (int i = 0; i < VEC; ++i) v[i] = src[i];
-    __builtin_nontemporal_store(v, reinterpret_cast<V*>(p));
-  }
-}
-
-__device__ __forceinline__ int64_t shfl_i64(int64_t x, int src) {
-  return __shfl(static_cast<long long>(x), src);
-}
+using psa::load_vec;
+using psa::load_vec_nt;
+using psa::shfl_i64;
+using psa::store_arg_nt;
+using psa::store_vec;
+using psa::store_vec_nt;
+using psa::Vec;
 
 // ---------------------------------------------------------------------------
 // Long rows (power-law graphs).  One wave pulls only a few GB/s (8 gathers in
@@ -1324,8 +1251,11 @@ int psa_spmm_sum_bw_csc(const int64_t* colptr, const int64_t* row_csc, const int
 }
 
 size_t psa_spmm_workspace_bytes(int reduce, int64_t K, int64_t nnz) {
-  if (K <= 0 || nnz <= kLongRow) return 0;  // no row can be long
-  return long_workspace_bytes(reduce == PSA_MIN || reduce == PSA_MAX, K, nnz);
+  if (K <= 0 || nnz <= 0) return 0;
+  const bool minmax = reduce == PSA_MIN || reduce == PSA_MAX;
+  const size_t eb = K % 4 == 0 ? psa::eb_workspace_bytes(minmax, K, nnz) : 0;
+  const size_t lr = nnz > kLongRow ? long_workspace_bytes(minmax, K, nnz) : 0;  // else no row can be long
+  return eb > lr ? eb : lr;
 }
 
 }  // extern "C"
@@ -1334,12 +1264,13 @@ namespace {
 
 // psa_spmm proper; *bytes_done tells whether the kernel that ran also stored
 // arg_bytes (only the fused-roles path does, the caller compresses otherwise).
-int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* col,
+int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* row, const int64_t* col,
                   const float* value, const float* mat, int64_t M, int64_t N,
                   int64_t K, int64_t nnz, float* out, int64_t* arg_out,
                   void* workspace, size_t workspace_bytes, hipStream_t s,
-                  uint8_t* arg_bytes, bool* bytes_done) {
+                  uint8_t* arg_bytes, bool* bytes_done, int algo) {
   PSA_REQUIRE(reduce >= PSA_SUM && reduce <= PSA_MAX, "bad reduce");
+  PSA_REQUIRE(algo >= PSA_SPMM_AUTO && algo <= PSA_SPMM_EDGE_RANGES, "bad algo");
   PSA_REQUIRE(M >= 0 && N >= 0 && K >= 0 && nnz >= 0, "negative size");
   if (M == 0 || K == 0) return PSA_OK;
   PSA_REQUIRE(rowptr != nullptr, "rowptr is NULL");
@@ -1349,6 +1280,19 @@ int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* col,
   const bool minmax = reduce == PSA_MIN || reduce == PSA_MAX;
   const int red = reduce == PSA_MIN ? R_MIN : (reduce == PSA_MAX ? R_MAX : R_SUM);
   const int mean = reduce == PSA_MEAN;
+
+  // Edge-balanced path (spmm_eb.hip): ranges of consecutive edges instead of rows.
+  // Variants 30-33 force it (31-33 with ranges of 128 / 512 / 1024 edges).
+  const bool eb_forced = (g_variant >= 30 && g_variant <= 36) || (algo == PSA_SPMM_EDGE_RANGES && g_variant == 0);
+  if (eb_forced && workspace != nullptr && N < (1ll << 31) && nnz > 0 && K % 4 == 0 && psa::aligned(mat, 16) &&
+      psa::aligned(out, 16) && psa::eb_supported(M, K, nnz)) {
+    *bytes_done = arg_bytes != nullptr && minmax;
+    const bool nt_gather = N * K * 4 >= kNtGatherBytes;
+    const int range_len = g_variant == 31 ? 128 : g_variant == 32 ? 512 : g_variant == 33 ? 1024 : 0;
+    return psa::launch_spmm_eb(red, mean, rowptr, row, col, value, mat, out, arg_out,
+                               minmax ? arg_bytes : nullptr, M, N, K, nnz, workspace, workspace_bytes,
+                               nt_gather, range_len, g_variant == 34 ? 1 : g_variant == 35 ? 2 : g_variant == 36 ? 4 : 0, s);
+  }
 
   // Long-row path: on when the caller brings a workspace (NULL keeps every row
   // on its own wave: same results, slow on power-law graphs).
@@ -1450,6 +1394,15 @@ int psa_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
              int64_t K, int64_t nnz, float* out, int64_t* arg_out,
              uint8_t* arg_bytes, void* workspace, size_t workspace_bytes,
              psa_stream_t stream) {
+  return psa_spmm_coo(reduce, rowptr, nullptr, col, value, mat, M, N, K, nnz, out, arg_out, arg_bytes,
+                      PSA_SPMM_AUTO, workspace, workspace_bytes, stream);
+}
+
+int psa_spmm_coo(int reduce, const int64_t* rowptr, const int64_t* row, const int64_t* col,
+                 const float* value, const float* mat, int64_t M, int64_t N,
+                 int64_t K, int64_t nnz, float* out, int64_t* arg_out,
+                 uint8_t* arg_bytes, int algo, void* workspace, size_t workspace_bytes,
+                 psa_stream_t stream) {
   const bool minmax = reduce == PSA_MIN || reduce == PSA_MAX;
   if (arg_bytes != nullptr && minmax && K % 4 != 0) {
     psa::set_error("psa_spmm: arg_bytes needs K % 4 == 0");
@@ -1457,8 +1410,8 @@ int psa_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
   }
   hipStream_t s = psa::as_stream(stream);
   bool bytes_done = false;
-  const int st = spmm_dispatch(reduce, rowptr, col, value, mat, M, N, K, nnz, out, arg_out, workspace,
-                               workspace_bytes, s, arg_bytes, &bytes_done);
+  const int st = spmm_dispatch(reduce, rowptr, row, col, value, mat, M, N, K, nnz, out, arg_out, workspace,
+                               workspace_bytes, s, arg_bytes, &bytes_done, algo);
   if (st != PSA_OK || arg_bytes == nullptr || !minmax || bytes_done || M == 0 || K == 0) return st;
   // the kernel that ran keeps arg_out only: one more pass turns it into bytes
   PSA_REQUIRE(arg_out != nullptr, "arg_bytes without arg_out needs a K tile whose kernel writes the bytes itself (K % 4 == 0, K <= 256)");

@@ -1,0 +1,26 @@
+// Edge-balanced SpMM forward (spmm_eb.hip): host entry used by psa_spmm's dispatch.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace psa {
+
+// Shapes the edge-balanced kernels serve: K % 4 == 0 (16-byte rows), sizes
+// whose edge and row ids fit 31 bits.
+bool eb_supported(int64_t M, int64_t K, int64_t nnz);
+
+// Scratch: [row ids built from rowptr when the caller has none] + two partial
+// slots per edge range (+ their winners for min/max with arg tracking).
+size_t eb_workspace_bytes(bool minmax, int64_t K, int64_t nnz);
+
+// red: 0 sum, 1 min, 2 max (the R_* ids of spmm.hip).  row may be NULL: it is
+// then derived from rowptr into the workspace (one ptr2ind launch).
+int launch_spmm_eb(int red, int mean, const int64_t* rowptr, const int64_t* row,
+                   const int64_t* col, const float* val, const float* mat, float* out,
+                   int64_t* arg_out, uint8_t* arg_bytes, int64_t M, int64_t N, int64_t K,
+                   int64_t nnz, void* workspace, size_t workspace_bytes, bool nt_gather,
+                   int range_len_override, int dbg, hipStream_t s);
+
+}  // namespace psa

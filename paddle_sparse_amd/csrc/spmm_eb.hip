@@ -1,0 +1,646 @@
+// Edge-balanced CSR x dense SpMM forward (sum / mean / min / max), fp32, gfx950.
+//
+// Not present in the reference (README.md:47-50); semantics are upstream
+// pytorch_sparse spmm (README.md:267-306), restated in oracle/spmm_oracle.c.
+//
+// Why a second forward beside the one-wave-per-row kernels of spmm.hip: on a
+// power-law graph most rows hold 0-3 edges, so a row's wave walks the chain
+// rowptr -> col/value -> gather -> store with one or two gathers in flight and
+// the chip sits at ~4.5 TB/s (R-MAT scale 21) against 6.3 TB/s on a uniform
+// graph.  Here the unit of work is a RANGE of `range_len` consecutive edges,
+// whatever rows they belong to:
+//   * a lane group (LPR lanes x float4 = one K tile) owns one range, a wave owns
+//     64 / LPR ranges; the range's col / value / row ids are read coalesced, one
+//     edge per lane, and handed to the gather loop by cross-lane moves — no
+//     dependent pointer chase, U gather instructions always in flight;
+//   * the group walks its edges in order and keeps the running reduction of the
+//     current row in registers; when the row id changes it stores the finished
+//     row (it is the only writer: no atomics, sums in exact edge order);
+//   * a row that crosses a range boundary leaves a partial in one of the range's
+//     two slots (head: the row came in from the left; tail: it goes on to the
+//     right), and a second launch folds each such row's partials in range
+//     order — deterministic, min/max keep the first winner;
+//   * rows without edges never show up in a range: the first `fill_blocks`
+//     workgroups of the same launch read rowptr (64 rows per wave instruction)
+//     and store their zeros (and the arg_out sentinel).
+#include <type_traits>
+
+#include "common.h"
+#include "long_rows.h"
+#include "spmm_eb.h"
+#include "vec_io.h"
+
+extern "C" int psa_ptr2ind(const int64_t* ptr, int64_t M, int64_t E, int64_t* out,
+                           psa_stream_t stream);
+
+namespace {
+
+using psa::load_vec;
+using psa::load_vec_nt;
+using psa::store_vec;
+using psa::store_vec_nt;
+using psa::store_arg_nt;
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+constexpr int kFillRows = 1024;  // rows per workgroup of the fill role
+constexpr int kByteExact = 128;  // rows up to this many edges: the one-byte form of arg_out is exact
+
+enum { R_SUM = 0, R_MIN = 1, R_MAX = 2 };
+
+struct EbArgs {
+  const int64_t* rowptr;
+  const int64_t* row;
+  const int64_t* col;
+  const float* val;
+  const float* mat;
+  float* out;
+  int64_t* arg_out;
+  uint8_t* arg_bytes;
+  float* part_val;    // [2 * ranges, K]: slot 2r = head partial of range r, 2r + 1 = tail partial
+  int64_t* part_arg;  // same shape, winners' edge ids (min/max with tracking)
+  int64_t M, K, nnz, num_ranges;
+  int range_len;      // edges per range, a multiple of LPR
+  unsigned fill_blocks;
+  int mean;
+  int nt_gather;
+  int minmax;
+  int dbg;  // A/B hooks: 1 = drop the row stores (timing only), 2 = ordinary instead of non-temporal stores
+};
+
+// Rows without edges: out = 0, arg_out = nnz.  One wave tests 64 rows per step
+// and zeroes the empty ones, 64 / P rows per store instruction (P lanes x 16 B
+// cover a row of K floats, or a 1 KiB slice of a wider one).
+__device__ __forceinline__ void eb_fill_role(const EbArgs& a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t K4 = a.K >> 2;
+  int P = 1;
+  while (P < K4 && P < 64) P <<= 1;
+  const int rps = 64 / P;
+  const int sub = lane / P, q0 = lane % P;
+  const int64_t base = static_cast<int64_t>(blockIdx.x) * kFillRows + wave * (kFillRows / kWaves);
+  const float zero[4] = {0.f, 0.f, 0.f, 0.f};
+  const int64_t sentinel[4] = {a.nnz, a.nnz, a.nnz, a.nnz};
+  for (int it = 0; it < kFillRows / kWaves / 64; ++it) {
+    const int64_t r0 = base + it * 64;
+    if (r0 >= a.M) break;
+    const int64_t r = r0 + lane;
+    bool empty = false;
+    if (r < a.M) empty = a.rowptr[r + 1] == a.rowptr[r];
+    unsigned long long mask = __ballot(empty);
+    while (mask) {
+      int mine = -1;
+      for (int t = 0; t < rps && mask; ++t) {
+        const int i = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        if (sub == t) mine = i;
+      }
+      if (mine >= 0) {
+        const int64_t rr = r0 + mine;
+        for (int64_t q = q0; q < K4; q += P) {
+          store_vec_nt<4>(a.out + rr * a.K + 4 * q, zero);
+          if (a.minmax) {
+            if (a.arg_out) store_arg_nt<4>(a.arg_out + rr * a.K + 4 * q, sentinel);
+            if (a.arg_bytes) __builtin_nontemporal_store(0u, reinterpret_cast<uint32_t*>(a.arg_bytes + rr * a.K + 4 * q));
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int RED>
+__device__ __forceinline__ float red_init() {
+  return RED == R_SUM ? 0.f : (RED == R_MAX ? -__FLT_MAX__ : __FLT_MAX__);
+}
+
+// One finished row of a range: out (and arg_out / arg_bytes) straight from the
+// registers of the lane group that reduced it.
+template <int RED, bool TRACK>
+__device__ __forceinline__ void eb_store_row(const EbArgs& a, int64_t row, int64_t k0, int64_t start,
+                                             int seg_first, int cnt, float (&acc)[4], const int (&arg)[4]) {
+  if (RED == R_SUM) {
+    if (a.mean && cnt > 1) {
+      const float d = static_cast<float>(cnt);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] = acc[i] / d;
+    }
+  } else if (TRACK) {
+    if (a.arg_out) {
+      int64_t g[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) g[i] = start + arg[i];
+      store_arg_nt<4>(a.arg_out + row * a.K + k0, g);
+    }
+    if (a.arg_bytes) {
+      uint32_t packed = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t b = static_cast<uint32_t>((arg[i] - seg_first) & 127) | (cnt > kByteExact ? 0x80u : 0u);
+        packed |= b << (8 * i);
+      }
+      __builtin_nontemporal_store(packed, reinterpret_cast<uint32_t*>(a.arg_bytes + row * a.K + k0));
+    }
+  }
+  if (a.dbg & 1) {
+    if (acc[0] != 12345.678f) return;
+  }
+  if (a.dbg & 4) {  // same store instructions, all into a cache-resident scratch (timing only)
+    store_vec_nt<4>(a.part_val + (row & 4095) * a.K + k0, acc);
+    return;
+  }
+  if (a.dbg & 2) store_vec<4>(a.out + row * a.K + k0, acc);
+  else store_vec_nt<4>(a.out + row * a.K + k0, acc);
+}
+
+template <int RED, bool TRACK>
+__device__ __forceinline__ void eb_store_partial(const EbArgs& a, int64_t slot, int64_t k0, int64_t start,
+                                                 const float (&acc)[4], const int (&arg)[4]) {
+  store_vec<4>(a.part_val + slot * a.K + k0, acc);
+  if (RED != R_SUM && TRACK) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a.part_arg[slot * a.K + k0 + i] = start + arg[i];
+  }
+}
+
+// static_for<N>(f): f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>) —
+// the ring buffers below must be indexed by constants to stay in registers.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_impl(F& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for_impl<I + 1, N>(f);
+  }
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl<0, N>(f);
+}
+
+// Range role.  The gathers run through a ring of D register buffers of U edges:
+// round t + D - 1 is requested, then round t is consumed, so (D - 1) * U gather
+// instructions stay in flight per wave at all times.
+//
+// The loads of the walk (gathers and the staged col / row / value words) are
+// issued from inline asm and waited for with hand-counted s_waitcnt vmcnt(N).
+// gfx950 retires stores through the same in-order counter as loads, and a flush
+// stores a finished row in the middle of the walk: the compiler's own
+// bookkeeping answers the divergent flush with vmcnt(0) before every round (first
+// form of this kernel: 1.95 ms on config 3 against 1.65 ms for one wave per row),
+// which waits for the stores' round trip to HBM as well.  Counted, the wait for
+// round t is vmcnt((D - 1) * U): the rounds t + 1 ... t + D - 1 requested after it
+// may stay in flight, and the flush stores of round t - 1, younger than all but
+// the last of them, fall inside that window — no wait ever covers a store.
+// Every asm load is unconditional (lanes and rounds past the end of the range
+// read a clamped, valid address and are ignored on consumption), so the count
+// holds on every path.  A destination register is named by the wait statement
+// that precedes its first use ("+v"), which keeps the compiler from reading it
+// early (cdna_hip_programming.md 5.7, form ii).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool NT>
+__device__ __forceinline__ void asm_gather16(f32x4& dst, const float* p) {
+  if constexpr (NT) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
+  else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void asm_load_word(int& dst, const void* p) {
+  asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+template <int N, int U>
+__device__ __forceinline__ void asm_wait_round(f32x4 (&b)[U]) {
+  static_assert(U == 1 || U == 2 || U == 4, "rounds of 1, 2 or 4 edges");
+  if constexpr (U == 1) asm volatile("s_waitcnt vmcnt(%c1)" : "+v"(b[0]) : "i"(N) : "memory");
+  else if constexpr (U == 2) asm volatile("s_waitcnt vmcnt(%c2)" : "+v"(b[0]), "+v"(b[1]) : "i"(N) : "memory");
+  else asm volatile("s_waitcnt vmcnt(%c4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "i"(N) : "memory");
+}
+
+template <int LPR, int RED, int U, int D, bool TRACK, bool NT>
+__global__ void __launch_bounds__(kThreads) spmm_eb_kernel(EbArgs a) {
+  if (blockIdx.x < a.fill_blocks) {  // ---- fill role ----
+    if (blockIdx.y == 0) eb_fill_role(a);
+    return;
+  }
+  // ---- range role ----
+  constexpr int G = 64 / LPR;
+  constexpr int RPS = LPR / U;  // rounds per staged batch of LPR edges
+  static_assert(LPR % U == 0 && RPS % D == 0 && D >= 2, "ring positions must repeat every staged batch");
+  static_assert((D - 1) * U < 64, "vmcnt is a 6-bit field");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int g = lane / LPR;
+  const int l = lane % LPR;
+  const int gsel = (lane - l) << 2;  // ds_bpermute byte address of the group's lane 0
+  const int64_t k0 = (static_cast<int64_t>(blockIdx.y) * LPR + l) * 4;
+  const bool kact = k0 < a.K;
+  const float* matk = a.mat + (kact ? k0 : 0);  // idle K lanes gather (and drop) column 0
+  const int64_t rg = ((static_cast<int64_t>(blockIdx.x) - a.fill_blocks) * kWaves + wave) * G + g;
+  const int64_t start = rg * a.range_len;
+  const bool active = start < a.nnz;
+  const int64_t end = !active ? start : (start + a.range_len < a.nnz ? start + a.range_len : a.nnz);
+  const int len = static_cast<int>(end - start);
+  const int64_t last = a.nnz - 1;
+
+  // rows of the neighbouring edges decide where a boundary row's partial goes
+  int prev_row = -1, next_row = -1;
+  if (active) {
+    if (start > 0) prev_row = static_cast<int>(a.row[start - 1]);
+    if (end < a.nnz) next_row = static_cast<int>(a.row[end]);
+  }
+  // the compiler's wait for these two (ordinary) loads lands here, ahead of the
+  // hand-counted part; inside the walk its vmcnt(0) would drain the ring
+  asm volatile("" : "+v"(prev_row), "+v"(next_row));
+
+  float acc[4];
+  int arg[4];
+  int cur_row = -1;        // row being reduced (-1: none yet)
+  int seg_first = 0;       // range-local index of its first edge in this range
+  bool head_open = false;  // cur_row came in from the previous range
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    acc[i] = red_init<RED>();
+    arg[i] = 0;
+  }
+
+  // staged edges: one per lane of the group (col and row ids fit 31 bits:
+  // eb_supported; the low words of the int64 entries are read)
+  struct Staged {
+    int c, r, v;
+  };
+  const bool has_val = a.val != nullptr;
+  const void* vsrc = has_val ? static_cast<const void*>(a.val) : static_cast<const void*>(a.col);  // no values: any readable word
+  auto stage = [&](Staged& s, int64_t sb) {  // 3 loads
+    int64_t e = sb + l;
+    e = e < last ? e : last;
+    asm_load_word(s.c, a.col + e);
+    asm_load_word(s.r, a.row + e);
+    asm_load_word(s.v, static_cast<const char*>(vsrc) + 4 * e);
+  };
+
+  f32x4 b[D][U];
+  float w[D][U];
+  int rr[D][U];
+  auto issue = [&](auto buf, const Staged& s, int idx0) {  // U loads
+    constexpr int B = decltype(buf)::value;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int sel = gsel + ((idx0 + u) << 2);
+      const int64_t c = __builtin_amdgcn_ds_bpermute(sel, s.c);
+      const float wv = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sel, s.v));
+      w[B][u] = has_val ? wv : 1.f;
+      rr[B][u] = __builtin_amdgcn_ds_bpermute(sel, s.r);
+      asm_gather16<NT>(b[B][u], matk + c * a.K);
+    }
+  };
+  auto consume = [&](auto buf, int local0) {
+    constexpr int B = decltype(buf)::value;
+    asm_wait_round<(D - 1) * U, U>(b[B]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int local = local0 + u;
+      if (local < len) {  // uniform inside the lane group
+        if (rr[B][u] != cur_row) {
+          if (cur_row >= 0 && kact) {
+            if (head_open) eb_store_partial<RED, TRACK>(a, 2 * rg, k0, start, acc, arg);
+            else eb_store_row<RED, TRACK>(a, cur_row, k0, start, seg_first, local - seg_first, acc, arg);
+          }
+          head_open = cur_row < 0 && rr[B][u] == prev_row;
+          cur_row = rr[B][u];
+          seg_first = local;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] = red_init<RED>();
+        }
+        if (RED == R_SUM) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] += w[B][u] * b[B][u][i];
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float x = w[B][u] * b[B][u][i];
+            const bool better = RED == R_MAX ? (x > acc[i]) : (x < acc[i]);
+            if (better) {
+              acc[i] = x;
+              if (TRACK) arg[i] = local;
+            }
+          }
+        }
+      }
+    }
+  };
+
+  Staged cur, nxt, pre;
+  stage(cur, start);
+  stage(nxt, start + LPR);
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur.c), "+v"(cur.r), "+v"(cur.v), "+v"(nxt.c), "+v"(nxt.r), "+v"(nxt.v) : : "memory");
+  static_for<D - 1>([&](auto q) { issue(q, cur, decltype(q)::value * U); });
+  for (int64_t sb = start; sb < end; sb += LPR) {
+    stage(pre, sb + 2 * LPR);
+    const int local0 = static_cast<int>(sb - start);
+#pragma unroll 1
+    for (int q0 = 0; q0 < RPS; q0 += D) {  // D rounds per trip: ring positions are constants
+      static_for<D>([&](auto d) {
+        constexpr int DD = decltype(d)::value;
+        const int qi = q0 + DD + D - 1;  // round requested while round q0 + DD is consumed
+        const bool from_next = qi >= RPS;  // it belongs to the next staged batch
+        Staged src;
+        src.c = from_next ? nxt.c : cur.c;
+        src.r = from_next ? nxt.r : cur.r;
+        src.v = from_next ? nxt.v : cur.v;
+        issue(std::integral_constant<int, (DD + D - 1) % D>{}, src, (from_next ? qi - RPS : qi) * U);
+        consume(d, local0 + (q0 + DD) * U);
+      });
+    }
+    // `pre` was requested before every gather of this batch, the last counted wait
+    // covered it; naming it here keeps the copies below behind that wait
+    asm volatile("" : "+v"(pre.c), "+v"(pre.r), "+v"(pre.v));
+    cur = nxt;
+    nxt = pre;
+  }
+  // the D - 1 rounds requested past the end: their registers must not be reused in flight
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (cur_row >= 0 && kact) {
+    if (head_open) eb_store_partial<RED, TRACK>(a, 2 * rg, k0, start, acc, arg);
+    else if (cur_row == next_row) eb_store_partial<RED, TRACK>(a, 2 * rg + 1, k0, start, acc, arg);
+    else eb_store_row<RED, TRACK>(a, cur_row, k0, start, seg_first, len - seg_first, acc, arg);
+  }
+}
+
+// Rows that cross range boundaries: the wave of the range where such a row
+// STARTS folds its partials in range order — the starting range's tail slot,
+// then the head slot of every following range the row reaches.
+template <int RED, bool TRACK>
+__global__ void __launch_bounds__(kThreads) spmm_eb_combine_kernel(EbArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x * kWaves + (threadIdx.x >> 6)));
+  const int64_t num_waves = static_cast<int64_t>(gridDim.x) * kWaves;
+  const int64_t T = a.range_len;
+  for (int64_t rg = wave0; rg < a.num_ranges; rg += num_waves) {
+    const int64_t start = rg * T;
+    const int64_t end = start + T < a.nnz ? start + T : a.nnz;
+    if (end >= a.nnz) continue;  // nothing to the right
+    const int64_t r_last = a.row[end - 1];
+    if (a.row[end] != r_last) continue;  // the boundary is closed
+    if (a.row[start] == r_last && start > 0 && a.row[start - 1] == r_last) continue;  // a middle piece: its starter folds it
+    // pieces to add: head slots of ranges rg + 1 ... rg + pieces
+    int64_t pieces = 0;
+    for (;;) {
+      const int64_t m = rg + 1 + pieces + lane;
+      const int64_t e_m = (m + 1) * T;
+      const bool cont = e_m < a.nnz && a.row[e_m - 1] == r_last && a.row[e_m] == r_last;
+      const unsigned long long mask = __ballot(cont);
+      const int t = ~mask == 0ull ? 64 : __builtin_ctzll(~mask);
+      pieces += t;
+      if (t < 64) break;
+    }
+    pieces += 1;  // the range in which the row ends
+    const int64_t rs = a.rowptr[r_last];
+    const int64_t deg = a.rowptr[r_last + 1] - rs;
+    for (int64_t kb = lane; kb < a.K; kb += 128) {
+      const bool two = kb + 64 < a.K;
+      const int64_t p_tail = (2 * rg + 1) * a.K + kb;
+      float acc[2];
+      int64_t arg[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const bool on = t == 0 || two;
+        acc[t] = on ? a.part_val[p_tail + 64 * t] : 0.f;
+        arg[t] = (RED == R_SUM || !TRACK || !on) ? 0 : a.part_arg[p_tail + 64 * t];
+      }
+      const int64_t p_head = 2 * (rg + 1) * a.K + kb;  // + 2 K per further range
+      for (int64_t c = 0; c < pieces; c += 8) {
+        float x[2][8];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+            x[t][i] = (c + i < pieces && (t == 0 || two)) ? a.part_val[p_head + 64 * t + (c + i) * 2 * a.K] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            if (c + i >= pieces || (t == 1 && !two)) break;
+            if (RED == R_SUM) {
+              acc[t] += x[t][i];
+            } else if (RED == R_MAX ? (x[t][i] > acc[t]) : (x[t][i] < acc[t])) {
+              acc[t] = x[t][i];
+              if (TRACK) arg[t] = a.part_arg[p_head + 64 * t + (c + i) * 2 * a.K];
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (t == 1 && !two) break;
+        const int64_t k = kb + 64 * t;
+        if (RED == R_SUM) {
+          if (a.mean) acc[t] = acc[t] / static_cast<float>(deg);
+        } else if (TRACK) {
+          if (a.arg_out) __builtin_nontemporal_store(arg[t], a.arg_out + r_last * a.K + k);
+          if (a.arg_bytes)
+            a.arg_bytes[r_last * a.K + k] = static_cast<uint8_t>(((arg[t] - rs) & 127) | (deg > kByteExact ? 0x80 : 0));
+        }
+        __builtin_nontemporal_store(acc[t], a.out + r_last * a.K + k);
+      }
+    }
+  }
+}
+
+// {empty rows, rows of 1-2 entries, rows above 128 entries, longest row}: one
+// 64-bit atomic per counter and workgroup.
+__global__ void __launch_bounds__(kThreads)
+csr_row_stats_kernel(const int64_t* __restrict__ rowptr, int64_t M, unsigned long long* __restrict__ stats) {
+  __shared__ unsigned long long sh[kWaves][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned long long empty = 0, tiny = 0, big = 0, longest = 0;
+  for (int64_t r = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x; r < M;
+       r += static_cast<int64_t>(gridDim.x) * kThreads) {
+    const unsigned long long deg = static_cast<unsigned long long>(rowptr[r + 1] - rowptr[r]);
+    empty += deg == 0;
+    tiny += deg >= 1 && deg <= 2;
+    big += deg > 128;
+    longest = deg > longest ? deg : longest;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    empty += __shfl_xor(empty, off);
+    tiny += __shfl_xor(tiny, off);
+    big += __shfl_xor(big, off);
+    const unsigned long long o = __shfl_xor(longest, off);
+    longest = o > longest ? o : longest;
+  }
+  if (lane == 0) {
+    sh[wave][0] = empty;
+    sh[wave][1] = tiny;
+    sh[wave][2] = big;
+    sh[wave][3] = longest;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    unsigned long long v = sh[0][threadIdx.x];
+    for (int w = 1; w < kWaves; ++w) v = threadIdx.x == 3 ? (sh[w][3] > v ? sh[w][3] : v) : v + sh[w][threadIdx.x];
+    if (threadIdx.x == 3) atomicMax(stats + 3, v);
+    else if (v) atomicAdd(stats + threadIdx.x, v);
+  }
+}
+
+struct EbPlan {
+  int lpr;
+  int range_len;
+  int k_tiles;
+};
+
+EbPlan eb_plan(int64_t K, int range_len_override) {
+  const int64_t q = K / 4;
+  EbPlan p;
+  p.k_tiles = 1;
+  if (q <= 4) p.lpr = 4;
+  else if (q <= 8) p.lpr = 8;
+  else if (q <= 16) p.lpr = 16;
+  else if (q <= 32) p.lpr = 32;
+  else if (K < 192) p.lpr = 64;
+  else {  // ceil(K / 128) tiles of the K = 128 form over grid.y, as the row kernels do
+    p.lpr = 32;
+    p.k_tiles = static_cast<int>(psa::ceil_div(K, 128));
+  }
+  // a wave (64 / LPR ranges) takes 512 edges, a range at least 32
+  p.range_len = p.lpr >= 32 ? 256 : (p.lpr == 16 ? 128 : (p.lpr == 8 ? 64 : 32));
+  if (range_len_override > 0) p.range_len = static_cast<int>(psa::ceil_div(range_len_override, p.lpr)) * p.lpr;
+  return p;
+}
+
+// The scratch holds two partial slots per range of the planned length (an
+// override for A/B runs may go down to 128 edges, not below the plan).
+int scratch_range_len(int64_t K) {
+  const int d = eb_plan(K, 0).range_len;
+  return d < 128 ? d : 128;
+}
+
+}  // namespace
+
+namespace psa {
+
+bool eb_supported(int64_t M, int64_t K, int64_t nnz) {
+  return K > 0 && K % 4 == 0 && M > 0 && M < (1ll << 31) && nnz < (1ll << 31);  // and N < 2^31: the caller checks
+}
+
+size_t eb_workspace_bytes(bool minmax, int64_t K, int64_t nnz) {
+  if (K <= 0 || nnz <= 0) return 256;
+  const size_t ranges = static_cast<size_t>(ceil_div(nnz, scratch_range_len(K)));
+  return align256(static_cast<size_t>(nnz) * sizeof(int64_t)) + align256(2 * ranges * K * sizeof(float)) +
+         (minmax ? align256(2 * ranges * K * sizeof(int64_t)) : 0);
+}
+
+int launch_spmm_eb(int red, int mean, const int64_t* rowptr, const int64_t* row,
+                   const int64_t* col, const float* val, const float* mat, float* out,
+                   int64_t* arg_out, uint8_t* arg_bytes, int64_t M, int64_t N, int64_t K,
+                   int64_t nnz, void* workspace, size_t workspace_bytes, bool nt_gather,
+                   int range_len_override, int dbg, hipStream_t s) {
+  (void)N;
+  PSA_REQUIRE(eb_supported(M, K, nnz), "shape not served by the edge-balanced kernels");
+  const bool minmax = red != R_SUM;
+  if (workspace == nullptr || workspace_bytes < eb_workspace_bytes(minmax, K, nnz)) {
+    set_error("psa_spmm: workspace too small");
+    return PSA_ERR_WORKSPACE;
+  }
+  PSA_REQUIRE(aligned(workspace, 16), "workspace must be 16-byte aligned");
+  const EbPlan plan = eb_plan(K, range_len_override);
+  PSA_REQUIRE(plan.range_len >= scratch_range_len(K), "range too short for the scratch layout");
+  char* p = static_cast<char*>(workspace);
+  if (row == nullptr && nnz > 0) {
+    int64_t* built = reinterpret_cast<int64_t*>(p);
+    const int st = psa_ptr2ind(rowptr, M, nnz, built, reinterpret_cast<psa_stream_t>(s));
+    if (st != PSA_OK) return st;
+    row = built;
+  }
+  p += align256(static_cast<size_t>(nnz > 0 ? nnz : 0) * sizeof(int64_t));
+  EbArgs a;
+  a.rowptr = rowptr;
+  a.row = row;
+  a.col = col;
+  a.val = val;
+  a.mat = mat;
+  a.out = out;
+  a.arg_out = minmax ? arg_out : nullptr;
+  a.arg_bytes = minmax ? arg_bytes : nullptr;
+  a.M = M;
+  a.K = K;
+  a.nnz = nnz;
+  a.range_len = plan.range_len;
+  a.num_ranges = ceil_div(nnz, plan.range_len);
+  const size_t slots = 2 * static_cast<size_t>(ceil_div(nnz > 0 ? nnz : 1, scratch_range_len(K)));
+  a.part_val = reinterpret_cast<float*>(p);
+  p += align256(slots * K * sizeof(float));
+  a.part_arg = minmax ? reinterpret_cast<int64_t*>(p) : nullptr;
+  a.fill_blocks = static_cast<unsigned>(ceil_div(M, kFillRows));
+  a.mean = mean;
+  a.nt_gather = nt_gather ? 1 : 0;
+  a.minmax = minmax ? 1 : 0;
+  a.dbg = dbg;
+  const int G = 64 / plan.lpr;
+  const int64_t range_blocks = ceil_div(a.num_ranges, static_cast<int64_t>(G) * kWaves);
+  const int64_t gx = static_cast<int64_t>(a.fill_blocks) + range_blocks;
+  PSA_REQUIRE(gx <= 0x7fffffff, "problem too large for one launch");
+  const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(plan.k_tiles)), block(kThreads);
+  const bool track = minmax && (arg_out != nullptr || arg_bytes != nullptr);
+  int64_t cblocks = ceil_div(a.num_ranges, kWaves);
+  if (cblocks > 4096) cblocks = 4096;
+  const dim3 cgrid(static_cast<unsigned>(cblocks > 0 ? cblocks : 1));
+
+#define PSA_EB_NT(LPR, U, D, NT)                                                                           \
+  do {                                                                                            \
+    if (red == R_SUM) {                                                                           \
+      hipLaunchKernelGGL((spmm_eb_kernel<LPR, R_SUM, U, D, false, NT>), grid, block, 0, s, a);           \
+      if (a.num_ranges > 1) hipLaunchKernelGGL((spmm_eb_combine_kernel<R_SUM, false>), cgrid, block, 0, s, a); \
+    } else if (red == R_MIN) {                                                                    \
+      if (track) {                                                                                \
+        hipLaunchKernelGGL((spmm_eb_kernel<LPR, R_MIN, U, D, true, NT>), grid, block, 0, s, a);          \
+        if (a.num_ranges > 1) hipLaunchKernelGGL((spmm_eb_combine_kernel<R_MIN, true>), cgrid, block, 0, s, a); \
+      } else {                                                                                    \
+        hipLaunchKernelGGL((spmm_eb_kernel<LPR, R_MIN, U, D, false, NT>), grid, block, 0, s, a);         \
+        if (a.num_ranges > 1) hipLaunchKernelGGL((spmm_eb_combine_kernel<R_MIN, false>), cgrid, block, 0, s, a); \
+      }                                                                                           \
+    } else {                                                                                      \
+      if (track) {                                                                                \
+        hipLaunchKernelGGL((spmm_eb_kernel<LPR, R_MAX, U, D, true, NT>), grid, block, 0, s, a);          \
+        if (a.num_ranges > 1) hipLaunchKernelGGL((spmm_eb_combine_kernel<R_MAX, true>), cgrid, block, 0, s, a); \
+      } else {                                                                                    \
+        hipLaunchKernelGGL((spmm_eb_kernel<LPR, R_MAX, U, D, false, NT>), grid, block, 0, s, a);         \
+        if (a.num_ranges > 1) hipLaunchKernelGGL((spmm_eb_combine_kernel<R_MAX, false>), cgrid, block, 0, s, a); \
+      }                                                                                           \
+    }                                                                                             \
+  } while (0)
+
+#define PSA_EB(LPR, U, D)                  \
+  do {                                     \
+    if (nt_gather) PSA_EB_NT(LPR, U, D, true); \
+    else PSA_EB_NT(LPR, U, D, false);      \
+  } while (0)
+  switch (plan.lpr) {
+    case 4: PSA_EB_NT(4, 2, 2, false); break;
+    case 8: PSA_EB_NT(8, 2, 4, false); break;
+    case 16: PSA_EB_NT(16, 2, 4, false); break;
+    case 32: PSA_EB(32, 2, 4); break;
+    default: PSA_EB(64, 2, 4); break;
+  }
+#undef PSA_EB
+#undef PSA_EB_NT
+  PSA_LAUNCH_CHECK();
+  return PSA_OK;
+}
+
+}  // namespace psa
+
+extern "C" int psa_csr_row_stats(const int64_t* rowptr, int64_t M, int64_t* stats, psa_stream_t stream) {
+  PSA_REQUIRE(M >= 0, "negative size");
+  PSA_REQUIRE(stats != nullptr && (M == 0 || rowptr != nullptr), "NULL pointer");
+  hipStream_t s = psa::as_stream(stream);
+  PSA_ZERO(stats, 4 * sizeof(int64_t), s);
+  if (M == 0) return PSA_OK;
+  int64_t blocks = psa::ceil_div(M, kThreads);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(csr_row_stats_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, s, rowptr, M,
+                     reinterpret_cast<unsigned long long*>(stats));
+  PSA_LAUNCH_CHECK();
+  return PSA_OK;
+}

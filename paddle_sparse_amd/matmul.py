@@ -45,6 +45,8 @@ class _SpMM(torch.autograd.Function):
     def forward(ctx, value: Optional[torch.Tensor], mat: torch.Tensor,
                 storage: SparseStorage, reduce: str, track: bool = True):
         rowptr, col = storage.rowptr(), storage.col()
+        algo = storage._spmm_algo()  # per-matrix choice, read once
+        row = storage.row() if algo == "edge_ranges" else None  # the COO row ids the edge-balanced kernels walk
         arg = arg_bytes = None
         if reduce in ("min", "max"):
             # What the backward will read decides what the forward stores.  The
@@ -58,10 +60,11 @@ class _SpMM(torch.autograd.Function):
             csc_bw = need_mat and ops.minmax_bw_csc_supported(mat.shape[1])
             bytes_only = csc_bw and storage._longest_row() <= ops.ARG_BYTES_EXACT_ROW
             want_arg = (need_value or need_mat) and not bytes_only
-            res = ops._spmm(reduce, rowptr, col, value, mat, want_arg_bytes=csc_bw, want_arg=want_arg)
+            res = ops._spmm(reduce, rowptr, col, value, mat, want_arg_bytes=csc_bw, want_arg=want_arg,
+                            row=row, algo=algo)
             out, arg, arg_bytes = res if csc_bw else (*res, None)
         else:
-            out = ops._spmm(reduce, rowptr, col, value, mat)[0]
+            out = ops._spmm(reduce, rowptr, col, value, mat, row=row, algo=algo)[0]
         ctx.storage, ctx.reduce = storage, reduce
         ctx.save_for_backward(value, mat, arg, arg_bytes)
         return out

@@ -74,15 +74,23 @@ def ptr2ind(ptr: torch.Tensor, E: int) -> torch.Tensor:
 
 def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
           value: Optional[torch.Tensor], mat: torch.Tensor, want_arg_bytes: bool = False,
-          want_arg: bool = True):
+          want_arg: bool = True, row: Optional[torch.Tensor] = None, algo: str = "auto"):
     """(out, arg_out | None) — and, with want_arg_bytes (min/max, K % 4 == 0), a
     third result: arg_out as row-local byte indices for spmm_minmax_bw_csc.
     want_arg=False (min/max) skips the int64 arg_out altogether: the kernel then
     stores `out` (and the bytes, if asked for) only — two thirds of the output
     traffic gone; for callers that need no backward, or whose backward is served
-    by the bytes alone (no row longer than ARG_BYTES_EXACT_ROW entries)."""
+    by the bytes alone (no row longer than ARG_BYTES_EXACT_ROW entries).
+    `row` (the COO row ids, SparseStorage.row()) is optional: the edge-balanced
+    kernels read it and derive it from rowptr when it is not given.  `algo`:
+    "auto" | "row_waves" | "edge_ranges" (psa_spmm_algo; csr_row_stats / 
+    SparseStorage._spmm_algo() choose per matrix)."""
     rowptr = _index(rowptr, "rowptr")
     col = _index(col, "col")
+    if row is not None:
+        row = _index(row, "row")
+        if row.numel() != col.numel():
+            raise ValueError("row must have one entry per edge")
     _gpu(mat, "mat")
     if mat.dtype != torch.float32:
         raise TypeError(f"spmm is fp32 in this build (mat is {mat.dtype})")
@@ -116,9 +124,9 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
     if want_arg_bytes and minmax and K % 4 == 0 and (want_arg or K <= 256):
         arg_bytes = torch.empty((M, K), dtype=torch.uint8, device=mat.device)
     with torch.cuda.device(mat.device):
-        check(lib.psa_spmm(rid, _ptr(rowptr), _ptr(col), _ptr(value), _ptr(mat),
-                           M, N, K, nnz, _ptr(out), _ptr(arg), _ptr(arg_bytes), _ptr(ws), ws_bytes,
-                           _stream()))
+        check(lib.psa_spmm_coo(rid, _ptr(rowptr), _ptr(row), _ptr(col), _ptr(value), _ptr(mat),
+                               M, N, K, nnz, _ptr(out), _ptr(arg), _ptr(arg_bytes),
+                               _lib.SPMM_ALGO_ID[algo], _ptr(ws), ws_bytes, _stream()))
     if want_arg_bytes:
         return out, arg, arg_bytes
     return out, arg
@@ -128,22 +136,33 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
 ARG_BYTES_EXACT_ROW = 128
 
 
-def spmm_sum(rowptr, col, value, mat) -> torch.Tensor:
+def spmm_sum(rowptr, col, value, mat, row=None, algo="auto") -> torch.Tensor:
     """out[i] = sum_e value[e] * mat[col[e]] (value None -> weights 1)."""
-    return _spmm("sum", rowptr, col, value, mat)[0]
+    return _spmm("sum", rowptr, col, value, mat, row=row, algo=algo)[0]
 
 
-def spmm_mean(rowptr, col, value, mat) -> torch.Tensor:
-    return _spmm("mean", rowptr, col, value, mat)[0]
+def spmm_mean(rowptr, col, value, mat, row=None, algo="auto") -> torch.Tensor:
+    return _spmm("mean", rowptr, col, value, mat, row=row, algo=algo)[0]
 
 
-def spmm_min(rowptr, col, value, mat) -> Tuple[torch.Tensor, torch.Tensor]:
+def spmm_min(rowptr, col, value, mat, row=None, algo="auto") -> Tuple[torch.Tensor, torch.Tensor]:
     """Returns (out, arg_out); arg_out == nnz marks an empty row."""
-    return _spmm("min", rowptr, col, value, mat)
+    return _spmm("min", rowptr, col, value, mat, row=row, algo=algo)
 
 
-def spmm_max(rowptr, col, value, mat) -> Tuple[torch.Tensor, torch.Tensor]:
-    return _spmm("max", rowptr, col, value, mat)
+def spmm_max(rowptr, col, value, mat, row=None, algo="auto") -> Tuple[torch.Tensor, torch.Tensor]:
+    return _spmm("max", rowptr, col, value, mat, row=row, algo=algo)
+
+
+def csr_row_stats(rowptr: torch.Tensor) -> Tuple[int, int, int, int]:
+    """(rows without entries, rows with 1-2 entries, rows above 128 entries,
+    longest row) of a CSR pointer.  Synchronises (one 32-byte host read)."""
+    rowptr = _index(rowptr, "rowptr")
+    stats = torch.empty(4, dtype=torch.int64, device=rowptr.device)
+    with torch.cuda.device(rowptr.device):
+        check(_lib.load().psa_csr_row_stats(_ptr(rowptr), rowptr.numel() - 1, _ptr(stats), _stream()))
+    e, t, b, m = stats.tolist()
+    return e, t, b, m
 
 
 def spmm_set_variant(variant: int) -> int:

@@ -119,6 +119,7 @@ class SparseStorage(object):
         self._row_csc: Optional[torch.Tensor] = None  # row[csr2csc], private
         self._edge_tags: Optional[torch.Tensor] = None  # uint8 per CSC edge, private (min/max backward)
         self._max_rowcount: Optional[int] = None  # longest row, private (structure only; one host read)
+        self._spmm_algo_memo: Optional[str] = None  # SpMM forward kernel family for this row structure
 
         # storage.py:158-171 — sort by (row, col) unless told it is sorted
         if not is_sorted and nnz > 0:
@@ -313,6 +314,18 @@ class SparseStorage(object):
             self._max_rowcount = int(self.rowcount().max().item()) if self._sparse_sizes[0] > 0 else 0
         return self._max_rowcount
 
+    def _spmm_algo(self) -> str:
+        """Which SpMM forward suits this row structure (memoised; one 32-byte host
+        read per matrix): "edge_ranges" once rows with at most two entries — the
+        empty ones included — make up more than 40 % of the rows (power-law
+        graphs), else "row_waves".  See psa_csr_row_stats in the header."""
+        if self._spmm_algo_memo is None:
+            M = self._sparse_sizes[0]
+            empty, tiny, _, longest = ops.csr_row_stats(self.rowptr()) if M > 0 else (0, 0, 0, 0)
+            self._max_rowcount = longest
+            self._spmm_algo_memo = "edge_ranges" if 5 * (empty + tiny) > 2 * M else "row_waves"
+        return self._spmm_algo_memo
+
     def _csc_edge_tags(self) -> torch.Tensor:
         """Position of every CSC-ordered edge inside its CSR row, one byte each
         (ops.csc_edge_tags): structure only, memoised for the min/max backward."""
@@ -362,6 +375,7 @@ class SparseStorage(object):
         self._row_csc = None
         self._edge_tags = None
         self._max_rowcount = None
+        self._spmm_algo_memo = None
         return self
 
     def cached_keys(self) -> List[str]:
@@ -380,6 +394,7 @@ class SparseStorage(object):
         if not (set(kw) - {"value"}):  # same sparsity structure: the private CSC helpers carry over
             out._row_csc, out._edge_tags = self._row_csc, self._edge_tags
             out._max_rowcount = self._max_rowcount
+            out._spmm_algo_memo = self._spmm_algo_memo
         return out
 
     def _map(self, fn: Callable[[torch.Tensor], torch.Tensor]):

@@ -5,6 +5,7 @@ C-ABI symbol checks.  `-m gpu` tests are the parity tests proper and call the
 HIP kernels through the C-ABI on a real MI355X.
 """
 import json
+import os
 import sys
 from pathlib import Path
 
@@ -37,4 +38,11 @@ def _built():
     spec.loader.exec_module(hip_build)
     oracle.build()
     hip_build.build()
+    # PSA_SPMM_VARIANT=<n> runs the whole suite with one SpMM kernel variant forced
+    # (e.g. 30 = the edge-balanced forward wherever its shapes allow)
+    variant = os.environ.get("PSA_SPMM_VARIANT")
+    if variant:
+        from paddle_sparse_amd import ops
+
+        ops.spmm_set_variant(int(variant))
     yield

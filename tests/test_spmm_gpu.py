@@ -16,6 +16,34 @@ pytestmark = pytest.mark.gpu
 
 RTOL = 1e-5
 
+# Every test of this file runs on both forward kernel families (psa_spmm_algo):
+# one wave per row, and edge ranges — the latter with the COO row ids handed in
+# (SparseStorage.row()) and with row = NULL (derived from rowptr by the call).
+ALGO = "row_waves"
+
+
+@pytest.fixture(autouse=True, params=["row_waves", "edge_ranges", "edge_ranges_norow"])
+def algo(request):
+    global ALGO
+    ALGO = request.param
+    yield request.param
+    ALGO = "row_waves"
+
+
+def once():
+    """For tests that pin kernel variants themselves or do not go through run_gpu."""
+    if ALGO != "row_waves":
+        pytest.skip("independent of the algo parameter")
+
+
+def algo_kwargs(rowptr_dev, nnz):
+    """algo / row arguments of the current parameter for direct ops.spmm_* calls."""
+    from paddle_sparse_amd import ops
+
+    if ALGO == "row_waves":
+        return {"algo": "row_waves"}
+    return {"algo": "edge_ranges", "row": ops.ptr2ind(rowptr_dev, nnz) if ALGO == "edge_ranges" else None}
+
 
 def dev(a):
     return None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
@@ -25,7 +53,10 @@ def run_gpu(reduce, rowptr, col, val, B):
     from paddle_sparse_amd import ops
 
     fn = getattr(ops, f"spmm_{reduce}")
-    res = fn(dev(rowptr), dev(col), dev(val), dev(B))
+    row = None
+    if ALGO == "edge_ranges":
+        row = dev(np.repeat(np.arange(rowptr.size - 1, dtype=np.int64), np.diff(rowptr)))
+    res = fn(dev(rowptr), dev(col), dev(val), dev(B), row=row, algo=ALGO.replace("_norow", ""))
     torch.cuda.synchronize()
     if isinstance(res, tuple):
         return res[0].cpu().numpy(), res[1].cpu().numpy()
@@ -110,6 +141,8 @@ def test_ties_pick_first_edge():
 def test_variants_k128(variant):
     from paddle_sparse_amd import ops
 
+    once()
+
     row, rowptr, col, val = random_csr(3000, 2000, 40000, seed=variant)
     B = np.random.default_rng(5).standard_normal((2000, 128)).astype(np.float32)
     prev = ops.spmm_set_variant(variant)
@@ -130,6 +163,8 @@ def test_variants_k128(variant):
 def test_multirow_variants_narrow_k(variant, K):
     from paddle_sparse_amd import ops
 
+    once()
+
     row, rowptr, col, val = skewed_csr(1000, 700, seed=K, long_rows=(0, 500, 999), long_deg=300)
     B = np.random.default_rng(K).standard_normal((700, K)).astype(np.float32)
     prev = ops.spmm_set_variant(variant)
@@ -149,6 +184,7 @@ def test_long_rows_take_the_chunked_path(reduce, K):
     (variant 10 switches the chunked path off) and the oracle."""
     from paddle_sparse_amd import ops
 
+    once()
     row, rowptr, col, val = skewed_csr(600, 500, seed=K, long_rows=(0, 1, 300, 599), long_deg=5000)
     deg = rowptr[1:] - rowptr[:-1]
     assert (deg > 512).sum() == 4 and (deg == 0).sum() > 0
@@ -211,7 +247,9 @@ def test_config4_per_gpu_shape():
     val = torch.randn(nnz, generator=g, device="cuda")
     rowptr = ops.ind2ptr(row, M)
     B = torch.randn(N, K, generator=g, device="cuda")
-    out = ops.spmm_sum(rowptr, col, val, B)
+    if ALGO == "edge_ranges_norow":
+        pytest.skip("same kernels as edge_ranges")
+    out = ops.spmm_sum(rowptr, col, val, B, **algo_kwargs(rowptr, nnz))
     sample = torch.cat([torch.arange(0, 500, device="cuda"), torch.arange(M - 500, M, device="cuda")])
     e0 = int(rowptr[500])
     e1 = int(rowptr[M - 500])
@@ -237,18 +275,76 @@ def test_linearity_full_size():
     rowptr = ops.ind2ptr(row, M)
     B1 = torch.randn(N, K, generator=g, device="cuda")
     B2 = torch.randn(N, K, generator=g, device="cuda")
-    o1 = ops.spmm_sum(rowptr, col, val, B1)
-    o2 = ops.spmm_sum(rowptr, col, val, B2)
-    o12 = ops.spmm_sum(rowptr, col, val, B1 + 2 * B2)
+    if ALGO == "edge_ranges_norow":
+        pytest.skip("same kernels as edge_ranges")
+    kw = algo_kwargs(rowptr, nnz)
+    o1 = ops.spmm_sum(rowptr, col, val, B1, **kw)
+    o2 = ops.spmm_sum(rowptr, col, val, B2, **kw)
+    o12 = ops.spmm_sum(rowptr, col, val, B1 + 2 * B2, **kw)
     scale = torch.zeros(M, device="cuda").index_add_(0, row, val.abs())
     err = (o12 - (o1 + 2 * o2)).abs().max(dim=1)[0]
     assert bool((err <= 1e-4 * (scale * 6 + 1e-6)).all())
     ones = torch.ones(N, K, device="cuda")
     rs = torch.zeros(M, device="cuda", dtype=torch.float64).index_add_(0, row, val.double())
-    o = ops.spmm_sum(rowptr, col, val, ones)
+    o = ops.spmm_sum(rowptr, col, val, ones, **kw)
     assert bool(((o[:, 0].double() - rs).abs() <= 1e-5 * scale.double() + 1e-6).all())
     assert bool((o == o[:, :1]).all())
     # mean / max agree with sum-derived quantities
     deg = (rowptr[1:] - rowptr[:-1]).clamp(min=1).float()
-    om = ops.spmm_mean(rowptr, col, val, B1)
+    om = ops.spmm_mean(rowptr, col, val, B1, **kw)
     assert bool(((om - o1 / deg[:, None]).abs() <= 1e-5 * (scale / deg * 6)[:, None] + 1e-6).all())
+
+
+def test_row_stats_and_algo_choice():
+    """psa_csr_row_stats against numpy, and the per-matrix choice built on it."""
+    from paddle_sparse_amd import SparseTensor, ops
+
+    once()
+
+    row, rowptr, col, val = skewed_csr(5000, 300, seed=9, long_rows=(0, 77), long_deg=1500, base_deg=1)
+    deg = np.diff(rowptr)
+    want = (int((deg == 0).sum()), int(((deg >= 1) & (deg <= 2)).sum()), int((deg > 128).sum()), int(deg.max()))
+    assert ops.csr_row_stats(dev(rowptr)) == want
+    skew = SparseTensor(rowptr=dev(rowptr), col=dev(col), value=dev(val), sparse_sizes=(5000, 300),
+                        is_sorted=True, trust_data=True)
+    assert skew.storage._spmm_algo() == "edge_ranges" and skew.storage._longest_row() == want[3]
+    row, rowptr, col, val = random_csr(800, 300, 8000, seed=1)
+    flat = SparseTensor(rowptr=dev(rowptr), col=dev(col), value=dev(val), sparse_sizes=(800, 300),
+                        is_sorted=True, trust_data=True)
+    assert flat.storage._spmm_algo() == "row_waves"
+    assert ops.csr_row_stats(dev(np.zeros(1, np.int64))) == (0, 0, 0, 0)
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max"])
+def test_edge_ranges_boundaries(reduce):
+    """Rows cut by range boundaries in every way: one row spanning many ranges, rows
+    ending exactly at a boundary, single-edge rows around boundaries, a tail of empty rows."""
+    rng = np.random.default_rng(11)
+    deg = np.concatenate([[256, 0, 256, 1, 255, 1000, 0, 0, 3, 509, 1, 1, 1, 253], rng.integers(0, 4, 300), [0] * 70])
+    M, N, K = deg.size, 97, 128
+    rowptr = np.zeros(M + 1, np.int64)
+    rowptr[1:] = np.cumsum(deg)
+    nnz = int(rowptr[-1])
+    col = rng.integers(0, N, nnz, dtype=np.int64)
+    val = rng.standard_normal(nnz).astype(np.float32)
+    B = rng.standard_normal((N, K)).astype(np.float32)
+    B[::3] = 1.0  # ties
+    check(reduce, rowptr, col, val, B)
+
+
+def test_edge_ranges_bitwise_reproducible():
+    from paddle_sparse_amd import ops
+
+    once()
+
+    row, rowptr, col, val = skewed_csr(3000, 500, seed=4, long_rows=(1, 2000), long_deg=3000, base_deg=2)
+    B = np.random.default_rng(3).standard_normal((500, 128)).astype(np.float32)
+    d = [dev(x) for x in (rowptr, col, val, B, row)]
+    a = ops.spmm_sum(d[0], d[1], d[2], d[3], row=d[4], algo="edge_ranges")
+    for _ in range(3):
+        assert torch.equal(a, ops.spmm_sum(d[0], d[1], d[2], d[3], row=d[4], algo="edge_ranges"))
+    # min/max: identical to the row-wave kernels, values and winners
+    for red in ("min", "max"):
+        o1, a1 = getattr(ops, f"spmm_{red}")(d[0], d[1], d[2], d[3], algo="row_waves")
+        o2, a2 = getattr(ops, f"spmm_{red}")(d[0], d[1], d[2], d[3], row=d[4], algo="edge_ranges")
+        assert torch.equal(o1, o2) and torch.equal(a1, a2)
