@@ -346,6 +346,50 @@ int psa_coalesce_small(const int64_t* row, const int64_t* col, int64_t n,
                        void* workspace, size_t workspace_bytes,
                        psa_stream_t stream);
 
+/* ---- coalesce(index, value, m, n, op) in two calls -------------------------
+ * What the reference's user gets from ONE call (paddle_sparse/coalesce.py:25-29
+ * = SparseStorage(is_sorted=False) storage.py:158-171 + storage.coalesce
+ * storage.py:454-486), with the one host read the dynamic output size needs:
+ *
+ *   psa_coalesce_count(...)          keys row * N + col, stable sort, run count
+ *   host reads status[0] (= count)   <- the only synchronisation
+ *   psa_coalesce_write(...)          [2, count] index + reduced values
+ *
+ * status = the first two int64 words of the workspace: status[0] = number of
+ * distinct (row, col) pairs; status[1] = flags, bit 0: some row/col lies outside
+ * [0, M) x [0, N) (the reference asserts this, storage.py:78-91: raise, the
+ * outputs are unspecified then), bit 1: the input was not sorted by (row, col).
+ * psa_coalesce_write takes the count from the device, so a caller may also
+ * allocate worst-case outputs (n rows), enqueue both calls back to back and read
+ * the status afterwards (count < 0 in the call = "not read yet").
+ *
+ * value: [n, D] of `dtype` (psa_dtype) or NULL; fp32 / int32 scalars (D = 1) ride
+ * through the sort as its payload.  index_out: int64[2 * rows] with rows >= count,
+ * filled as the contiguous [2, count] index (row' then col'); value_out [rows, D].
+ * n <= 10240 runs as one workgroup whose radix sort stays in the LDS (two
+ * launches in all); larger inputs use psa_index_sort / psa_sort_pairs_u32,
+ * psa_unique_* and psa_segment_reduce.  transpose(index, value, m, n)
+ * (paddle_sparse/transpose.py:41-65) is the same two calls with row/col and M/N
+ * swapped.  workspace: psa_coalesce_workspace_bytes(n, M, N) bytes, 16-byte
+ * aligned, untouched between the two calls. */
+size_t psa_coalesce_workspace_bytes(int64_t n, int64_t M, int64_t N);
+int psa_coalesce_count(const int64_t* row, const int64_t* col, const void* value,
+                       int dtype, int64_t D, int64_t n, int64_t M, int64_t N,
+                       void* workspace, size_t workspace_bytes,
+                       psa_stream_t stream);
+int psa_coalesce_write(const void* value, int dtype, int64_t D, int64_t n,
+                       int64_t M, int64_t N, int reduce, int64_t count,
+                       const void* workspace, int64_t* index_out,
+                       void* value_out, psa_stream_t stream);
+
+/* psa_make_keys for (row, col) with the reference's range assertions folded in:
+ * keys[i] = row[i] * N + col[i]; status int64[4] (device): status[1] gets bit 0
+ * when some row/col lies outside [0, M) x [0, N), bit 1 when keys[i] < keys[i-1]
+ * for some i (storage.py:163); status[0] is zeroed, status[2..3] are scratch. */
+int psa_make_keys_checked(const int64_t* row, const int64_t* col, int64_t n,
+                          int64_t M, int64_t N, int64_t* keys, int64_t* status,
+                          psa_stream_t stream);
+
 /* Test/bench hook: scatter kernel variant of psa_index_sort for this process
  * (0 = production: single-sweep passes with decoupled look-back, 512 threads x
  * 16 keys; 5 = the same with 1024 x 8; 1-4, 7 = histogram / scan / scatter

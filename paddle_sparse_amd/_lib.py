@@ -69,6 +69,13 @@ SIGNATURES = {
     "psa_coalesce_small_workspace_bytes": (c_size_t, [c_int64]),
     "psa_coalesce_small": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "psa_coalesce_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
+    "psa_coalesce_count": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int64,
+                                   c_void_p, c_size_t, c_void_p]),
+    "psa_coalesce_write": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_int64,
+                                   c_void_p, c_void_p, c_void_p, c_void_p]),
+    "psa_make_keys_checked": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                      c_void_p]),
     "psa_make_keys": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p,
                               c_void_p, c_void_p]),
     "psa_split_keys": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),

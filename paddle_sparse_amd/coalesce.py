@@ -19,28 +19,26 @@ import torch
 from . import ops
 
 
-_ALWAYS_SORT_BELOW = 1 << 18
-_ONE_WORKGROUP_BELOW = 10_240  # entries = one tile step of the one-workgroup kernel (it takes up to 40960,
-# but from its second tile step on the multi-launch chain is faster: 174 vs 145 us at 16384, tools/coalesce_sizes.py)
+_ONE_WORKGROUP_BELOW = 10_240  # entries the one-workgroup, LDS-resident sort of the chain takes
+_CHAIN_BELOW = 1 << 20  # entries: the two-call chain (always sorts); above, asking whether the keys
+# are sorted already is worth its host read (a sorted 100 M-entry input skips 4 ms of sort)
 
 
 def _coalesce_sorted_stream(row, col, value, m: int, n: int, op: str):
     nnz = col.numel()
     if nnz == 0:
         return row, col, value
-    if nnz <= _ONE_WORKGROUP_BELOW and m * n < (1 << 62) and m > 0 and n > 0:
-        # one launch for sort + run lengths, one for the values
-        count, ptr, new_row, new_col, perm = ops.coalesce_small(row, col, m, n)
-        if value is not None:
-            value = ops.segment_csr(value, ptr, op, perm=perm) if count < nnz else ops.gather_rows(value, perm)
-        return new_row, new_col, value
-    # Small inputs are launch- and sync-bound (10k edges: ~150 us, of which each
-    # host read is ~15): asking the device whether the keys are sorted already
-    # costs more than sorting them, so below this size the question is skipped.
-    ask = nnz > _ALWAYS_SORT_BELOW
-    keys, unsorted = ops.make_keys(row, col, n, check_sorted=ask)
+    if (nnz <= _CHAIN_BELOW and m > 0 and n > 0 and m * n < (1 << 62)
+            and (value is None or value.dtype in ops._DTYPE_ID)):
+        # psa_coalesce_count + psa_coalesce_write on worst-case buffers, one host read at the end
+        index, value, _ = ops.coalesce_chain(row, col, value, m, n, op)
+        return index[0], index[1], value
+    keys, status = ops.make_keys_checked(row, col, m, n)
+    flags = int(status[1].item())
+    if flags & 1:
+        raise ops.IndexRangeError(f"coalesce: an index lies outside the {m} x {n} matrix")
     perm = None
-    was_sorted = ask and not int(unsorted.item())
+    was_sorted = not (flags & 2)
     if not was_sorted:
         if value is not None and value.dim() == 1 and value.element_size() == 4:
             # 4-byte scalar values ride through the sort as the payload: the
@@ -86,15 +84,14 @@ def _coalesce_two_sorted(row_a, col_a, value_a, row_b, col_b, value_b, n: int, o
 
 
 def _stack_index(row: torch.Tensor, col: torch.Tensor) -> torch.Tensor:
-    """stack([row, col]) (coalesce.py:29) without the copy when row and col are
-    already the two rows of one [2, nnz] buffer (ops.unique_sorted writes them
-    that way)."""
-    base = row._base
-    if (base is not None and base is col._base and base.dim() == 2 and base.shape[0] == 2
-            and base.is_contiguous() and row.numel() == base.shape[1]
-            and row.data_ptr() == base.data_ptr()
-            and col.data_ptr() == base.data_ptr() + base.shape[1] * base.element_size()):
-        return base
+    """stack([row, col]) (coalesce.py:29) without the copy when col already
+    follows row in one buffer (the coalesce chain and ops.unique_sorted write
+    them that way)."""
+    n = row.numel()
+    if (row.dim() == 1 and col.dim() == 1 and col.numel() == n and row.is_contiguous() and col.is_contiguous()
+            and row.untyped_storage().data_ptr() == col.untyped_storage().data_ptr()
+            and col.storage_offset() == row.storage_offset() + n):
+        return torch.as_strided(row, (2, n), (n, 1))
     return torch.stack([row, col], dim=0)
 
 

@@ -15,9 +15,14 @@
 
 #include <type_traits>
 
+#include "coalesce_internal.h"
 #include "common.h"
+#include "reduce_util.h"
 
 namespace {
+
+using psa::Acc;
+using psa::mean_div;
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
@@ -116,8 +121,9 @@ unique_write_kernel(const int64_t* __restrict__ keys, int64_t n, int64_t N,
                     const uint32_t* __restrict__ block_offsets,
                     const int64_t* __restrict__ count,
                     int64_t* __restrict__ ptr_out, int64_t* __restrict__ row_out,
-                    int64_t* __restrict__ col_out) {
+                    int64_t* __restrict__ col_out, int packed) {
   __shared__ uint32_t wsum[kWaves];
+  if (packed) col_out = row_out + *count;  // [2, count] index: the col row follows the row row
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -156,46 +162,16 @@ unique_write_kernel(const int64_t* __restrict__ keys, int64_t n, int64_t N,
 // ---- segmented reduce ------------------------------------------------------
 enum { R_SUM = 0, R_MEAN = 1, R_MIN = 2, R_MAX = 3 };
 
-template <typename T>
-struct Acc {
-  using type = T;
-  static __device__ type load(const T* p) { return *p; }
-  static __device__ void store(T* p, type v) { *p = v; }
-};
-template <>
-struct Acc<__half> {
-  using type = float;
-  static __device__ type load(const __half* p) { return __half2float(*p); }
-  static __device__ void store(__half* p, type v) { *p = __float2half(v); }
-};
-template <>
-struct Acc<__hip_bfloat16> {
-  using type = float;
-  static __device__ type load(const __hip_bfloat16* p) { return __bfloat162float(*p); }
-  static __device__ void store(__hip_bfloat16* p, type v) { *p = __float2bfloat16(v); }
-};
-
-template <typename A>
-__device__ __forceinline__ A mean_div(A acc, int64_t cnt) {
-  if constexpr (std::is_integral<A>::value) {
-    // pytorch_scatter: div_(count, rounding_mode="floor")
-    A q = acc / static_cast<A>(cnt);
-    if ((acc % static_cast<A>(cnt) != 0) && ((acc < 0) != (cnt < 0))) --q;
-    return q;
-  } else {
-    return acc / static_cast<A>(cnt);
-  }
-}
-
 // One thread per output element (s, d); sequential, in segment order — the
 // same order as the reference's segment_csr, so fp sums are reproducible.
 template <typename T, int RED>
 __global__ void __launch_bounds__(kThreads)
 segment_reduce_kernel(const T* __restrict__ src, const int64_t* __restrict__ perm,
                       const int64_t* __restrict__ ptr, int64_t nseg, int64_t D,
-                      T* __restrict__ out) {
+                      T* __restrict__ out, const int64_t* __restrict__ nseg_dev) {
   using A = typename Acc<T>::type;
   const int64_t g = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
+  if (nseg_dev) nseg = *nseg_dev < nseg ? *nseg_dev : nseg;
   if (g >= nseg * D) return;
   const int64_t s = D == 1 ? g : g / D;
   const int64_t d = D == 1 ? 0 : g - s * D;
@@ -221,10 +197,11 @@ __global__ void __launch_bounds__(kThreads)
 segment_reduce_wave_kernel(const T* __restrict__ src,
                            const int64_t* __restrict__ perm,
                            const int64_t* __restrict__ ptr, int64_t nseg,
-                           T* __restrict__ out) {
+                           T* __restrict__ out, const int64_t* __restrict__ nseg_dev) {
   using A = typename Acc<T>::type;
   const int lane = threadIdx.x & 63;
   const int64_t s = static_cast<int64_t>(blockIdx.x) * kWaves + (threadIdx.x >> 6);
+  if (nseg_dev) nseg = *nseg_dev < nseg ? *nseg_dev : nseg;
   if (s >= nseg) return;
   const int64_t b = ptr[s], e = ptr[s + 1];
   A acc = A(0);
@@ -263,7 +240,7 @@ segment_reduce_wave_kernel(const T* __restrict__ src,
 template <typename T>
 int launch_segment(int reduce, const void* src, const int64_t* perm,
                    const int64_t* ptr, int64_t nseg, int64_t D, int64_t n_hint,
-                   void* out, hipStream_t s) {
+                   void* out, hipStream_t s, const int64_t* nseg_dev = nullptr) {
   const T* sp = static_cast<const T*>(src);
   T* op = static_cast<T*>(out);
   const bool wave = D == 1 && n_hint >= 32 * nseg;
@@ -271,7 +248,7 @@ int launch_segment(int reduce, const void* src, const int64_t* perm,
     const int64_t blocks = psa::ceil_div(nseg, kWaves);
     PSA_REQUIRE(blocks <= 0x7fffffff, "too many segments for one launch");
     const dim3 grid(static_cast<unsigned>(blocks)), block(kThreads);
-#define PSA_W(R) hipLaunchKernelGGL((segment_reduce_wave_kernel<T, R>), grid, block, 0, s, sp, perm, ptr, nseg, op)
+#define PSA_W(R) hipLaunchKernelGGL((segment_reduce_wave_kernel<T, R>), grid, block, 0, s, sp, perm, ptr, nseg, op, nseg_dev)
     if (reduce == PSA_SUM) PSA_W(R_SUM);
     else if (reduce == PSA_MEAN) PSA_W(R_MEAN);
     else if (reduce == PSA_MIN) PSA_W(R_MIN);
@@ -281,7 +258,7 @@ int launch_segment(int reduce, const void* src, const int64_t* perm,
     const int64_t blocks = psa::ceil_div(nseg * D, kThreads);
     PSA_REQUIRE(blocks <= 0x7fffffff, "too many elements for one launch");
     const dim3 grid(static_cast<unsigned>(blocks)), block(kThreads);
-#define PSA_S(R) hipLaunchKernelGGL((segment_reduce_kernel<T, R>), grid, block, 0, s, sp, perm, ptr, nseg, D, op)
+#define PSA_S(R) hipLaunchKernelGGL((segment_reduce_kernel<T, R>), grid, block, 0, s, sp, perm, ptr, nseg, D, op, nseg_dev)
     if (reduce == PSA_SUM) PSA_S(R_SUM);
     else if (reduce == PSA_MEAN) PSA_S(R_MEAN);
     else if (reduce == PSA_MIN) PSA_S(R_MIN);
@@ -297,7 +274,48 @@ size_t unique_ws_bytes(int64_t n) {
   return static_cast<size_t>(nb) * sizeof(uint32_t) + 256;
 }
 
+int segment_dispatch(int reduce, int dtype, const void* src, const int64_t* perm, const int64_t* ptr,
+                     int64_t nseg, int64_t D, int64_t n_hint, void* out, hipStream_t s,
+                     const int64_t* nseg_dev) {
+  switch (dtype) {
+    case PSA_F32: return launch_segment<float>(reduce, src, perm, ptr, nseg, D, n_hint, out, s, nseg_dev);
+    case PSA_F64: return launch_segment<double>(reduce, src, perm, ptr, nseg, D, n_hint, out, s, nseg_dev);
+    case PSA_I32: return launch_segment<int32_t>(reduce, src, perm, ptr, nseg, D, n_hint, out, s, nseg_dev);
+    case PSA_I64: return launch_segment<int64_t>(reduce, src, perm, ptr, nseg, D, n_hint, out, s, nseg_dev);
+    case PSA_F16: return launch_segment<__half>(reduce, src, perm, ptr, nseg, D, n_hint, out, s, nseg_dev);
+    case PSA_BF16: return launch_segment<__hip_bfloat16>(reduce, src, perm, ptr, nseg, D, n_hint, out, s, nseg_dev);
+    default:
+      psa::set_error("psa_segment_reduce: unsupported dtype");
+      return PSA_ERR_UNSUPPORTED;
+  }
+}
+
 }  // namespace
+
+namespace psa {
+
+int unique_write_packed(const int64_t* sorted_keys, int64_t n, int64_t N, const void* workspace,
+                        const int64_t* count, int64_t* ptr_out, int64_t* index_out, hipStream_t s) {
+  PSA_REQUIRE(n > 0 && N > 0, "empty input");
+  PSA_REQUIRE(sorted_keys && workspace && count && index_out, "NULL pointer");
+  const int64_t nb = ceil_div(n, kTile);
+  hipLaunchKernelGGL(unique_write_kernel, dim3(static_cast<unsigned>(nb)), dim3(kThreads), 0, s, sorted_keys, n, N,
+                     static_cast<const uint32_t*>(workspace), count, ptr_out, index_out,
+                     static_cast<int64_t*>(nullptr), 1);
+  PSA_LAUNCH_CHECK();
+  return PSA_OK;
+}
+
+int segment_reduce_dev(int reduce, int dtype, const void* src, const int64_t* perm,
+                       const int64_t* ptr, int64_t nseg_bound, const int64_t* nseg_dev,
+                       int64_t D, int64_t n_hint, void* out, hipStream_t s) {
+  PSA_REQUIRE(reduce >= PSA_SUM && reduce <= PSA_MAX, "bad reduce");
+  if (nseg_bound <= 0 || D <= 0) return PSA_OK;
+  PSA_REQUIRE(ptr && out, "NULL pointer");
+  return segment_dispatch(reduce, dtype, src, perm, ptr, nseg_bound, D, n_hint, out, s, nseg_dev);
+}
+
+}  // namespace psa
 
 extern "C" {
 
@@ -341,7 +359,7 @@ int psa_unique_write(const int64_t* sorted_keys, int64_t n, int64_t N,
   hipLaunchKernelGGL(unique_write_kernel, dim3(static_cast<unsigned>(nb)),
                      dim3(kThreads), 0, psa::as_stream(stream), sorted_keys, n, N,
                      static_cast<const uint32_t*>(workspace), count, ptr_out,
-                     row_out, col_out);
+                     row_out, col_out, 0);
   PSA_LAUNCH_CHECK();
   return PSA_OK;
 }
@@ -354,18 +372,7 @@ int psa_segment_reduce(int reduce, int dtype, const void* src,
   PSA_REQUIRE(nseg >= 0 && D >= 0, "negative size");
   if (nseg == 0 || D == 0) return PSA_OK;
   PSA_REQUIRE(ptr && out, "NULL pointer");
-  hipStream_t s = psa::as_stream(stream);
-  switch (dtype) {
-    case PSA_F32: return launch_segment<float>(reduce, src, perm, ptr, nseg, D, n_hint, out, s);
-    case PSA_F64: return launch_segment<double>(reduce, src, perm, ptr, nseg, D, n_hint, out, s);
-    case PSA_I32: return launch_segment<int32_t>(reduce, src, perm, ptr, nseg, D, n_hint, out, s);
-    case PSA_I64: return launch_segment<int64_t>(reduce, src, perm, ptr, nseg, D, n_hint, out, s);
-    case PSA_F16: return launch_segment<__half>(reduce, src, perm, ptr, nseg, D, n_hint, out, s);
-    case PSA_BF16: return launch_segment<__hip_bfloat16>(reduce, src, perm, ptr, nseg, D, n_hint, out, s);
-    default:
-      psa::set_error("psa_segment_reduce: unsupported dtype");
-      return PSA_ERR_UNSUPPORTED;
-  }
+  return segment_dispatch(reduce, dtype, src, perm, ptr, nseg, D, n_hint, out, psa::as_stream(stream), nullptr);
 }
 
 }  // extern "C"

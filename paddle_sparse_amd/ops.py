@@ -24,6 +24,27 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class _NoSwitch:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def _on(device):
+    """Context that makes `device` current for the launches inside — the no-op
+    singleton when it already is (torch.cuda.device() costs ~8 us per op even
+    then, as much as two kernel launches)."""
+    idx = device.index
+    if idx is None or idx == torch.cuda.current_device():
+        return _NO_SWITCH
+    return torch.cuda.device(device)
+
+
 def _gpu(x: torch.Tensor, name: str) -> torch.Tensor:
     if not isinstance(x, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor")
@@ -56,7 +77,7 @@ def ind2ptr(ind: torch.Tensor, M: int) -> torch.Tensor:
     """csrc/convert.cpp:13-43.  ind: sorted int64[E] -> int64[M+1]."""
     ind = _index(ind, "ind")
     out = torch.empty(M + 1, dtype=torch.int64, device=ind.device)
-    with torch.cuda.device(ind.device):
+    with _on(ind.device):
         check(_lib.load().psa_ind2ptr(_ptr(ind), ind.numel(), M, _ptr(out), _stream()))
     return out
 
@@ -67,7 +88,7 @@ def ptr2ind(ptr: torch.Tensor, E: int) -> torch.Tensor:
     if ptr.numel() < 1:
         raise ValueError("ptr must have at least one element")
     out = torch.empty(E, dtype=torch.int64, device=ptr.device)
-    with torch.cuda.device(ptr.device):
+    with _on(ptr.device):
         check(_lib.load().psa_ptr2ind(_ptr(ptr), ptr.numel() - 1, E, _ptr(out), _stream()))
     return out
 
@@ -123,7 +144,7 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
     arg_bytes = None
     if want_arg_bytes and minmax and K % 4 == 0 and (want_arg or K <= 256):
         arg_bytes = torch.empty((M, K), dtype=torch.uint8, device=mat.device)
-    with torch.cuda.device(mat.device):
+    with _on(mat.device):
         check(lib.psa_spmm_coo(rid, _ptr(rowptr), _ptr(row), _ptr(col), _ptr(value), _ptr(mat),
                                M, N, K, nnz, _ptr(out), _ptr(arg), _ptr(arg_bytes),
                                _lib.SPMM_ALGO_ID[algo], _ptr(ws), ws_bytes, _stream()))
@@ -159,7 +180,7 @@ def csr_row_stats(rowptr: torch.Tensor) -> Tuple[int, int, int, int]:
     longest row) of a CSR pointer.  Synchronises (one 32-byte host read)."""
     rowptr = _index(rowptr, "rowptr")
     stats = torch.empty(4, dtype=torch.int64, device=rowptr.device)
-    with torch.cuda.device(rowptr.device):
+    with _on(rowptr.device):
         check(_lib.load().psa_csr_row_stats(_ptr(rowptr), rowptr.numel() - 1, _ptr(stats), _stream()))
     e, t, b, m = stats.tolist()
     return e, t, b, m
@@ -204,7 +225,7 @@ def index_sort(keys: torch.Tensor, max_value: Optional[int] = None,
     lib = _lib.load()
     nbytes = lib.psa_index_sort_workspace_bytes(n, max_value)
     ws = _workspace(nbytes, keys.device)
-    with torch.cuda.device(keys.device):
+    with _on(keys.device):
         check(lib.psa_index_sort(_ptr(keys), n, max_value, _ptr(out), _ptr(perm),
                                  _ptr(ws), ws.numel(), _stream()))
     return out, perm
@@ -221,7 +242,7 @@ def index_sort_checked(keys: torch.Tensor, max_value: int):
     out = torch.empty(n, dtype=torch.int64, device=keys.device)
     lib = _lib.load()
     ws = _workspace(lib.psa_index_sort_workspace_bytes(n, max_value), keys.device)
-    with torch.cuda.device(keys.device):
+    with _on(keys.device):
         check(lib.psa_index_sort(_ptr(keys), n, max_value, _ptr(out), _ptr(perm),
                                  _ptr(ws), ws.numel(), _stream()))
         status = lib.psa_index_sort_status(_ptr(ws), n, max_value, _stream())
@@ -245,7 +266,7 @@ def sort_pairs(keys: torch.Tensor, payload: torch.Tensor, max_value: Optional[in
     out_pay = torch.empty_like(payload)
     lib = _lib.load()
     ws = _workspace(lib.psa_index_sort_workspace_bytes(n, max_value), keys.device)
-    with torch.cuda.device(keys.device):
+    with _on(keys.device):
         check(lib.psa_sort_pairs_u32(_ptr(keys), _ptr(payload), n, max_value, _ptr(out_keys),
                                      _ptr(out_pay), _ptr(ws), ws.numel(), _stream()))
     return out_keys, out_pay
@@ -264,7 +285,7 @@ def sort_pairs_field(keys: torch.Tensor, payload: torch.Tensor, first_bit: int, 
     out_keys, out_pay = torch.empty_like(keys), torch.empty_like(payload)
     lib = _lib.load()
     ws = _workspace(lib.psa_index_sort_workspace_bytes(n, max_value), keys.device)
-    with torch.cuda.device(keys.device):
+    with _on(keys.device):
         check(lib.psa_sort_pairs_u32_field(_ptr(keys), _ptr(payload), n, int(first_bit), max_value,
                                            _ptr(out_keys), _ptr(out_pay), _ptr(ws), ws.numel(), _stream()))
     return out_keys, out_pay
@@ -291,7 +312,7 @@ def merge_sorted(a: torch.Tensor, b: torch.Tensor, payload_a: Optional[torch.Ten
         pay_out = torch.empty(na + nb, dtype=payload_a.dtype, device=a.device)
     merged = torch.empty(na + nb, dtype=torch.int64, device=a.device)
     source = torch.empty(na + nb, dtype=torch.int64, device=a.device) if want_source else None
-    with torch.cuda.device(a.device):
+    with _on(a.device):
         check(_lib.load().psa_merge_sorted(_ptr(a), na, _ptr(b), nb, _ptr(payload_a), _ptr(payload_b),
                                            _ptr(merged), _ptr(source), _ptr(pay_out), _stream()))
     return merged, source, pay_out
@@ -315,12 +336,81 @@ def coalesce_small(row: torch.Tensor, col: torch.Tensor, m: int, n: int):
     count = torch.empty(1, dtype=torch.int64, device=dev)
     lib = _lib.load()
     ws = _workspace(lib.psa_coalesce_small_workspace_bytes(nnz), dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib.psa_coalesce_small(_ptr(row), _ptr(col), nnz, int(m), int(n), out[0].data_ptr(),
                                      out[1].data_ptr(), _ptr(ptr), _ptr(perm), _ptr(count), _ptr(ws),
                                      ws.numel(), _stream()))
     c = int(count.item())
     return c, ptr[:c + 1], out[0, :c], out[1, :c], perm
+
+
+class IndexRangeError(AssertionError):
+    """A row / col index lies outside the matrix (the reference asserts
+    row.max() < M and col.max() < N, storage.py:78-91)."""
+
+
+def coalesce_chain(row: torch.Tensor, col: torch.Tensor, value: Optional[torch.Tensor], m: int, n: int,
+                   op: str = "sum", read_first: bool = False):
+    """coalesce of (row, col, value) of an m x n matrix in two C-ABI calls
+    (psa_coalesce_count / psa_coalesce_write) and ONE host read.  Returns
+    (index int64[2, count] contiguous, value' | None, was_sorted).  With
+    read_first the count is read between the calls and the outputs are sized
+    exactly; otherwise both calls are enqueued on worst-case buffers first."""
+    row, col = _index(row, "row"), _index(col, "col")
+    nnz, dev = row.numel(), row.device
+    if col.numel() != nnz:
+        raise ValueError("row and col must have the same length")
+    dt, D = 0, 0
+    if value is not None:
+        _gpu(value, "value")
+        if value.dtype not in _DTYPE_ID:
+            raise TypeError(f"coalesce: unsupported value dtype {value.dtype}")
+        if value.shape[0] != nnz:
+            raise ValueError("value.shape[0] must equal nnz")
+        value = value.contiguous()
+        dt, D = _DTYPE_ID[value.dtype], 1
+        for s in value.shape[1:]:
+            D *= s
+    if nnz == 0:
+        return torch.empty((2, 0), dtype=torch.int64, device=dev), value, True
+    lib = _lib.load()
+    ws = _workspace(lib.psa_coalesce_workspace_bytes(nnz, int(m), int(n)), dev)
+    status = ws[:16].view(torch.int64)
+    rid = REDUCE_ID[op]
+    tail = tuple(value.shape[1:]) if value is not None else ()
+    with _on(dev):
+        check(lib.psa_coalesce_count(_ptr(row), _ptr(col), _ptr(value), dt, D, nnz, int(m), int(n),
+                                     _ptr(ws), ws.numel(), _stream()))
+        count = -1
+        if read_first:
+            count, flags = status.tolist()
+            if flags & 1:
+                raise IndexRangeError(f"coalesce: an index lies outside the {m} x {n} matrix")
+        rows = nnz if count < 0 else count
+        index = torch.empty(2 * rows, dtype=torch.int64, device=dev)
+        out = torch.empty((rows,) + tail, dtype=value.dtype, device=dev) if value is not None else None
+        check(lib.psa_coalesce_write(_ptr(value), dt, D, nnz, int(m), int(n), rid, count, _ptr(ws),
+                                     _ptr(index), _ptr(out), _stream()))
+        if not read_first:
+            count, flags = status.tolist()
+            if flags & 1:
+                raise IndexRangeError(f"coalesce: an index lies outside the {m} x {n} matrix")
+    index = index[:2 * count].view(2, count)
+    if out is not None:
+        out = out[:count]
+    return index, out, not (flags & 2)
+
+
+def make_keys_checked(row: torch.Tensor, col: torch.Tensor, m: int, n: int):
+    """keys = row * n + col plus the device status words {0, flags}: bit 0 = an
+    index outside [0, m) x [0, n), bit 1 = keys not sorted (storage.py:159-163)."""
+    row, col = _index(row, "row"), _index(col, "col")
+    keys = torch.empty_like(row)
+    status = torch.empty(4, dtype=torch.int64, device=row.device)
+    with _on(row.device):
+        check(_lib.load().psa_make_keys_checked(_ptr(row), _ptr(col), row.numel(), int(m), int(n), _ptr(keys),
+                                                _ptr(status), _stream()))
+    return keys, status
 
 
 def make_keys(a: torch.Tensor, b: torch.Tensor, mul: int, check_sorted: bool = False
@@ -332,7 +422,7 @@ def make_keys(a: torch.Tensor, b: torch.Tensor, mul: int, check_sorted: bool = F
         raise ValueError("a and b must have the same length")
     keys = torch.empty_like(a)
     flag = torch.zeros(1, dtype=torch.int32, device=a.device) if check_sorted else None
-    with torch.cuda.device(a.device):
+    with _on(a.device):
         check(_lib.load().psa_make_keys(_ptr(a), _ptr(b), int(mul), a.numel(), _ptr(keys),
                                         _ptr(flag), _stream()))
     return keys, flag
@@ -345,7 +435,7 @@ def split_keys(keys: torch.Tensor, div: int, want_hi: bool = True, want_lo: bool
     keys = _index(keys, "keys")
     hi = torch.empty_like(keys) if want_hi else None
     lo = torch.empty_like(keys) if want_lo else None
-    with torch.cuda.device(keys.device):
+    with _on(keys.device):
         check(_lib.load().psa_split_keys(_ptr(keys), keys.numel(), int(div), _ptr(hi), _ptr(lo),
                                          _stream()))
     return hi, lo
@@ -361,7 +451,7 @@ def gather_rows(src: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
     row_bytes = src.element_size()
     for s in src.shape[1:]:
         row_bytes *= s
-    with torch.cuda.device(src.device):
+    with _on(src.device):
         check(_lib.load().psa_gather_rows(_ptr(src), _ptr(perm), n, row_bytes, _ptr(out), _stream()))
     return out
 
@@ -369,7 +459,7 @@ def gather_rows(src: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
 def invert_permutation(perm: torch.Tensor) -> torch.Tensor:
     perm = _index(perm, "perm")
     inv = torch.empty_like(perm)
-    with torch.cuda.device(perm.device):
+    with _on(perm.device):
         check(_lib.load().psa_invert_permutation(_ptr(perm), perm.numel(), _ptr(inv), _stream()))
     return inv
 
@@ -392,7 +482,7 @@ def segment_csr(src: torch.Tensor, indptr: torch.Tensor, reduce: str = "sum",
         D *= s
     n_rows = perm.numel() if perm is not None else src.shape[0]
     out = torch.empty((nseg,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
-    with torch.cuda.device(src.device):
+    with _on(src.device):
         check(_lib.load().psa_segment_reduce(REDUCE_ID[reduce], _DTYPE_ID[src.dtype], _ptr(src),
                                              _ptr(perm), _ptr(indptr), nseg, D, n_rows,
                                              _ptr(out), _stream()))
@@ -411,7 +501,7 @@ def unique_sorted(sorted_keys: torch.Tensor, N: int, want_ptr: bool = True,
     lib = _lib.load()
     ws = _workspace(lib.psa_unique_workspace_bytes(n), dev)
     count_d = torch.empty(1, dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         check(lib.psa_unique_count(_ptr(sorted_keys), n, _ptr(ws), ws.numel(), _ptr(count_d), _stream()))
         count = int(count_d.item())
         ptr = torch.empty(count + 1, dtype=torch.int64, device=dev) if want_ptr else None
@@ -454,7 +544,7 @@ def spmm_value_bw(row, rowptr, col, mat, grad, reduce: str = "sum") -> torch.Ten
     lib = _lib.load()
     ws_bytes = lib.psa_spmm_value_bw_workspace_bytes(nnz)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=mat.device) if ws_bytes else None
-    with torch.cuda.device(mat.device):
+    with _on(mat.device):
         check(lib.psa_spmm_value_bw(REDUCE_ID[reduce], _ptr(rowptr), _ptr(col), _ptr(mat),
                                     _ptr(grad), M, K, nnz, _ptr(out), _ptr(ws), ws_bytes, _stream()))
     return out
@@ -470,7 +560,7 @@ def transpose_weights(value, csr2csc, row_csc, rowptr, mean: bool) -> torch.Tens
     if mean:
         row_csc, rowptr = _index(row_csc, "row_csc"), _index(rowptr, "rowptr")
     out = torch.empty(nnz, dtype=torch.float32, device=csr2csc.device)
-    with torch.cuda.device(csr2csc.device):
+    with _on(csr2csc.device):
         check(_lib.load().psa_transpose_weights(_ptr(value), _ptr(csr2csc),
                                                 _ptr(row_csc) if mean else None,
                                                 _ptr(rowptr) if mean else None,
@@ -490,7 +580,7 @@ def spmm_minmax_bw(col, value, mat, grad, arg_out, want_value: bool = True, want
     (N, K), M, nnz = mat.shape, grad.shape[0], col.numel()
     gv = torch.empty(nnz, dtype=torch.float32, device=mat.device) if want_value else None
     gm = torch.empty((N, K), dtype=torch.float32, device=mat.device) if want_mat else None
-    with torch.cuda.device(mat.device):
+    with _on(mat.device):
         check(_lib.load().psa_spmm_minmax_bw(_ptr(col), _ptr(value), _ptr(mat), _ptr(grad),
                                              _ptr(arg_out), M, N, K, nnz, _ptr(gv), _ptr(gm),
                                              _stream()))
@@ -502,7 +592,7 @@ def csc_edge_tags(rowptr, row_csc, csr2csc) -> torch.Tensor:
     bit 7 marks rows of more than 128 edges).  Structure only — cache it next to csr2csc."""
     rowptr, row_csc, csr2csc = _index(rowptr, "rowptr"), _index(row_csc, "row_csc"), _index(csr2csc, "csr2csc")
     tag = torch.empty(csr2csc.numel(), dtype=torch.uint8, device=csr2csc.device)
-    with torch.cuda.device(csr2csc.device):
+    with _on(csr2csc.device):
         check(_lib.load().psa_csc_edge_tags(_ptr(rowptr), _ptr(row_csc), _ptr(csr2csc),
                                             csr2csc.numel(), _ptr(tag), _stream()))
     return tag
@@ -548,7 +638,7 @@ def spmm_minmax_bw_csc(rowptr, colptr, row_csc, csr2csc, tag, value, mat, grad, 
     gm = torch.empty((N, K), dtype=torch.float32, device=grad.device)
     lib = _lib.load()
     ws = _workspace(lib.psa_spmm_minmax_bw_csc_workspace_bytes(M, K, nnz), grad.device)
-    with torch.cuda.device(grad.device):
+    with _on(grad.device):
         check(lib.psa_spmm_minmax_bw_csc(_ptr(rowptr), _ptr(colptr), _ptr(row_csc), _ptr(csr2csc),
                                          _ptr(tag.contiguous()), _ptr(value),
                                          _ptr(mat) if want_value else None, _ptr(grad), _ptr(arg_out),
@@ -583,7 +673,7 @@ def spmm_sum_bw_csc(colptr, row_csc, csr2csc, value, mat, grad, want_value: bool
     gm = torch.empty((N, K), dtype=torch.float32, device=grad.device)
     lib = _lib.load()
     ws = _workspace(lib.psa_spmm_sum_bw_csc_workspace_bytes(K, nnz), grad.device)
-    with torch.cuda.device(grad.device):
+    with _on(grad.device):
         check(lib.psa_spmm_sum_bw_csc(_ptr(colptr), _ptr(row_csc), _ptr(csr2csc), _ptr(value),
                                       _ptr(row_scale), _ptr(mat) if want_value else None, _ptr(grad), N, K, nnz,
                                       _ptr(gv), _ptr(gm), _ptr(ws), ws.numel(), _stream()))
@@ -596,7 +686,7 @@ def bincount(index: torch.Tensor, size: int) -> torch.Tensor:
     """int64[size] occurrence counts (colcount, storage.py:414-418)."""
     index = _index(index, "index")
     out = torch.empty(size, dtype=torch.int64, device=index.device)
-    with torch.cuda.device(index.device):
+    with _on(index.device):
         check(_lib.load().psa_bincount(_ptr(index), index.numel(), size, _ptr(out), _stream()))
     return out
 
@@ -608,7 +698,7 @@ def count2ptr(counts: torch.Tensor) -> torch.Tensor:
     out = torch.empty(n + 1, dtype=torch.int64, device=counts.device)
     lib = _lib.load()
     ws = _workspace(lib.psa_count2ptr_workspace_bytes(n), counts.device)
-    with torch.cuda.device(counts.device):
+    with _on(counts.device):
         check(lib.psa_count2ptr(_ptr(counts), n, _ptr(out), _ptr(ws), ws.numel(), _stream()))
     return out
 
@@ -629,7 +719,7 @@ def scatter(src: torch.Tensor, index: torch.Tensor, dim_size: int, reduce: str =
     out = torch.empty((dim_size,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
     lib = _lib.load()
     ws = _workspace(lib.psa_scatter_workspace_bytes(dim_size), src.device)
-    with torch.cuda.device(src.device):
+    with _on(src.device):
         check(lib.psa_scatter_reduce(REDUCE_ID[reduce], _DTYPE_ID[src.dtype], _ptr(src), _ptr(index),
                                      index.numel(), D, dim_size, _ptr(out), _ptr(ws), ws.numel(),
                                      _stream()))
@@ -640,7 +730,7 @@ def spspmm_count(colA: torch.Tensor, rowptrB: torch.Tensor) -> torch.Tensor:
     """counts[e] = stored entries of B's row colA[e] (products A entry e takes part in)."""
     colA, rowptrB = _index(colA, "colA"), _index(rowptrB, "rowptrB")
     out = torch.empty_like(colA)
-    with torch.cuda.device(colA.device):
+    with _on(colA.device):
         check(_lib.load().psa_spspmm_count(_ptr(colA), colA.numel(), _ptr(rowptrB), _ptr(out),
                                            _stream()))
     return out
@@ -663,7 +753,7 @@ def spspmm_expand(rowA, colA, valA, rowptrB, colB, valB, offsets, owner, total: 
     has_value = valA is not None or valB is not None
     keys = torch.empty(total, dtype=torch.int64, device=colA.device)
     vals = torch.empty(total, dtype=dtype, device=colA.device) if has_value else None
-    with torch.cuda.device(colA.device):
+    with _on(colA.device):
         check(_lib.load().psa_spspmm_expand(_DTYPE_ID[dtype], _ptr(rowA), _ptr(colA), _ptr(valA),
                                             _ptr(rowptrB), _ptr(colB), _ptr(valB), _ptr(offsets),
                                             _ptr(owner), int(total), int(n), _ptr(keys), _ptr(vals),
@@ -685,7 +775,7 @@ def sample_adj(rowptr: torch.Tensor, col: torch.Tensor, idx: torch.Tensor, num_n
     lib = _lib.load()
     S, k, rep, seed = idx.numel(), int(num_neighbors), int(bool(replace)), int(seed) & (2**64 - 1)
     num_nodes = rowptr.numel() - 1
-    with torch.cuda.device(dev):
+    with _on(dev):
         counts = torch.empty(S, dtype=torch.int64, device=dev)
         check(lib.psa_sample_count(_ptr(rowptr), _ptr(idx), S, k, rep, _ptr(counts), _stream()))
         out_rowptr = count2ptr(counts)

@@ -105,10 +105,52 @@ int main() {
   for (int i = 0; i < 8; ++i)
     if (oval[i] != want_v[i]) return std::printf("coalesced value[%d] = %f\n", i, oval[i]), 8;
 
+  // the same known answer through the two-call chain (psa_coalesce_count / _write), both protocols:
+  // (a) worst-case outputs, both calls enqueued, status read afterwards; (b) count read in between
+  {
+    const size_t cb = psa_coalesce_workspace_bytes(cn, cm, cN);
+    void* cws;
+    HIP_OK(hipMalloc(&cws, cb));
+    for (int protocol = 0; protocol < 2; ++protocol) {
+      int64_t status[2] = {-1, -1};
+      PSA_OK_(psa_coalesce_count(d_crow, d_ccol, d_cval, PSA_F32, 2, cn, cm, cN, cws, cb, stream));
+      int64_t rows = cn, known = -1;
+      if (protocol == 1) {
+        HIP_OK(hipMemcpyAsync(status, cws, 16, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        rows = known = status[0];
+      }
+      int64_t* d_index;
+      float* d_cv;
+      HIP_OK(hipMalloc(&d_index, 8 * 2 * rows));
+      HIP_OK(hipMalloc(&d_cv, 4 * 2 * rows));
+      PSA_OK_(psa_coalesce_write(d_cval, PSA_F32, 2, cn, cm, cN, PSA_SUM, known, cws, d_index, d_cv, stream));
+      HIP_OK(hipMemcpyAsync(status, cws, 16, hipMemcpyDeviceToHost, stream));
+      HIP_OK(hipStreamSynchronize(stream));
+      if (status[0] != 4 || status[1] != 2) return std::printf("chain status {%lld, %lld}\n", (long long)status[0], (long long)status[1]), 11;
+      std::vector<int64_t> index(8);
+      std::vector<float> cv(8);
+      HIP_OK(hipMemcpy(index.data(), d_index, 8 * 8, hipMemcpyDeviceToHost));
+      HIP_OK(hipMemcpy(cv.data(), d_cv, 4 * 8, hipMemcpyDeviceToHost));
+      for (int i = 0; i < 4; ++i)
+        if (index[i] != want_r[i] || index[4 + i] != want_c[i]) return std::printf("chain index %d wrong\n", i), 12;
+      for (int i = 0; i < 8; ++i)
+        if (cv[i] != want_v[i]) return std::printf("chain value[%d] = %f\n", i, cv[i]), 13;
+    }
+    // an index outside the matrix comes back as flag bit 0, not as a fault
+    std::vector<int64_t> bad_col = {0, 1, 1, 1, 0, 2};
+    int64_t* d_bad = to_device(bad_col);
+    int64_t status[2];
+    PSA_OK_(psa_coalesce_count(d_crow, d_bad, nullptr, 0, 0, cn, cm, cN, cws, cb, stream));
+    HIP_OK(hipMemcpyAsync(status, cws, 16, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    if (!(status[1] & 1)) return 14;
+  }
+
   // error reporting: a bad enum comes back as a status + message, not a crash
   if (psa_spmm(17, d_rowptr, d_col, d_val, d_B, M, N, K, nnz, d_out, nullptr, nullptr, nullptr, 0, stream) != PSA_ERR_INVALID_ARG)
     return 9;
   if (psa_last_error()[0] == '\0') return 10;
-  std::printf("C-ABI client: ind2ptr, spmm (README KAT), coalesce chain (test_coalesce KAT), error path OK\n");
+  std::printf("C-ABI client: ind2ptr, spmm (README KAT), coalesce as primitives and as the two-call chain (test_coalesce KAT), error path OK\n");
   return 0;
 }

@@ -81,3 +81,99 @@ def test_coalesce_takes_the_small_path_with_the_same_results(op, shape_tail, npd
     tr_i, tr_v = so.transpose(index, val, M, N)
     gt_i, gt_v = ps.transpose(idx(index), torch.from_numpy(val).cuda(), M, N)
     assert np.array_equal(gt_i.cpu().numpy(), tr_i) and np.array_equal(gt_v.cpu().numpy(), tr_v)
+
+
+# ---- the two-call chain (psa_coalesce_count / psa_coalesce_write) -------------------------------
+
+@pytest.mark.parametrize("n,M,N,seed", [
+    (1, 1, 1, 0), (2, 1, 2, 1), (63, 5, 7, 2), (64, 300, 300, 3), (65, 3, 2, 4), (1000, 1000, 1000, 5),
+    (10_000, 1000, 1000, 6),            # BASELINE config 1: one workgroup, sort resident in the LDS
+    (10_240, 70_000, 90_000, 7),        # the one-workgroup limit, 5 passes
+    (10_241, 2, 3, 8),                  # first size on the multi-launch path; massive duplication
+    (5000, 1 << 30, 1 << 31, 11),       # 8 passes in the LDS
+    (300_000, 1 << 20, 1 << 20, 9), (1_000_000, 3000, 3000, 10),
+])
+@pytest.mark.parametrize("read_first", [False, True])
+def test_chain_equals_the_oracle(n, M, N, seed, read_first):
+    from paddle_sparse_amd import ops
+
+    rng = np.random.default_rng(seed)
+    row, col = rng.integers(0, M, n), rng.integers(0, N, n)
+    index = np.stack([row, col])
+    for val, op in ((None, "add"), (rng.integers(-9, 10, n).astype(np.float32), "add"),
+                    (rng.integers(-9, 10, (n, 2)).astype(np.float64), "max"),
+                    (rng.integers(-9, 10, n).astype(np.int64), "min"), (rng.integers(-9, 10, n).astype(np.int32), "mean")):
+        ref_i, ref_v = so.coalesce(index, val, M, N, op)
+        got_i, got_v, was_sorted = ops.coalesce_chain(idx(row), idx(col), None if val is None else torch.from_numpy(val).cuda(),
+                                                      M, N, op, read_first=read_first)
+        assert got_i.is_contiguous() and np.array_equal(got_i.cpu().numpy(), ref_i)
+        assert (got_v is None) == (val is None)
+        if val is not None:
+            assert np.array_equal(got_v.cpu().numpy(), ref_v)
+        key = row.astype(object) * N + col
+        assert was_sorted == bool(np.all(key[1:] >= key[:-1]))
+
+
+def test_chain_and_functional_forms_reject_indices_outside_the_matrix():
+    """The reference asserts row.max() < M and col.max() < N (storage.py:78-91);
+    here the key kernels raise a flag that the one host read brings back."""
+    import paddle_sparse_amd as ps
+    from paddle_sparse_amd import ops
+
+    for n in (100, 50_000, 1_500_000):  # one workgroup, chain, multi-call path
+        rng = np.random.default_rng(n)
+        row, col = rng.integers(0, 40, n), rng.integers(0, 30, n)
+        val = torch.ones(n, device="cuda")
+        for bad_row, bad_col in ((40, 0), (0, 30), (-1, 0), (0, -2)):
+            r, c = row.copy(), col.copy()
+            r[n // 2], c[n // 2] = bad_row, bad_col
+            index = idx(np.stack([r, c]))
+            with pytest.raises(ops.IndexRangeError):
+                ps.coalesce(index, val, 40, 30)
+            with pytest.raises(ops.IndexRangeError):
+                ps.transpose(index, val, 40, 30)
+            with pytest.raises(ops.IndexRangeError):
+                ps.spmm(index, val, 40, 30, torch.ones(30, 4, device="cuda"))
+        ps.coalesce(idx(np.stack([row, col])), val, 40, 30)  # in range: fine
+
+
+def test_chain_replays_from_a_hip_graph():
+    """Both calls are allocation-free and read nothing on the host: with worst-case
+    outputs the whole coalesce is capturable; the status words come back after the replay."""
+    from paddle_sparse_amd import _lib, ops
+
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for n, M, N in ((10_000, 1000, 1000), (200_000, 5000, 7000)):
+        row = torch.randint(0, M, (n,), generator=g, device="cuda")
+        col = torch.randint(0, N, (n,), generator=g, device="cuda")
+        val = torch.randn(n, generator=g, device="cuda")
+        ws = torch.empty(lib.psa_coalesce_workspace_bytes(n, M, N), dtype=torch.uint8, device="cuda")
+        index = torch.empty(2 * n, dtype=torch.int64, device="cuda")
+        out = torch.empty(n, device="cuda")
+
+        def run():
+            st = torch.cuda.current_stream().cuda_stream
+            _lib.check(lib.psa_coalesce_count(row.data_ptr(), col.data_ptr(), val.data_ptr(), 0, 1, n, M, N,
+                                              ws.data_ptr(), ws.numel(), st))
+            _lib.check(lib.psa_coalesce_write(val.data_ptr(), 0, 1, n, M, N, 0, -1, ws.data_ptr(), index.data_ptr(),
+                                              out.data_ptr(), st))
+
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            run()
+        torch.cuda.current_stream().wait_stream(s)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            run()
+        for trial in range(3):
+            row.copy_(torch.randint(0, M, (n,), generator=g, device="cuda"))
+            col.copy_(torch.randint(0, N, (n,), generator=g, device="cuda"))
+            val.copy_(torch.randn(n, generator=g, device="cuda"))
+            graph.replay()
+            torch.cuda.synchronize()
+            count = int(ws[:8].view(torch.int64).item())
+            e_i, e_v, _ = ops.coalesce_chain(row, col, val, M, N, "add")
+            assert count == e_i.shape[1]
+            assert torch.equal(index[:2 * count].view(2, count), e_i) and torch.equal(out[:count], e_v)
