@@ -26,6 +26,35 @@ namespace {
 inline void* stream_of(const paddle::Tensor& t) { return reinterpret_cast<void*>(t.stream()); }
 inline const int64_t* i64(const paddle::Tensor& t) { return t.data<int64_t>(); }
 inline const float* f32(const paddle::Tensor& t) { return t.data<float>(); }
+inline const int64_t* i64_or_null(const paddle::optional<paddle::Tensor>& t) { return t ? t.get().data<int64_t>() : nullptr; }
+inline const float* f32_or_null(const paddle::optional<paddle::Tensor>& t) { return t ? t.get().data<float>() : nullptr; }
+inline paddle::Tensor i64_empty(int64_t n, const paddle::Place& place) { return paddle::empty({n}, paddle::DataType::INT64, place); }
+inline paddle::Tensor scratch(size_t bytes, const paddle::Place& place) {
+  return paddle::empty({static_cast<int64_t>(bytes > 0 ? bytes : 1)}, paddle::DataType::UINT8, place);
+}
+inline int dtype_id_of(const paddle::Tensor& t) {
+  switch (t.dtype()) {
+    case paddle::DataType::FLOAT32: return PSA_F32;
+    case paddle::DataType::FLOAT64: return PSA_F64;
+    case paddle::DataType::INT32: return PSA_I32;
+    case paddle::DataType::INT64: return PSA_I64;
+    case paddle::DataType::FLOAT16: return PSA_F16;
+    case paddle::DataType::BFLOAT16: return PSA_BF16;
+    default: PD_THROW("unsupported value dtype");
+  }
+  return -1;
+}
+inline int64_t row_elems(const paddle::Tensor& t) {  // elements per entry along dim 0
+  int64_t d = 1;
+  const auto shape = t.shape();
+  for (size_t i = 1; i < shape.size(); ++i) d *= shape[i];
+  return d;
+}
+// one small device -> host read (counts that size dynamic outputs)
+inline std::vector<int64_t> read_i64(const paddle::Tensor& t, int64_t first, int64_t n) {
+  auto host = paddle::experimental::slice(t, {0}, {first}, {first + n}, {}, {}).copy_to(paddle::CPUPlace(), true);
+  return std::vector<int64_t>(host.data<int64_t>(), host.data<int64_t>() + n);
+}
 }  // namespace
 
 // ---- sparse_cuda_version (csrc/version.cpp:14-40) ---------------------------
@@ -99,12 +128,14 @@ PD_BUILD_OP(index_sort)
     .SetInferDtypeFn(PD_INFER_DTYPE(index_sort_infer_dtype));
 
 // ---- spmm_{sum,mean,min,max}: new ops, same convention -------------------------------
-// `value` is optional in the Python API; Paddle's paddle::optional<Tensor>
-// input (anticipated by PD_DISPATCH_HAS_VALUE, csrc/cpu/utils.h:11-20) maps
-// to a NULL pointer in the C-ABI.
+// `value` and `row` are optional; Paddle's paddle::optional<Tensor> input
+// (anticipated by PD_DISPATCH_HAS_VALUE, csrc/cpu/utils.h:11-20) maps to a NULL
+// pointer in the C-ABI.  `row` = SparseStorage.row() when it is cached; `algo` =
+// psa_spmm_algo, chosen once per matrix from csr_row_stats below.
 static std::vector<paddle::Tensor> spmm_impl(int reduce, paddle::Tensor& rowptr, paddle::Tensor& col,
                                              const paddle::optional<paddle::Tensor>& value,
-                                             paddle::Tensor& mat) {
+                                             const paddle::optional<paddle::Tensor>& row, paddle::Tensor& mat,
+                                             int64_t algo, bool want_arg, bool want_arg_bytes) {
   CHECK_GPU(mat);
   CHECK_I64(rowptr);
   CHECK_I64(col);
@@ -112,32 +143,46 @@ static std::vector<paddle::Tensor> spmm_impl(int reduce, paddle::Tensor& rowptr,
   const int64_t M = rowptr.numel() - 1, N = mat.shape()[0], K = mat.shape()[1], nnz = col.numel();
   auto out = paddle::empty({M, K}, mat.dtype(), mat.place());
   const bool minmax = reduce == PSA_MIN || reduce == PSA_MAX;
-  auto arg = minmax ? paddle::empty({M, K}, paddle::DataType::INT64, mat.place())
-                    : paddle::empty({0}, paddle::DataType::INT64, mat.place());
-  // scratch of the long-row path (rows > 128 edges are reduced chunk-wise)
-  const int64_t ws_bytes = static_cast<int64_t>(psa_spmm_workspace_bytes(reduce, K, nnz));
-  auto ws = paddle::empty({ws_bytes > 0 ? ws_bytes : 1}, paddle::DataType::UINT8, mat.place());
-  PSA_CALL(psa_spmm(reduce, i64(rowptr), i64(col), value ? f32(value.get()) : nullptr, f32(mat), M, N,
-                    K, nnz, out.data<float>(), minmax ? arg.data<int64_t>() : nullptr,
-                    /*arg_bytes=*/nullptr, ws_bytes > 0 ? ws.data<uint8_t>() : nullptr,
-                    static_cast<size_t>(ws_bytes),
-                    stream_of(mat)));
-  return {out, arg};
+  auto arg = minmax && want_arg ? paddle::empty({M, K}, paddle::DataType::INT64, mat.place())
+                                : paddle::empty({0}, paddle::DataType::INT64, mat.place());
+  auto arg_bytes = minmax && want_arg_bytes ? paddle::empty({M, K}, paddle::DataType::UINT8, mat.place())
+                                            : paddle::empty({0}, paddle::DataType::UINT8, mat.place());
+  const size_t ws_bytes = psa_spmm_workspace_bytes(reduce, K, nnz);
+  auto ws = scratch(ws_bytes, mat.place());
+  PSA_CALL(psa_spmm_coo(reduce, i64(rowptr), i64_or_null(row), i64(col), f32_or_null(value), f32(mat), M, N, K, nnz,
+                        out.data<float>(), minmax && want_arg ? arg.data<int64_t>() : nullptr,
+                        minmax && want_arg_bytes ? arg_bytes.data<uint8_t>() : nullptr, static_cast<int>(algo),
+                        ws_bytes > 0 ? ws.data<uint8_t>() : nullptr, ws_bytes, stream_of(mat)));
+  return {out, arg, arg_bytes};
 }
 #define PSA_SPMM_OP(NAME, RED)                                                                \
   std::vector<paddle::Tensor> NAME(paddle::Tensor& rowptr, paddle::Tensor& col,                \
                                    const paddle::optional<paddle::Tensor>& value,             \
-                                   paddle::Tensor& mat) {                                     \
-    return spmm_impl(RED, rowptr, col, value, mat);                                           \
+                                   const paddle::optional<paddle::Tensor>& row,               \
+                                   paddle::Tensor& mat, int64_t algo, bool want_arg,          \
+                                   bool want_arg_bytes) {                                     \
+    return spmm_impl(RED, rowptr, col, value, row, mat, algo, want_arg, want_arg_bytes);      \
   }                                                                                           \
   PD_BUILD_OP(NAME)                                                                           \
-      .Inputs({"rowptr", "col", paddle::Optional("value"), "mat"})                            \
-      .Outputs({"out", "arg_out"})                                                            \
+      .Inputs({"rowptr", "col", paddle::Optional("value"), paddle::Optional("row"), "mat"})   \
+      .Outputs({"out", "arg_out", "arg_bytes"})                                               \
+      .Attrs({"algo: int64_t", "want_arg: bool", "want_arg_bytes: bool"})                     \
       .SetKernelFn(PD_KERNEL(NAME));
 PSA_SPMM_OP(spmm_sum, PSA_SUM)
 PSA_SPMM_OP(spmm_mean, PSA_MEAN)
 PSA_SPMM_OP(spmm_min, PSA_MIN)
 PSA_SPMM_OP(spmm_max, PSA_MAX)
+
+// {rows without entries, rows of 1-2 entries, rows above 128 entries, longest row}: read once per
+// matrix by the Python layer to pick `algo` (paddle_sparse_amd/storage.py::_spmm_algo).
+std::vector<paddle::Tensor> csr_row_stats(paddle::Tensor& rowptr) {
+  CHECK_GPU(rowptr);
+  CHECK_I64(rowptr);
+  auto stats = i64_empty(4, rowptr.place());
+  PSA_CALL(psa_csr_row_stats(i64(rowptr), rowptr.numel() - 1, stats.data<int64_t>(), stream_of(rowptr)));
+  return {stats};
+}
+PD_BUILD_OP(csr_row_stats).Inputs({"rowptr"}).Outputs({"stats"}).SetKernelFn(PD_KERNEL(csr_row_stats));
 
 // grad wrt the values (upstream spmm_value_bw); grad wrt mat is spmm_sum over
 // the CSC view and is composed in Python (paddle_sparse/matmul.py PyLayer),
@@ -160,20 +205,280 @@ PD_BUILD_OP(spmm_value_bw)
     .Attrs({"mean: bool"})
     .SetKernelFn(PD_KERNEL(spmm_value_bw));
 
+// CSC-ordered edge weights of grad_mat = A^T grad_out (upstream torch_sparse/matmul.py backward)
+std::vector<paddle::Tensor> transpose_weights(const paddle::optional<paddle::Tensor>& value, paddle::Tensor& csr2csc,
+                                              const paddle::optional<paddle::Tensor>& row_csc,
+                                              const paddle::optional<paddle::Tensor>& rowptr, bool mean) {
+  CHECK_GPU(csr2csc);
+  CHECK_I64(csr2csc);
+  const int64_t nnz = csr2csc.numel();
+  auto out = paddle::empty({nnz}, paddle::DataType::FLOAT32, csr2csc.place());
+  PSA_CALL(psa_transpose_weights(f32_or_null(value), i64(csr2csc), i64_or_null(row_csc), i64_or_null(rowptr), nnz,
+                                 mean ? 1 : 0, out.data<float>(), stream_of(csr2csc)));
+  return {out};
+}
+PD_BUILD_OP(transpose_weights)
+    .Inputs({paddle::Optional("value"), "csr2csc", paddle::Optional("row_csc"), paddle::Optional("rowptr")})
+    .Outputs({"out"})
+    .Attrs({"mean: bool"})
+    .SetKernelFn(PD_KERNEL(transpose_weights));
+
+// min/max backward through arg_out with float atomics (any K)
+std::vector<paddle::Tensor> spmm_minmax_bw(paddle::Tensor& col, const paddle::optional<paddle::Tensor>& value,
+                                           paddle::Tensor& mat, paddle::Tensor& grad, paddle::Tensor& arg_out,
+                                           bool want_value, bool want_mat) {
+  CHECK_GPU(mat);
+  CHECK_I64(col);
+  CHECK_I64(arg_out);
+  const int64_t N = mat.shape()[0], K = mat.shape()[1], M = grad.shape()[0], nnz = col.numel();
+  auto gv = paddle::empty({want_value ? nnz : 0}, mat.dtype(), mat.place());
+  auto gm = want_mat ? paddle::empty({N, K}, mat.dtype(), mat.place()) : paddle::empty({0}, mat.dtype(), mat.place());
+  PSA_CALL(psa_spmm_minmax_bw(i64(col), f32_or_null(value), f32(mat), f32(grad), i64(arg_out), M, N, K, nnz,
+                              want_value ? gv.data<float>() : nullptr, want_mat ? gm.data<float>() : nullptr,
+                              stream_of(mat)));
+  return {gv, gm};
+}
+PD_BUILD_OP(spmm_minmax_bw)
+    .Inputs({"col", paddle::Optional("value"), "mat", "grad", "arg_out"})
+    .Outputs({"grad_value", "grad_mat"})
+    .Attrs({"want_value: bool", "want_mat: bool"})
+    .SetKernelFn(PD_KERNEL(spmm_minmax_bw));
+
+// position of every CSC-ordered edge inside its CSR row (structure only: cache it with csr2csc)
+std::vector<paddle::Tensor> csc_edge_tags(paddle::Tensor& rowptr, paddle::Tensor& row_csc, paddle::Tensor& csr2csc) {
+  CHECK_GPU(csr2csc);
+  CHECK_I64(rowptr);
+  CHECK_I64(row_csc);
+  CHECK_I64(csr2csc);
+  const int64_t nnz = csr2csc.numel();
+  auto tag = paddle::empty({nnz}, paddle::DataType::UINT8, csr2csc.place());
+  PSA_CALL(psa_csc_edge_tags(i64(rowptr), i64(row_csc), i64(csr2csc), nnz, tag.data<uint8_t>(), stream_of(csr2csc)));
+  return {tag};
+}
+PD_BUILD_OP(csc_edge_tags).Inputs({"rowptr", "row_csc", "csr2csc"}).Outputs({"tag"}).SetKernelFn(PD_KERNEL(csc_edge_tags));
+
+// min/max backward, both gradients in one pass over the CSC view, no atomics; grad_value comes back
+// in CSR order (the pass writes CSC order, one gather through csc2csr follows)
+std::vector<paddle::Tensor> spmm_minmax_bw_csc(paddle::Tensor& rowptr, paddle::Tensor& colptr, paddle::Tensor& row_csc,
+                                               paddle::Tensor& csr2csc, paddle::Tensor& csc2csr, paddle::Tensor& tag,
+                                               const paddle::optional<paddle::Tensor>& value, paddle::Tensor& mat,
+                                               paddle::Tensor& grad, const paddle::optional<paddle::Tensor>& arg_out,
+                                               const paddle::optional<paddle::Tensor>& arg_bytes, bool want_value) {
+  CHECK_GPU(grad);
+  const int64_t M = grad.shape()[0], K = grad.shape()[1], N = colptr.numel() - 1, nnz = csr2csc.numel();
+  const auto place = grad.place();
+  auto gv_csc = paddle::empty({want_value ? nnz : 0}, grad.dtype(), place);
+  auto gv = paddle::empty({want_value ? nnz : 0}, grad.dtype(), place);
+  auto gm = paddle::empty({N, K}, grad.dtype(), place);
+  const size_t ws_bytes = psa_spmm_minmax_bw_csc_workspace_bytes(M, K, nnz);
+  auto ws = scratch(ws_bytes, place);
+  PSA_CALL(psa_spmm_minmax_bw_csc(i64(rowptr), i64(colptr), i64(row_csc), i64(csr2csc), tag.data<uint8_t>(),
+                                  f32_or_null(value), want_value ? f32(mat) : nullptr, f32(grad), i64_or_null(arg_out),
+                                  arg_bytes ? arg_bytes.get().data<uint8_t>() : nullptr, M, N, K, nnz,
+                                  want_value ? gv_csc.data<float>() : nullptr, gm.data<float>(), ws.data<uint8_t>(),
+                                  ws_bytes, stream_of(grad)));
+  if (want_value) PSA_CALL(psa_gather_rows(gv_csc.data<float>(), i64(csc2csr), nnz, 4, gv.data<float>(), stream_of(grad)));
+  return {gv, gm};
+}
+PD_BUILD_OP(spmm_minmax_bw_csc)
+    .Inputs({"rowptr", "colptr", "row_csc", "csr2csc", "csc2csr", "tag", paddle::Optional("value"), "mat", "grad",
+             paddle::Optional("arg_out"), paddle::Optional("arg_bytes")})
+    .Outputs({"grad_value", "grad_mat"})
+    .Attrs({"want_value: bool"})
+    .SetKernelFn(PD_KERNEL(spmm_minmax_bw_csc));
+
+// sum / mean backward, both gradients in one pass over the CSC view (trainable edge values)
+std::vector<paddle::Tensor> spmm_sum_bw_csc(paddle::Tensor& colptr, paddle::Tensor& row_csc, paddle::Tensor& csr2csc,
+                                            paddle::Tensor& csc2csr, const paddle::optional<paddle::Tensor>& value,
+                                            const paddle::optional<paddle::Tensor>& row_scale, paddle::Tensor& mat,
+                                            paddle::Tensor& grad, bool want_value) {
+  CHECK_GPU(grad);
+  const int64_t K = grad.shape()[1], N = colptr.numel() - 1, nnz = csr2csc.numel();
+  const auto place = grad.place();
+  auto gv_csc = paddle::empty({want_value ? nnz : 0}, grad.dtype(), place);
+  auto gv = paddle::empty({want_value ? nnz : 0}, grad.dtype(), place);
+  auto gm = paddle::empty({N, K}, grad.dtype(), place);
+  const size_t ws_bytes = psa_spmm_sum_bw_csc_workspace_bytes(K, nnz);
+  auto ws = scratch(ws_bytes, place);
+  PSA_CALL(psa_spmm_sum_bw_csc(i64(colptr), i64(row_csc), i64(csr2csc), f32_or_null(value), f32_or_null(row_scale),
+                               want_value ? f32(mat) : nullptr, f32(grad), N, K, nnz,
+                               want_value ? gv_csc.data<float>() : nullptr, gm.data<float>(), ws.data<uint8_t>(),
+                               ws_bytes, stream_of(grad)));
+  if (want_value) PSA_CALL(psa_gather_rows(gv_csc.data<float>(), i64(csc2csr), nnz, 4, gv.data<float>(), stream_of(grad)));
+  return {gv, gm};
+}
+PD_BUILD_OP(spmm_sum_bw_csc)
+    .Inputs({"colptr", "row_csc", "csr2csc", "csc2csr", paddle::Optional("value"), paddle::Optional("row_scale"), "mat",
+             "grad"})
+    .Outputs({"grad_value", "grad_mat"})
+    .Attrs({"want_value: bool"})
+    .SetKernelFn(PD_KERNEL(spmm_sum_bw_csc));
+
+// ---- the index-arithmetic seams of storage.py / tensor.py / reduce.py ------
+// bincount + count2ptr: colcount / colptr (storage.py:397-398, 414-418)
+std::vector<paddle::Tensor> bincount(paddle::Tensor& index, int64_t size) {
+  CHECK_GPU(index);
+  CHECK_I64(index);
+  auto out = i64_empty(size, index.place());
+  PSA_CALL(psa_bincount(i64(index), index.numel(), size, out.data<int64_t>(), stream_of(index)));
+  return {out};
+}
+PD_BUILD_OP(bincount).Inputs({"index"}).Outputs({"out"}).Attrs({"size: int64_t"}).SetKernelFn(PD_KERNEL(bincount));
+
+std::vector<paddle::Tensor> count2ptr(paddle::Tensor& counts) {
+  CHECK_GPU(counts);
+  CHECK_I64(counts);
+  const int64_t n = counts.numel();
+  auto out = i64_empty(n + 1, counts.place());
+  const size_t ws_bytes = psa_count2ptr_workspace_bytes(n);
+  auto ws = scratch(ws_bytes, counts.place());
+  PSA_CALL(psa_count2ptr(i64(counts), n, out.data<int64_t>(), ws.data<uint8_t>(), ws_bytes, stream_of(counts)));
+  return {out};
+}
+PD_BUILD_OP(count2ptr).Inputs({"counts"}).Outputs({"out"}).SetKernelFn(PD_KERNEL(count2ptr));
+
+// invert_permutation: csc2csr without the second sort (storage.py:444-445)
+std::vector<paddle::Tensor> invert_permutation(paddle::Tensor& perm) {
+  CHECK_GPU(perm);
+  CHECK_I64(perm);
+  auto inv = i64_empty(perm.numel(), perm.place());
+  PSA_CALL(psa_invert_permutation(i64(perm), perm.numel(), inv.data<int64_t>(), stream_of(perm)));
+  return {inv};
+}
+PD_BUILD_OP(invert_permutation).Inputs({"perm"}).Outputs({"inv"}).SetKernelFn(PD_KERNEL(invert_permutation));
+
+// make_keys / split_keys: row * N + col and back (storage.py:159-163, 166-168)
+std::vector<paddle::Tensor> make_keys(paddle::Tensor& a, paddle::Tensor& b, int64_t mul) {
+  CHECK_GPU(a);
+  CHECK_I64(a);
+  CHECK_I64(b);
+  auto keys = i64_empty(a.numel(), a.place());
+  auto unsorted = paddle::zeros({1}, paddle::DataType::INT32, a.place());
+  PSA_CALL(psa_make_keys(i64(a), i64(b), mul, a.numel(), keys.data<int64_t>(), unsorted.data<int32_t>(), stream_of(a)));
+  return {keys, unsorted};
+}
+PD_BUILD_OP(make_keys).Inputs({"a", "b"}).Outputs({"keys", "unsorted"}).Attrs({"mul: int64_t"}).SetKernelFn(PD_KERNEL(make_keys));
+
+std::vector<paddle::Tensor> make_keys_checked(paddle::Tensor& row, paddle::Tensor& col, int64_t M, int64_t N) {
+  CHECK_GPU(row);
+  CHECK_I64(row);
+  CHECK_I64(col);
+  auto keys = i64_empty(row.numel(), row.place());
+  auto status = i64_empty(4, row.place());
+  PSA_CALL(psa_make_keys_checked(i64(row), i64(col), row.numel(), M, N, keys.data<int64_t>(), status.data<int64_t>(),
+                                 stream_of(row)));
+  return {keys, status};
+}
+PD_BUILD_OP(make_keys_checked)
+    .Inputs({"row", "col"})
+    .Outputs({"keys", "status"})
+    .Attrs({"M: int64_t", "N: int64_t"})
+    .SetKernelFn(PD_KERNEL(make_keys_checked));
+
+std::vector<paddle::Tensor> split_keys(paddle::Tensor& keys, int64_t div) {
+  CHECK_GPU(keys);
+  CHECK_I64(keys);
+  auto hi = i64_empty(keys.numel(), keys.place()), lo = i64_empty(keys.numel(), keys.place());
+  PSA_CALL(psa_split_keys(i64(keys), keys.numel(), div, hi.data<int64_t>(), lo.data<int64_t>(), stream_of(keys)));
+  return {hi, lo};
+}
+PD_BUILD_OP(split_keys).Inputs({"keys"}).Outputs({"hi", "lo"}).Attrs({"div: int64_t"}).SetKernelFn(PD_KERNEL(split_keys));
+
+// sort_pairs: the stable sort carrying a 4-byte value instead of the permutation (storage.py:164-169)
+std::vector<paddle::Tensor> sort_pairs(paddle::Tensor& keys, paddle::Tensor& payload, int64_t max_value) {
+  CHECK_GPU(keys);
+  CHECK_I64(keys);
+  const int64_t n = keys.numel();
+  auto sorted = i64_empty(n, keys.place());
+  auto out = paddle::empty({n}, payload.dtype(), keys.place());
+  const size_t ws_bytes = psa_index_sort_workspace_bytes(n, max_value);
+  auto ws = scratch(ws_bytes, keys.place());
+  PSA_CALL(psa_sort_pairs_u32(i64(keys), payload.data(), n, max_value, sorted.data<int64_t>(), out.data(),
+                              ws.data<uint8_t>(), ws_bytes, stream_of(keys)));
+  return {sorted, out};
+}
+PD_BUILD_OP(sort_pairs)
+    .Inputs({"keys", "payload"})
+    .Outputs({"sorted", "payload_out"})
+    .Attrs({"max_value: int64_t"})
+    .SetKernelFn(PD_KERNEL(sort_pairs));
+
+// gather_rows: x[perm] along dim 0 (storage.py:166-169, transpose.py:14-22, tensor.py:252-257)
+std::vector<paddle::Tensor> gather_rows(paddle::Tensor& src, paddle::Tensor& perm) {
+  CHECK_GPU(src);
+  CHECK_I64(perm);
+  auto shape = src.shape();
+  const int64_t n = perm.numel();
+  const int64_t row_bytes = row_elems(src) * static_cast<int64_t>(paddle::SizeOf(src.dtype()));
+  shape[0] = n;
+  auto out = paddle::empty(shape, src.dtype(), src.place());
+  PSA_CALL(psa_gather_rows(src.data(), i64(perm), n, row_bytes, out.data(), stream_of(src)));
+  return {out};
+}
+PD_BUILD_OP(gather_rows).Inputs({"src", "perm"}).Outputs({"out"}).SetKernelFn(PD_KERNEL(gather_rows));
+
+// merge_sorted: the cat + argsort of add.py:30-47 / mul.py:57-73 / tensor.py:415-451 on two sorted halves
+std::vector<paddle::Tensor> merge_sorted(paddle::Tensor& a, paddle::Tensor& b) {
+  CHECK_GPU(a);
+  CHECK_I64(a);
+  CHECK_I64(b);
+  const int64_t na = a.numel(), nb = b.numel();
+  auto merged = i64_empty(na + nb, a.place()), source = i64_empty(na + nb, a.place());
+  PSA_CALL(psa_merge_sorted(i64(a), na, i64(b), nb, nullptr, nullptr, merged.data<int64_t>(), source.data<int64_t>(),
+                            nullptr, stream_of(a)));
+  return {merged, source};
+}
+PD_BUILD_OP(merge_sorted).Inputs({"a", "b"}).Outputs({"merged", "source"}).SetKernelFn(PD_KERNEL(merge_sorted));
+
+// unique_sorted: head flags / row[mask] / col[mask] / ptr of storage.py:455-470 (one host read: the count)
+std::vector<paddle::Tensor> unique_sorted(paddle::Tensor& sorted_keys, int64_t N) {
+  CHECK_GPU(sorted_keys);
+  CHECK_I64(sorted_keys);
+  const int64_t n = sorted_keys.numel();
+  const auto place = sorted_keys.place();
+  void* s = stream_of(sorted_keys);
+  const size_t ws_bytes = psa_unique_workspace_bytes(n);
+  auto ws = scratch(ws_bytes, place);
+  auto count = i64_empty(1, place);
+  PSA_CALL(psa_unique_count(i64(sorted_keys), n, ws.data<uint8_t>(), ws_bytes, count.data<int64_t>(), s));
+  const int64_t distinct = read_i64(count, 0, 1)[0];
+  auto ptr = i64_empty(distinct + 1, place);
+  auto index = paddle::empty({2, distinct}, paddle::DataType::INT64, place);
+  if (n > 0)
+    PSA_CALL(psa_unique_write(i64(sorted_keys), n, N, ws.data<uint8_t>(), i64(count), ptr.data<int64_t>(),
+                              index.data<int64_t>(), index.data<int64_t>() + distinct, s));
+  return {ptr, index};
+}
+PD_BUILD_OP(unique_sorted)
+    .Inputs({"sorted_keys"})
+    .Outputs({"ptr", "index"})
+    .Attrs({"N: int64_t"})
+    .SetKernelFn(PD_KERNEL(unique_sorted));
+
+// scatter: paddle_scatter.scatter(src, index, 0, None, dim_size, reduce) of reduce.py:42
+std::vector<paddle::Tensor> scatter(paddle::Tensor& src, paddle::Tensor& index, int64_t dim_size, int64_t reduce) {
+  CHECK_GPU(src);
+  CHECK_I64(index);
+  auto shape = src.shape();
+  shape[0] = dim_size;
+  auto out = paddle::empty(shape, src.dtype(), src.place());
+  const size_t ws_bytes = psa_scatter_workspace_bytes(dim_size);
+  auto ws = scratch(ws_bytes, src.place());
+  PSA_CALL(psa_scatter_reduce(static_cast<int>(reduce), dtype_id_of(src), src.data(), i64(index), index.numel(),
+                              row_elems(src), dim_size, out.data(), ws.data<uint8_t>(), ws_bytes, stream_of(src)));
+  return {out};
+}
+PD_BUILD_OP(scatter)
+    .Inputs({"src", "index"})
+    .Outputs({"out"})
+    .Attrs({"dim_size: int64_t", "reduce: int64_t"})
+    .SetKernelFn(PD_KERNEL(scatter));
+
 // ---- segment_csr with an optional gather permutation (storage.py:471) -----------------
 std::vector<paddle::Tensor> segment_csr_perm(paddle::Tensor& src, paddle::Tensor& ptr,
                                              const paddle::optional<paddle::Tensor>& perm, int64_t reduce) {
   CHECK_GPU(src);
-  int dtype = -1;
-  switch (src.dtype()) {
-    case paddle::DataType::FLOAT32: dtype = PSA_F32; break;
-    case paddle::DataType::FLOAT64: dtype = PSA_F64; break;
-    case paddle::DataType::INT32: dtype = PSA_I32; break;
-    case paddle::DataType::INT64: dtype = PSA_I64; break;
-    case paddle::DataType::FLOAT16: dtype = PSA_F16; break;
-    case paddle::DataType::BFLOAT16: dtype = PSA_BF16; break;
-    default: PD_THROW("segment_csr: unsupported dtype");
-  }
+  const int dtype = dtype_id_of(src);
   auto shape = src.shape();
   const int64_t nseg = ptr.numel() - 1;
   int64_t D = 1;
@@ -266,10 +571,10 @@ PD_BUILD_OP(sample_adj)
     .SetInferDtypeFn(PD_INFER_DTYPE(sample_adj_infer_dtype));
 
 // ---- coalesce as ONE op (seam: paddle_sparse/coalesce.py:25-29) ----------------------
-// The Python layer of this repository composes the chain call by call (and pays
-// ~10 us of interpreter per call); inside a custom op the same chain is plain
-// C++.  index int64[2, nnz] + optional value [nnz, ...] -> coalesced pair.
-// `reduce`: psa_reduce.  One device -> host read (the number of distinct entries).
+// psa_coalesce_count -> one host read (count + flags) -> psa_coalesce_write; the same two
+// calls paddle_sparse_amd/coalesce.py makes.  index int64[2, nnz] + optional value
+// [nnz, ...] -> coalesced pair.  `reduce`: psa_reduce.  transpose(index, value, m, n) of
+// transpose.py:41-65 is this op on the swapped index rows with (n, m).
 std::vector<paddle::Tensor> coalesce(paddle::Tensor& index, const paddle::optional<paddle::Tensor>& value,
                                      int64_t m, int64_t n, int64_t reduce) {
   CHECK_GPU(index);
@@ -278,44 +583,26 @@ std::vector<paddle::Tensor> coalesce(paddle::Tensor& index, const paddle::option
   const int64_t nnz = index.shape()[1];
   void* s = stream_of(index);
   const auto place = index.place();
-  auto i64_empty = [&](std::vector<int64_t> shape) { return paddle::empty(shape, paddle::DataType::INT64, place); };
-  auto bytes = [&](size_t b) { return paddle::empty({static_cast<int64_t>(b > 0 ? b : 1)}, paddle::DataType::UINT8, place); };
-  const int64_t* row = i64(index);            // index is contiguous [2, nnz]: row, then col
+  const int64_t* row = i64(index);  // index is contiguous [2, nnz]: row, then col
   const int64_t* col = i64(index) + nnz;
   if (nnz == 0) return {index, value ? value.get() : paddle::empty({0}, paddle::DataType::FLOAT32, place)};
-
-  auto keys = i64_empty({nnz}), sorted = i64_empty({nnz}), perm = i64_empty({nnz}), count = i64_empty({1});
-  PSA_CALL(psa_make_keys(row, col, n, nnz, keys.data<int64_t>(), nullptr, s));
-  auto sort_ws = bytes(psa_index_sort_workspace_bytes(nnz, m * n));
-  PSA_CALL(psa_index_sort(i64(keys), nnz, m * n, sorted.data<int64_t>(), perm.data<int64_t>(),
-                          sort_ws.data<uint8_t>(), psa_index_sort_workspace_bytes(nnz, m * n), s));
-  auto uniq_ws = bytes(psa_unique_workspace_bytes(nnz));
-  PSA_CALL(psa_unique_count(i64(sorted), nnz, uniq_ws.data<uint8_t>(), psa_unique_workspace_bytes(nnz),
-                            count.data<int64_t>(), s));
-  const int64_t distinct = count.copy_to(paddle::CPUPlace(), true).data<int64_t>()[0];
-  auto out_index = i64_empty({2, distinct});
-  auto ptr = i64_empty({distinct + 1});
-  PSA_CALL(psa_unique_write(i64(sorted), nnz, n, uniq_ws.data<uint8_t>(), i64(count), ptr.data<int64_t>(),
-                            out_index.data<int64_t>(), out_index.data<int64_t>() + distinct, s));
-  if (!value) return {out_index, paddle::empty({0}, paddle::DataType::FLOAT32, place)};
-  const paddle::Tensor& v = value.get();
-  int dtype = -1;
-  switch (v.dtype()) {
-    case paddle::DataType::FLOAT32: dtype = PSA_F32; break;
-    case paddle::DataType::FLOAT64: dtype = PSA_F64; break;
-    case paddle::DataType::INT32: dtype = PSA_I32; break;
-    case paddle::DataType::INT64: dtype = PSA_I64; break;
-    case paddle::DataType::FLOAT16: dtype = PSA_F16; break;
-    case paddle::DataType::BFLOAT16: dtype = PSA_BF16; break;
-    default: PD_THROW("coalesce: unsupported value dtype");
-  }
-  auto shape = v.shape();
-  int64_t D = 1;
-  for (size_t i = 1; i < shape.size(); ++i) D *= shape[i];
-  shape[0] = distinct;
-  auto out_value = paddle::empty(shape, v.dtype(), place);
-  PSA_CALL(psa_segment_reduce(static_cast<int>(reduce), dtype, v.data(), i64(perm), i64(ptr), distinct, D, nnz,
-                              out_value.data(), s));
+  const int dtype = value ? dtype_id_of(value.get()) : 0;
+  const int64_t D = value ? row_elems(value.get()) : 0;
+  const void* v = value ? value.get().data() : nullptr;
+  const size_t ws_bytes = psa_coalesce_workspace_bytes(nnz, m, n);
+  auto ws = scratch(ws_bytes, place);
+  PSA_CALL(psa_coalesce_count(row, col, v, dtype, D, nnz, m, n, ws.data<uint8_t>(), ws_bytes, s));
+  // the status words {count, flags} are the first 16 bytes of the workspace: the one host read
+  auto status_words = paddle::experimental::slice(ws, {0}, {0}, {16}, {}, {}).copy_to(paddle::CPUPlace(), true);
+  const int64_t distinct = reinterpret_cast<const int64_t*>(status_words.data<uint8_t>())[0];
+  const int64_t flags = reinterpret_cast<const int64_t*>(status_words.data<uint8_t>())[1];
+  PD_CHECK(!(flags & 1), "coalesce: an index lies outside the m x n matrix");  // storage.py:78-91 asserts it
+  auto out_index = paddle::empty({2, distinct}, paddle::DataType::INT64, place);
+  auto shape = value ? value.get().shape() : std::vector<int64_t>{0};
+  shape[0] = value ? distinct : 0;
+  auto out_value = paddle::empty(shape, value ? value.get().dtype() : paddle::DataType::FLOAT32, place);
+  PSA_CALL(psa_coalesce_write(v, dtype, D, nnz, m, n, static_cast<int>(reduce), distinct, ws.data<uint8_t>(),
+                              out_index.data<int64_t>(), value ? out_value.data() : nullptr, s));
   return {out_index, out_value};
 }
 PD_BUILD_OP(coalesce)

@@ -13,6 +13,8 @@
 //     (LPR lanes x float4 cover the K-tile; 64/LPR edges share a wave
 //     instruction), several of them in flight before the first use;
 //   * partial sums of the 64/LPR edge slots are folded with wave shuffles.
+#include <type_traits>
+
 #include "common.h"
 #include "long_rows.h"
 #include "spmm_eb.h"
@@ -966,24 +968,25 @@ int launch_fused(int red, const int64_t* rowptr, const int64_t* col, const float
   // not track the winners' edge ids (the combine still folds chunk partials by
   // value; ids it reads there only break ties between equal values)
   const bool no_arg = red != R_SUM && arg_out == nullptr && arg_bytes == nullptr && g_variant != 19;
-#define PSA_FUSED(R)                                                                          \
-  do {                                                                                        \
-    if (R != R_SUM && no_arg)                                                                 \
-      hipLaunchKernelGGL((spmm_fused_kernel<VEC, LPR, R, U, (R == R_SUM ? M_PLAIN : M_NOARG)>), grid, block, 0, s, \
-                         rowptr, col, val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list, \
-                         w.part_val, w.part_arg, plain);                                      \
-    else                                                                                      \
-    hipLaunchKernelGGL((spmm_fused_kernel<VEC, LPR, R, U>), grid, block, 0, s, rowptr, col,   \
-                       val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list, w.part_val,    \
-                       w.part_arg, plain);                                                    \
-    hipLaunchKernelGGL((spmm_long_combine_kernel<R>), cgrid, cblock, 0, s, rowptr, K, mean,   \
-                       w.ctr, w.list, w.part_val, w.part_arg, out, arg_out,                   \
-                       plain.arg_bytes_out);                                                  \
-  } while (0)
-  if (red == R_SUM) PSA_FUSED(R_SUM);
-  else if (red == R_MIN) PSA_FUSED(R_MIN);
-  else PSA_FUSED(R_MAX);
-#undef PSA_FUSED
+  auto launch = [&](auto red_tag) {
+    constexpr int R = decltype(red_tag)::value;
+    bool done = false;
+    if constexpr (R != R_SUM) {
+      if (no_arg) {
+        hipLaunchKernelGGL((spmm_fused_kernel<VEC, LPR, R, U, M_NOARG>), grid, block, 0, s, rowptr, col, val, mat, out,
+                           arg_out, M, K, nnz, mean, w.ctr, w.list, w.part_val, w.part_arg, plain);
+        done = true;
+      }
+    }
+    if (!done)
+      hipLaunchKernelGGL((spmm_fused_kernel<VEC, LPR, R, U>), grid, block, 0, s, rowptr, col, val, mat, out, arg_out, M,
+                         K, nnz, mean, w.ctr, w.list, w.part_val, w.part_arg, plain);
+    hipLaunchKernelGGL((spmm_long_combine_kernel<R>), cgrid, cblock, 0, s, rowptr, K, mean, w.ctr, w.list, w.part_val,
+                       w.part_arg, out, arg_out, plain.arg_bytes_out);
+  };
+  if (red == R_SUM) launch(std::integral_constant<int, R_SUM>{});
+  else if (red == R_MIN) launch(std::integral_constant<int, R_MIN>{});
+  else launch(std::integral_constant<int, R_MAX>{});
   PSA_LAUNCH_CHECK();
   return PSA_OK;
 }

@@ -36,6 +36,99 @@ def test_binding_table_matches_header():
     _lib.load()  # sets restype/argtypes for every symbol
 
 
+# ---- the Paddle custom-op shim (integration/paddle_shim) against the header ----------------------
+SHIM = ROOT / "integration" / "paddle_shim" / "paddle_sparse_hip_ops.cc"
+INTEGRATION = ROOT / "INTEGRATION.md"
+
+
+def _strip_comments(text):
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return re.sub(r"//[^\n]*", "", text)
+
+
+def _top_level_args(text, open_paren):
+    """Number of top-level arguments of the call whose '(' is at open_paren."""
+    depth, args, i, seen = 0, 1, open_paren, False
+    while True:
+        c = text[i]
+        if c in "([{":
+            depth += 1
+        elif c in ")]}":
+            depth -= 1
+            if depth == 0:
+                return args if seen else 0
+        elif c == "," and depth == 1:
+            args += 1
+        elif depth >= 1 and not c.isspace():
+            seen = True
+        i += 1
+
+
+def header_arity():
+    text = _strip_comments(HEADER.read_text())
+    out = {}
+    for m in re.finditer(r"\b(psa_[a-z0-9_]+)\s*\(", text):
+        n = _top_level_args(text, m.end() - 1)
+        inner = text[m.end():text.index(")", m.end())].strip()
+        out[m.group(1)] = 0 if inner == "void" else n
+    return out
+
+
+def test_shim_calls_match_the_header_arity():
+    arity = header_arity()
+    text = _strip_comments(SHIM.read_text())
+    calls = [(m.group(1), _top_level_args(text, m.end() - 1)) for m in re.finditer(r"\b(psa_[a-z0-9_]+)\s*\(", text)]
+    assert len(calls) > 40
+    for name, n in calls:
+        assert name in arity, f"shim calls {name}, which the header does not declare"
+        assert n == arity[name], f"{name}: shim passes {n} arguments, header declares {arity[name]}"
+
+
+def shim_ops():
+    return set(re.findall(r"PD_BUILD_OP\((\w+)\)", SHIM.read_text())) | {"spmm_sum", "spmm_mean", "spmm_min", "spmm_max"}
+
+
+def test_every_seam_of_integration_md_has_an_op():
+    """INTEGRATION.md section 2 tells a maintainer which paddle_sparse_ops.<op> to call at
+    every seam; each of them must be registered by the shim."""
+    text = INTEGRATION.read_text()
+    seam = text[text.index("| file:line | today | with the HIP ops |"):text.index("`paddle_sparse_amd/` in this repository is that host layer")]
+    named = set(re.findall(r"`(?:paddle_sparse_ops\.)?([a-z_0-9]+)(?:\([^`]*\))?`", seam))
+    ops = shim_ops()
+    wanted = {n for n in named if n in ops or n in {
+        "index_sort", "make_keys", "make_keys_checked", "sort_pairs", "split_keys", "bincount", "count2ptr",
+        "invert_permutation", "unique_sorted", "segment_csr_perm", "scatter", "ind2ptr", "gather_rows", "merge_sorted",
+        "coalesce", "csr_row_stats", "transpose_weights", "spmm_value_bw", "spmm_sum_bw_csc", "spmm_minmax_bw_csc",
+        "spmm_minmax_bw", "csc_edge_tags", "sample_adj"}}
+    assert len(wanted) >= 20, sorted(wanted)
+    assert not (wanted - ops), f"named in INTEGRATION.md but not registered: {sorted(wanted - ops)}"
+
+
+def test_every_entry_point_is_bound_or_listed_as_unbound():
+    """Each C-ABI function is either called by the shim or named in INTEGRATION.md's
+    'not bound by the shim' list with the reason."""
+    text = INTEGRATION.read_text()
+    unbound = text[text.index("**Not bound by the shim**"):]
+    unbound = unbound[:unbound.index("\n\n")]
+    called = set(re.findall(r"\b(psa_[a-z0-9_]+)\s*\(", _strip_comments(SHIM.read_text())))
+    for name in declared_functions():
+        assert name in called or f"`{name}`" in unbound, f"{name} is neither bound nor listed as unbound"
+
+
+def test_shim_type_checks():
+    """g++ -fsyntax-only of the shim against include/paddle_sparse_hip.h and the test-only
+    stub of the custom-op API (tests/paddle_stub): pointer types, argument order, arity."""
+    import shutil
+    import subprocess
+
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    res = subprocess.run([gxx, "-std=c++17", "-fsyntax-only", "-Wall", f"-I{ROOT / 'tests' / 'paddle_stub'}",
+                          f"-I{ROOT / 'include'}", str(SHIM)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
+
+
 def test_version_probes_without_gpu():
     from paddle_sparse_amd import _lib, ops
 
