@@ -16,6 +16,9 @@ on Paddle ops + paddle_scatter, neither importable here):
   reduction() .......... /root/reference/paddle_sparse/reduce.py:12-71
   to_symmetric() ....... /root/reference/paddle_sparse/tensor.py:415-451
   add() / mul() ........ /root/reference/paddle_sparse/add.py:30-47, mul.py:35-73
+  index_select / masked_select / narrow (and the _nnz forms)
+                         /root/reference/paddle_sparse/index_select.py:13-101,
+                         masked_select.py:12-96, narrow.py:11-100
 
 Third-party arithmetic that is not under /root/reference:
   paddle_scatter.segment_csr / scatter / scatter_add (unpinned HEAD,
@@ -30,8 +33,13 @@ Third-party arithmetic that is not under /root/reference:
 Pinned by the reference's known answers (tests/golden/reference_kats.json,
 from test/test_storage.py, test/test_coalesce.py, test/test_transpose.py,
 test/test_tensor.py, test/test_eye.py, test/test_add.py, test/test_mul.py,
-README.md:204-264).  reduce(dim=0/1), mean/min coalesce: "parity unpinned"
-(test/test_reduce.py only covers dim=None).
+README.md:204-264).  reduce(dim=0/1), mean/min coalesce: no reference fixture
+(test/test_reduce.py only covers dim=None) — pinned instead by the third-party
+answers frozen in tests/golden/third_party.npz (numpy ufunc.at,
+torch.segment_reduce; tests/golden/make_golden.py).  The slicing functions:
+the reference's own tests are shape-only (test/test_tensor.py:16-68, in
+reference_kats.json as "getitem_shapes"); values are checked against dense
+numpy indexing of the same matrix.
 """
 from __future__ import annotations
 
@@ -266,3 +274,122 @@ def reduction(st: Storage, dim, reduce="sum", dtype=np.float32):
             return segment_csr_fast(value, st.rowptr(), reduce)
         return st.rowcount().astype(dtype) if reduce in ("sum", "add") else np.ones(st.M, dtype)
     raise ValueError(dim)
+
+
+# ---- slicing ------------------------------------------------------------
+# index_select.py:13-96, masked_select.py:12-90, narrow.py:11-100, restated op for op.
+# paddle_scatter.gather_csr(src, indptr) repeats src[j] over segment j (pytorch_scatter semantics).
+# Each function returns (Storage, caches): the caches the reference hands to the new
+# SparseStorage (rowptr / rowcount / colptr / colcount / csc2csr), None where it passes None.
+
+def _gather_csr(src: np.ndarray, indptr: np.ndarray) -> np.ndarray:
+    return np.repeat(src, np.diff(indptr))
+
+
+def index_select(st: Storage, dim: int, idx) -> tuple:
+    """index_select.py:13-80."""
+    idx = np.asarray(idx, dtype=np.int64)
+    ndim = 2 + (0 if st.value is None else st.value.ndim - 1)
+    dim = ndim + dim if dim < 0 else dim
+    if dim == 0:  # :17-44
+        old_rowptr = st.rowptr()
+        rowcount = st.rowcount()[idx]
+        rowptr = np.zeros(idx.size + 1, np.int64)
+        rowptr[1:] = np.cumsum(rowcount)
+        row = np.repeat(np.arange(idx.size, dtype=np.int64), rowcount)
+        perm = np.arange(row.size, dtype=np.int64) + _gather_csr(old_rowptr[idx] - rowptr[:-1], rowptr)
+        value = None if st.value is None else st.value[perm]
+        return (Storage(row, st.col[perm], value, (idx.size, st.N), is_sorted=True),
+                {"rowptr": rowptr, "rowcount": rowcount})
+    if dim == 1:  # :46-75
+        to_csc = st.csr2csc()
+        old_colptr, row_csc = st.colptr(), st.row[to_csc]
+        value_csc = None if st.value is None else st.value[to_csc]
+        colcount = st.colcount()[idx]
+        colptr = np.zeros(idx.size + 1, np.int64)
+        colptr[1:] = np.cumsum(colcount)
+        col = np.repeat(np.arange(idx.size, dtype=np.int64), colcount)
+        perm = np.arange(col.size, dtype=np.int64) + _gather_csr(old_colptr[idx] - colptr[:-1], colptr)
+        row = row_csc[perm]
+        csc2csr = index_sort(idx.size * row + col)
+        value = None if value_csc is None else value_csc[perm][csc2csr]
+        return (Storage(row[csc2csr], col[csc2csr], value, (st.M, idx.size), is_sorted=True),
+                {"colptr": colptr, "colcount": colcount, "csc2csr": csc2csr})
+    if st.value is None:  # :76-80
+        raise ValueError
+    return Storage(st.row, st.col, np.take(st.value, idx, axis=dim - 1), (st.M, st.N), is_sorted=True), {}
+
+
+def index_select_nnz(st: Storage, idx, layout=None) -> Storage:
+    """index_select.py:83-101."""
+    idx = np.asarray(idx, dtype=np.int64)
+    if layout == "csc":
+        idx = st.csc2csr()[idx]
+    value = None if st.value is None else st.value[idx]
+    return Storage(st.row[idx], st.col[idx], value, (st.M, st.N), is_sorted=True)
+
+
+def masked_select(st: Storage, dim: int, mask) -> tuple:
+    """masked_select.py:12-77."""
+    mask = np.asarray(mask, dtype=bool)
+    ndim = 2 + (0 if st.value is None else st.value.ndim - 1)
+    dim = ndim + dim if dim < 0 else dim
+    if dim == 0:  # :18-40
+        rowcount = st.rowcount()[mask]
+        emask = mask[st.row]
+        row = np.repeat(np.arange(rowcount.size, dtype=np.int64), rowcount)
+        value = None if st.value is None else st.value[emask]
+        return Storage(row, st.col[emask], value, (rowcount.size, st.N), is_sorted=True), {"rowcount": rowcount}
+    if dim == 1:  # :42-70
+        to_csc = st.csr2csc()
+        row, col = st.row[to_csc], st.col[to_csc]
+        colcount = st.colcount()[mask]
+        emask = mask[col]
+        col = np.repeat(np.arange(colcount.size, dtype=np.int64), colcount)
+        row = row[emask]
+        csc2csr = index_sort(colcount.size * row + col)
+        value = None if st.value is None else st.value[to_csc][emask][csc2csr]
+        return (Storage(row[csc2csr], col[csc2csr], value, (st.M, colcount.size), is_sorted=True),
+                {"colcount": colcount, "csc2csr": csc2csr})
+    if st.value is None:  # :71-77
+        raise ValueError
+    return Storage(st.row, st.col, np.take(st.value, np.nonzero(mask)[0], axis=dim - 1), (st.M, st.N), is_sorted=True), {}
+
+
+def masked_select_nnz(st: Storage, mask, layout=None) -> Storage:
+    """masked_select.py:80-96."""
+    mask = np.asarray(mask, dtype=bool)
+    if layout == "csc":
+        mask = mask[st.csc2csr()]
+    value = None if st.value is None else st.value[mask]
+    return Storage(st.row[mask], st.col[mask], value, (st.M, st.N), is_sorted=True)
+
+
+def narrow(st: Storage, dim: int, start: int, length: int) -> tuple:
+    """narrow.py:11-100."""
+    ndim = 2 + (0 if st.value is None else st.value.ndim - 1)
+    if dim < 0:
+        dim = ndim + dim
+    sizes = (st.M, st.N) + (() if st.value is None else st.value.shape[1:])
+    if start < 0:
+        start = sizes[dim] + start
+    if dim == 0:  # :17-50
+        rowptr = st.rowptr()[start:start + length + 1]
+        row_start = rowptr[0]
+        rowptr = rowptr - row_start
+        row_length = rowptr[-1]
+        sl = slice(row_start, row_start + row_length)
+        value = None if st.value is None else st.value[sl]
+        return (Storage(st.row[sl] - start, st.col[sl], value, (length, st.N), is_sorted=True),
+                {"rowptr": rowptr, "rowcount": st.rowcount()[start:start + length]})
+    if dim == 1:  # :52-87
+        mask = (st.col >= start) & (st.col < start + length)
+        value = None if st.value is None else st.value[mask]
+        colptr = st.colptr()[start:start + length + 1]
+        return (Storage(st.row[mask], st.col[mask] - start, value, (st.M, length), is_sorted=True),
+                {"colptr": colptr - colptr[0], "colcount": st.colcount()[start:start + length]})
+    if st.value is None:  # :88-96
+        raise ValueError
+    sl = [slice(None)] * st.value.ndim
+    sl[dim - 1] = slice(start, start + length)
+    return Storage(st.row, st.col, st.value[tuple(sl)], (st.M, st.N), is_sorted=True), {}

@@ -29,7 +29,7 @@ def _coalesce_sorted_stream(row, col, value, m: int, n: int, op: str):
     if nnz == 0:
         return row, col, value
     if (nnz <= _CHAIN_BELOW and m > 0 and n > 0 and m * n < (1 << 62)
-            and (value is None or value.dtype in ops._DTYPE_ID)):
+            and (value is None or value.dtype in ops._DTYPE_ID) and not ops.needs_grad(value)):
         # psa_coalesce_count + psa_coalesce_write on worst-case buffers, one host read at the end
         index, value, _ = ops.coalesce_chain(row, col, value, m, n, op)
         return index[0], index[1], value
@@ -40,9 +40,11 @@ def _coalesce_sorted_stream(row, col, value, m: int, n: int, op: str):
     perm = None
     was_sorted = not (flags & 2)
     if not was_sorted:
-        if value is not None and value.dim() == 1 and value.element_size() == 4:
+        if value is not None and value.dim() == 1 and value.element_size() == 4 and not ops.needs_grad(value):
             # 4-byte scalar values ride through the sort as the payload: the
             # reduce below then reads them as a stream, not as value[perm[i]]
+            # (values that autograd tracks go through the permutation instead:
+            # ops.segment_csr / ops.gather_rows are differentiable)
             keys, value = ops.sort_pairs(keys, value, m * n)
         else:
             keys, perm = ops.index_sort(keys, m * n, with_sorted_inputs=True)
@@ -69,7 +71,7 @@ def _coalesce_two_sorted(row_a, col_a, value_a, row_b, col_b, value_b, n: int, o
     total = keys_a.numel() + keys_b.numel()
     has_value = value_a is not None and value_b is not None
     rides = (has_value and value_a.dim() == 1 and value_b.dim() == 1 and value_a.element_size() == 4
-             and value_a.dtype == value_b.dtype)
+             and value_a.dtype == value_b.dtype and not ops.needs_grad(value_a) and not ops.needs_grad(value_b))
     keys, source, value = ops.merge_sorted(keys_a, keys_b, value_a.contiguous() if rides else None,
                                            value_b.contiguous() if rides else None,
                                            want_source=has_value and not rides)

@@ -30,7 +30,8 @@ def _mul_sparse(a: SparseTensor, b: SparseTensor) -> SparseTensor:
     M, N = max(a.size(0), b.size(0)), max(a.size(1), b.size(1))
     keys_a, _ = ops.make_keys(ra, ca, N)
     keys_b, _ = ops.make_keys(rb, cb, N)
-    rides = va.dim() == 1 and vb.dim() == 1 and va.element_size() == 4 and va.dtype == vb.dtype
+    rides = (va.dim() == 1 and vb.dim() == 1 and va.element_size() == 4 and va.dtype == vb.dtype
+             and not ops.needs_grad(va) and not ops.needs_grad(vb))
     keys, source, value = ops.merge_sorted(keys_a, keys_b, va.contiguous() if rides else None,
                                            vb.contiguous() if rides else None, want_source=not rides)
     if not rides:

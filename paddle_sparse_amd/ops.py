@@ -441,8 +441,44 @@ def split_keys(keys: torch.Tensor, div: int, want_hi: bool = True, want_lo: bool
     return hi, lo
 
 
-def gather_rows(src: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
-    """src[perm] along dim 0 for any dtype / trailing shape."""
+def needs_grad(x: Optional[torch.Tensor]) -> bool:
+    """True when autograd will want a gradient for x (callers then keep the
+    values on a differentiable route instead of letting them ride a sort)."""
+    return x is not None and torch.is_grad_enabled() and x.requires_grad
+
+
+class _GatherRows(torch.autograd.Function):
+    """src[perm] with the reference's differentiability (paddle `value[perm]`,
+    storage.py:166-169, transpose.py:14-22): the backward adds every output
+    row's gradient back into the row it was read from — a gather through the
+    inverse permutation when the caller has one, a scatter-add otherwise."""
+
+    @staticmethod
+    def forward(ctx, src, perm, inverse):
+        ctx.save_for_backward(perm, inverse)
+        ctx.rows = src.shape[0]
+        return _gather_rows_raw(src, perm)
+
+    @staticmethod
+    def backward(ctx, grad):
+        perm, inverse = ctx.saved_tensors
+        grad = grad.contiguous()
+        if inverse is not None:
+            return _gather_rows_raw(grad, inverse), None, None
+        acc = grad if grad.dtype in (torch.float32, torch.float64) else grad.float()
+        return scatter(acc, perm, ctx.rows, "sum").to(grad.dtype), None, None
+
+
+def gather_rows(src: torch.Tensor, perm: torch.Tensor, inverse: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """src[perm] along dim 0 for any dtype / trailing shape; differentiable in
+    src.  `inverse` (optional): the inverse of perm when perm is a permutation
+    of all rows — the backward is then a gather instead of a scatter-add."""
+    if needs_grad(src):
+        return _GatherRows.apply(src, perm, inverse)
+    return _gather_rows_raw(src, perm)
+
+
+def _gather_rows_raw(src: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
     _gpu(src, "src")
     perm = _index(perm, "perm")
     src = src.contiguous()
@@ -464,11 +500,48 @@ def invert_permutation(perm: torch.Tensor) -> torch.Tensor:
     return inv
 
 
+class _SegmentCsr(torch.autograd.Function):
+    """segment_csr with paddle_scatter's differentiability for sum / mean (the
+    coalesce and reduce(dim) call sites, storage.py:471, reduce.py:51): every
+    element of a segment receives the segment's gradient (over the segment's
+    length for mean); with `perm` the gradient lands on src[perm[i]]."""
+
+    @staticmethod
+    def forward(ctx, src, indptr, reduce, perm):
+        if REDUCE_ID[reduce] not in (_lib.SUM, _lib.MEAN):
+            raise NotImplementedError(
+                f"segment_csr(reduce={reduce!r}) is not differentiable in this build (sum / mean are)")
+        ctx.save_for_backward(indptr, perm)
+        ctx.mean, ctx.rows = REDUCE_ID[reduce] == _lib.MEAN, src.shape[0]
+        return _segment_csr_raw(src, indptr, reduce, perm)
+
+    @staticmethod
+    def backward(ctx, grad):
+        indptr, perm = ctx.saved_tensors
+        n = perm.numel() if perm is not None else ctx.rows
+        grad = grad.contiguous()
+        if ctx.mean:
+            count = (indptr[1:] - indptr[:-1]).clamp(min=1).to(grad.dtype)
+            grad = grad / count.view((-1,) + (1,) * (grad.dim() - 1))
+        g = _gather_rows_raw(grad, ptr2ind(indptr, n))  # the segment's gradient for each of its elements
+        if perm is not None:
+            acc = g if g.dtype in (torch.float32, torch.float64) else g.float()
+            g = scatter(acc, perm, ctx.rows, "sum").to(grad.dtype)
+        return g, None, None, None
+
+
 def segment_csr(src: torch.Tensor, indptr: torch.Tensor, reduce: str = "sum",
                 perm: Optional[torch.Tensor] = None) -> torch.Tensor:
     """paddle_scatter.segment_csr(src, indptr, reduce=...) along dim 0
     (call sites storage.py:471, reduce.py:51); with `perm`, reduces
-    src[perm] without materialising it."""
+    src[perm] without materialising it.  Differentiable in src for sum / mean."""
+    if needs_grad(src):
+        return _SegmentCsr.apply(src, indptr, reduce, perm)
+    return _segment_csr_raw(src, indptr, reduce, perm)
+
+
+def _segment_csr_raw(src: torch.Tensor, indptr: torch.Tensor, reduce: str = "sum",
+                     perm: Optional[torch.Tensor] = None) -> torch.Tensor:
     _gpu(src, "src")
     indptr = _index(indptr, "indptr")
     if src.dtype not in _DTYPE_ID:

@@ -127,7 +127,8 @@ class SparseStorage(object):
             if int(unsorted.item()):
                 # row[perm] / col[perm] (storage.py:166-167) are read back
                 # from the sorted keys; a 4-byte scalar value rides the sort.
-                if value is not None and value.dim() == 1 and value.element_size() == 4:
+                if (value is not None and value.dim() == 1 and value.element_size() == 4
+                        and not ops.needs_grad(value)):  # tracked values take the differentiable gather below
                     keys, self._value = ops.sort_pairs(keys, value, M * N)
                 else:
                     keys, perm = index_sort(keys, M * N, with_sorted_inputs=True)

@@ -413,3 +413,74 @@ def test_equal_and_to():
     assert not mat.storage.value().is_cuda and not mat.storage.row().is_cuda and not mat.storage.col().is_cuda
     back = mat.to(value)  # device and dtype of a tensor
     assert back.storage.value().dtype == torch.int64 and back.storage.col().is_cuda and back == a
+
+
+# ---- edge values stay differentiable through every value-moving op (the reference's do) -------------
+def test_value_gradients_flow_through_t_coalesce_and_friends():
+    """paddle `value[perm]` / paddle_scatter.segment_csr keep autograd alive in t(), csc(),
+    set_value(layout="csc"), storage.coalesce(), coalesce(), transpose(), to_symmetric() and
+    index_select(); here the gathers and the segmented sum / mean are autograd Functions."""
+    import paddle_sparse_amd as ps
+    from paddle_sparse_amd import SparseTensor
+
+    rng = np.random.default_rng(33)
+    M, N, K = 60, 45, 8
+    key = np.unique(rng.integers(0, M * N, 700))
+    row, col = key // N, key % N
+    nnz = key.size
+    val = rng.standard_normal(nnz).astype(np.float32)
+    B = rng.standard_normal((M, K)).astype(np.float32)
+    G = rng.standard_normal((N, K)).astype(np.float32)
+
+    # (a) A.t() @ B: d/dvalue[e] = <B[row[e]], G[col[e]]>
+    v = torch.from_numpy(val).cuda().requires_grad_()
+    a = SparseTensor(row=idx(row), col=idx(col), value=v, sparse_sizes=(M, N))
+    (a.t() @ torch.from_numpy(B).cuda()).backward(torch.from_numpy(G).cuda())
+    want = (B[row] * G[col]).sum(1)
+    scale = (np.abs(B[row]) * np.abs(G[col])).sum(1)
+    assert np.all(np.abs(v.grad.cpu().numpy() - want) <= 1e-5 * scale + 1e-30)
+
+    # (b) coalesce / transpose with duplicates: the gradient of the summed entry reaches every duplicate
+    dup_r = np.concatenate([row, row[:100]])
+    dup_c = np.concatenate([col, col[:100]])
+    w = rng.standard_normal(nnz + 100).astype(np.float32)
+    for fn, op in ((ps.coalesce, "add"), (ps.coalesce, "mean"), (ps.transpose, None)):
+        v = torch.from_numpy(w).cuda().requires_grad_()
+        index = idx(np.stack([dup_r, dup_c]))
+        out_i, out_v = fn(index, v, M, N, op) if op else fn(index, v, M, N)
+        coef = torch.from_numpy(rng.standard_normal(out_v.shape[0]).astype(np.float32)).cuda()
+        (out_v * coef).sum().backward()
+        oi = out_i.cpu().numpy()
+        if op:
+            pos = np.searchsorted(oi[0] * N + oi[1], dup_r * N + dup_c)
+        else:  # transpose: the output is the N x M matrix, sorted by (col, row) of the input
+            pos = np.searchsorted(oi[0] * M + oi[1], dup_c * M + dup_r)
+        okey = oi[0]
+        cnt = np.bincount(pos, minlength=okey.size)[pos]
+        want = coef.cpu().numpy()[pos] / (cnt if op == "mean" else 1)
+        np.testing.assert_allclose(v.grad.cpu().numpy(), want, rtol=1e-6, atol=1e-7)
+
+    # (c) csc(), set_value(layout="csc"), to_symmetric(), index_select(), storage.coalesce()
+    v = torch.from_numpy(val).cuda().requires_grad_()
+    a = SparseTensor(row=idx(row), col=idx(col), value=v, sparse_sizes=(M, N))
+    coef = torch.from_numpy(rng.standard_normal(nnz).astype(np.float32)).cuda()
+    (a.csc()[2] * coef).sum().backward()
+    perm = a.storage.csr2csc()
+    assert torch.allclose(v.grad[perm], coef)
+    v.grad = None
+    b = a.set_value(v * 2.0, layout="csc")
+    (b.storage.value() * coef).sum().backward()
+    assert torch.allclose(v.grad, 2.0 * coef[a.storage.csr2csc()])
+    v.grad = None
+    sq = SparseTensor(row=idx(row % 40), col=idx(col % 40), value=v, sparse_sizes=(40, 40))
+    sym = sq.to_symmetric()
+    sym.storage.value().sum().backward()
+    assert torch.allclose(v.grad, torch.full_like(v, 2.0))  # every entry appears as (i, j) and (j, i)
+    v.grad = None
+    sel = idx([3, 3, 10, 59])
+    a.index_select(0, sel).storage.value().sum().backward()
+    times = np.bincount(np.array([3, 3, 10, 59]), minlength=M)[row]
+    assert np.array_equal(v.grad.cpu().numpy(), times.astype(np.float32))
+    # detached paths still take the fast routes
+    with torch.no_grad():
+        assert ps.coalesce(idx(np.stack([dup_r, dup_c])), torch.from_numpy(w).cuda(), M, N)[1].requires_grad is False

@@ -99,3 +99,85 @@ def test_index_select_nnz(mat):
     out = t.index_select_nnz(pick, layout="csc")
     perm = t.storage.csc2csr()[pick]
     assert out.storage.col().tolist() == col[perm].tolist()
+
+
+# ---- against the oracle's restatement of index_select.py / masked_select.py / narrow.py -------------
+
+def _same(t, ref, caches=None):
+    """Same entries, order, values and sizes as the oracle's Storage; caches the reference
+    passes to the new SparseStorage hold the same numbers here whenever they are present."""
+    row, col, val = t.coo()
+    assert t.sparse_sizes() == (ref.M, ref.N)
+    assert np.array_equal(row.cpu().numpy(), ref.row) and np.array_equal(col.cpu().numpy(), ref.col)
+    assert (val is None) == (ref.value is None)
+    if val is not None:
+        assert np.array_equal(val.cpu().numpy(), ref.value)
+    for name, want in (caches or {}).items():
+        got = getattr(t.storage, "_" + name)
+        if got is not None:
+            assert np.array_equal(got.cpu().numpy(), want), name
+
+
+@pytest.fixture(scope="module")
+def pair():
+    from oracle import storage_oracle as so
+    from paddle_sparse_amd import SparseTensor
+
+    rng = np.random.default_rng(31)
+    M, N = 70, 55
+    key = np.unique(rng.integers(0, M * N, 900))
+    row, col = key // N, key % N
+    val = rng.standard_normal((key.size, 3)).astype(np.float32)
+    t = SparseTensor(row=idx(row), col=idx(col), value=torch.from_numpy(val).cuda(), sparse_sizes=(M, N))
+    return t, so.Storage(row, col, val, (M, N), is_sorted=True)
+
+
+def test_slicing_vs_oracle(pair):
+    from oracle import storage_oracle as so
+
+    t, st = pair
+    rng = np.random.default_rng(5)
+    for sel in ([5, 0, 69, 5, 33], [], list(range(70))):
+        _same(t.index_select(0, idx(sel)), *so.index_select(st, 0, sel))
+    for sel in ([54, 1, 1, 20], [0], list(range(54, -1, -1))):
+        _same(t.index_select(1, idx(sel)), *so.index_select(st, 1, sel))
+    _same(t.index_select(2, idx([2, 0])), *so.index_select(st, 2, [2, 0]))
+    _same(t.index_select(-1, idx([1])), *so.index_select(st, -1, [1]))
+    pick = rng.integers(0, st.row.size, 40)
+    for layout in ("coo", "csc"):
+        _same(t.index_select_nnz(idx(pick), layout=layout), so.index_select_nnz(st, pick, layout))
+    m0, m1, m2 = rng.random(70) < 0.4, rng.random(55) < 0.5, np.array([True, False, True])
+    _same(t.masked_select(0, torch.from_numpy(m0).cuda()), *so.masked_select(st, 0, m0))
+    _same(t.masked_select(1, torch.from_numpy(m1).cuda()), *so.masked_select(st, 1, m1))
+    _same(t.masked_select(2, torch.from_numpy(m2).cuda()), *so.masked_select(st, 2, m2))
+    keep = rng.random(st.row.size) < 0.5
+    for layout in ("coo", "csc"):
+        _same(t.masked_select_nnz(torch.from_numpy(keep).cuda(), layout=layout), so.masked_select_nnz(st, keep, layout))
+    for dim, start, length in ((0, 10, 25), (0, -5, 5), (0, 0, 70), (1, 3, 40), (1, -10, 10), (2, 1, 2), (-1, 0, 1)):
+        _same(t.narrow(dim, start, length), *so.narrow(st, dim, start, length))
+    t.storage.fill_cache_()  # with every cache present the narrowed caches are the reference's slices
+    for dim, start, length in ((0, 10, 25), (1, 3, 40)):
+        _same(t.narrow(dim, start, length), *so.narrow(st, dim, start, length))
+
+
+def test_getitem_shapes_of_the_reference(kats):
+    """test/test_tensor.py:16-68: the reference's own (shape-only) checks of __getitem__."""
+    from paddle_sparse_amd import SparseTensor
+
+    k = kats["getitem_shapes"]
+    m, n, kk = k["m"], k["n"], k["k"]
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    mat = SparseTensor.from_dense(torch.randn(m, n, generator=g, device="cuda"))
+    idx1 = torch.randint(0, m, (kk,), generator=g, device="cuda")
+    idx2 = torch.randint(0, n, (kk,), generator=g, device="cuda")
+    bool1 = torch.zeros(m, dtype=torch.bool, device="cuda")
+    bool2 = torch.zeros(n, dtype=torch.bool, device="cuda")
+    bool1[idx1] = True
+    bool2[idx2] = True
+    env = dict(mat=mat, k=kk, idx1=idx1, idx2=idx2, bool1=bool1, bool2=bool2,
+               idx1np=idx1.cpu().numpy(), idx2np=idx2.cpu().numpy(), bool1np=bool1.cpu().numpy(), bool2np=bool2.cpu().numpy(),
+               idx1list=idx1.tolist(), idx2list=idx2.tolist(), bool1list=bool1.tolist(), bool2list=bool2.tolist())
+    sizes = dict(m=m, n=n, k=kk, k1_bool=int(bool1.sum()), k2_bool=int(bool2.sum()))
+    for case in k["cases"]:
+        got = eval(case["expr"], {}, env)  # noqa: S307 - expressions come from the committed fixture
+        assert list(got.sizes()) == [sizes[s] for s in case["sizes"]], case["expr"]
