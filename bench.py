@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
 """Headline benchmark: SpMM GEdges/s + achieved-HBM fraction.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--op spmm_sum]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--op spmm_sum] [--config c3|c4]
 
 N = 1 (default): BASELINE.json config 3 — random CSR, 2M x 2M, nnz = 20M,
 dense F = 128 fp32, one `spmm_sum` forward per step, inputs resident in HBM.
 N > 1 (launched by torch.distributed.run, one rank per GPU): the same per-GPU
 rows/edges on every rank (weak scaling, BASELINE config 4's structure): rank r
 owns rows [r*2M, (r+1)*2M) of A (20M edges, columns over all N*2M nodes) and
-the matching 2M-row block of B; a step = RCCL all-gather of B + local SpMM
-(paddle_sparse_amd.distributed.RowPartitionedSpMM).
+the matching 2M-row block of B; a step = exchange of B over RCCL (all of it by
+all-gather, or only the rows the rank's columns touch by all_to_all_single) +
+local SpMM (paddle_sparse_amd.distributed.RowPartitionedSpMM).  --config c4
+runs F = 256: at 8 GPUs BASELINE config 4 (16M x 16M, 160M entries).
 
 Prints ONE JSON line on rank 0 (contract in the task brief): whole-job
 GEdges/s, the roofline object of the dominant kernel (algorithmic bytes /
@@ -115,6 +117,90 @@ def event_ms(fn, reps: int) -> float:
     return a.elapsed_time(b) / reps
 
 
+def rmat_graph(scale: int, n: int, device, seed: int = 4, relabel: bool = False):
+    """R-MAT (0.57, 0.19, 0.19, 0.05) at the given scale, coalesced; optionally with the column
+    ids relabelled by a random permutation (Graph500 relabels vertices: hubs then sit anywhere
+    in memory instead of at ids with few bits set).  Returns (N, rowptr, row, col, value)."""
+    from paddle_sparse_amd import coalesce, ops
+
+    N = 1 << scale
+    g = torch.Generator(device=device).manual_seed(seed)
+    row = torch.zeros(n, dtype=torch.int64, device=device)
+    col = torch.zeros(n, dtype=torch.int64, device=device)
+    for bit in range(scale):
+        r = torch.rand(n, generator=g, device=device)
+        row |= (r >= 0.76).to(torch.int64) << bit
+        col |= (((r >= 0.57) & (r < 0.76)) | (r >= 0.95)).to(torch.int64) << bit
+    index, val = coalesce(torch.stack([row, col]), torch.randn(n, generator=g, device=device), N, N)
+    row, col = index[0].contiguous(), index[1].contiguous()
+    if relabel:
+        col = torch.randperm(N, generator=g, device=device)[col].contiguous()
+    return N, ops.ind2ptr(row, N), row, col, val
+
+
+def breadth(rowptr, col, val, B, reps: int):
+    """BASELINE config 3 is spmm_{sum,mean,max} forward AND backward: step times of the other
+    ops of the path on the same workload, each with its algorithmic-byte fraction of the HBM
+    peak (SURVEY.md §8(d) models: forward nnz*(12+4F) + M*(8+4F) [+ M*F*8 arg_out]; backward
+    = grad of the dense operand (forward model with M and N swapped + nnz*16) + grad of the
+    values nnz*(8+8+8F+4))."""
+    from paddle_sparse_amd import SparseTensor, ops
+
+    M, F, nnz = rowptr.numel() - 1, B.shape[1], col.numel()
+    N = B.shape[0]
+    fwd = algorithmic_bytes(nnz, M, F, True, False)
+    fwd_arg = algorithmic_bytes(nnz, M, F, True, True)
+    bwd = algorithmic_bytes(nnz, N, F, True, False) + nnz * 16 + nnz * (8 + 8 + 8 * F + 4)
+    out = {}
+
+    def put(name, ms, nbytes):
+        out[name] = {"ms": round(ms, 4), "gedges_per_s": round(nnz / ms / 1e6, 3),
+                     "algorithmic_gb": round(nbytes / 1e9, 3), "frac_of_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+
+    for op, nb in (("spmm_mean", fwd), ("spmm_max", fwd_arg)):
+        fn = getattr(ops, op)
+        fn(rowptr, col, val, B)
+        put(f"{op}_fwd", event_ms(lambda: fn(rowptr, col, val, B), reps), nb)
+    row = ops.ptr2ind(rowptr, nnz)
+    G = torch.randn(M, F, device=B.device)
+    v = val.clone().requires_grad_()
+    Bt = B.clone().requires_grad_()
+    a = SparseTensor(row=row, rowptr=rowptr, col=col, value=v, sparse_sizes=(M, N), is_sorted=True, trust_data=True)
+    a.storage.csr2csc(), a.storage.csc2csr(), a.storage._csc_edge_tags()  # one-off CSC view of the matrix (cached)
+
+    def fwd_bwd(reduce):
+        v.grad = Bt.grad = None
+        a.matmul(Bt, reduce).backward(G)
+
+    for reduce, nb in (("sum", fwd + bwd), ("max", fwd_arg + bwd)):
+        fwd_bwd(reduce)
+        put(f"spmm_{reduce}_fwd_bwd", event_ms(lambda: fwd_bwd(reduce), max(3, reps // 4)), nb)
+    return out
+
+
+def power_law(device, F: int, reps: int):
+    """The forward on a power-law graph (R-MAT scale 21, 19.5 M entries), both kernel families,
+    as generated and with relabelled columns."""
+    from paddle_sparse_amd import ops
+
+    res = {}
+    for relabel in (False, True):
+        N, rowptr, row, col, val = rmat_graph(21, 20_000_000, device, relabel=relabel)
+        B = torch.randn(N, F, device=device)
+        nnz = col.numel()
+        entry = {"nnz": nnz, "rows": N}
+        for algo in ("row_waves", "edge_ranges"):
+            for op in ("spmm_sum", "spmm_max"):
+                fn = getattr(ops, op)
+                fn(rowptr, col, val, B, row=row, algo=algo)
+                ms = event_ms(lambda: fn(rowptr, col, val, B, row=row, algo=algo), reps)
+                entry[f"{op}_{algo}_ms"] = round(ms, 4)
+        entry["algo_chosen_by_row_stats"] = "edge_ranges" if 5 * sum(ops.csr_row_stats(rowptr)[:2]) > 2 * N else "row_waves"
+        res["rmat21_relabelled_columns" if relabel else "rmat21_as_generated"] = entry
+        del B
+    return res
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,11 +208,18 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--op", default="spmm_sum", choices=["spmm_sum", "spmm_mean", "spmm_max", "spmm_min"])
     ap.add_argument("--variant", type=int, default=0)
+    ap.add_argument("--config", default="c3", choices=["c3", "c4"],
+                    help="c3 (default): 2M rows / 20M entries per GPU, F = 128 (BASELINE config 3 per GPU); "
+                         "c4: F = 256 — at 8 GPUs BASELINE config 4 (16M x 16M, 160M entries)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the breadth / power-law legs after the timed region")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "full", "halo"],
+                    help="N > 1: all of B by all-gather, or only the rows this rank's columns touch "
+                         "(all_to_all_single); auto times both during warmup")
     ap.add_argument("--feature-chunks", type=int, default=0,
-                    help="N > 1: all-gather B in this many column slices and run the SpMM of a "
-                         "slice under the exchange of the next ones (1: one all-gather, then the SpMM; "
-                         "default 0: time both forms during warmup and keep the faster one)")
+                    help="N > 1: exchange B in this many column slices and run the SpMM of a slice under the "
+                         "exchange of the next ones (1: one exchange, then the SpMM; default 0: time 1 and 4 "
+                         "during warmup and keep the faster)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -162,7 +255,8 @@ def main() -> None:
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    M, nnz, F = M_PER_GPU, NNZ_PER_GPU, FEAT
+    M, nnz = M_PER_GPU, NNZ_PER_GPU
+    F = 256 if args.config == "c4" else FEAT
     N = M * world
     reduce = args.op.split("_", 1)[1]
     rowptr, col, val = make_workload(M, N, nnz, F, seed=2 + rank, device=device)
@@ -170,38 +264,27 @@ def main() -> None:
     B_local = torch.randn(M, F, generator=g, device=device)
     ops.spmm_set_variant(args.variant)
 
-    chunks = 1
-    if use_dist:
-        from paddle_sparse_amd.distributed import RowPartitionedSpMM, RowShard
-
-        op = RowPartitionedSpMM(RowShard(rowptr, col, val, rank * M, (rank + 1) * M, N), reduce=reduce)
-        chunks = args.feature_chunks
-        step = lambda: op(B_local, feature_chunks=chunks)  # noqa: E731  all-gather(B) + local HIP SpMM
-        B_full = op.gather(B_local)
-    else:
-        fn = getattr(ops, args.op)
-        B_full = B_local
-        step = lambda: fn(rowptr, col, val, B_full)  # noqa: E731
-
-    def local_kernel():
-        return ops._spmm(reduce, rowptr, col, val, B_full)[0]
-
     def sync_all():
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
-    # Two forms of the same step exist (one all-gather then the SpMM; or column
-    # slices whose exchanges overlap the SpMM of earlier slices).  Which is faster
-    # depends on the fabric, so — untimed, before the warmup — both run a few
-    # steps, the slowest rank's times decide, and every rank keeps the same form.
-    overlap_chunks = 4
+    forms = {}  # (exchange, chunks) -> RowPartitionedSpMM
+    chosen = ("full", 1)
     tune_ms = {}
-    if use_dist and chunks == 0:
-        candidates = [1] + ([overlap_chunks] if F % overlap_chunks == 0 else [])
+    if use_dist:
+        from paddle_sparse_amd.distributed import RowPartitionedSpMM, RowShard
+
+        shard = RowShard(rowptr, col, val, rank * M, (rank + 1) * M, N)
+        exchanges = ["full", "halo"] if args.exchange == "auto" else [args.exchange]
+        chunk_opts = [1, 4] if args.feature_chunks == 0 and F % 4 == 0 else [max(args.feature_chunks, 1)]
+        ops_by_exchange = {e: RowPartitionedSpMM(shard, reduce=reduce, exchange=e) for e in exchanges}
+        forms = {(e, c): ops_by_exchange[e] for e in exchanges for c in chunk_opts}
+        # Which form is faster depends on the fabric and on the graph: untimed, before the warmup,
+        # every form runs a few steps; the slowest rank's time decides and every rank keeps the same form.
         spent = []
-        for c in candidates:
+        for (e, c), op in forms.items():
             op(B_local, feature_chunks=c)
             sync_all()
             t_c = time.perf_counter()
@@ -212,8 +295,21 @@ def main() -> None:
         spent_t = torch.tensor(spent, dtype=torch.float64, device=device)
         dist.all_reduce(spent_t, op=dist.ReduceOp.MAX)
         spent = [float(x) for x in spent_t]
-        chunks = candidates[spent.index(min(spent))]
-        tune_ms = {str(c): round(x * 1e3, 4) for c, x in zip(candidates, spent)}
+        keys = list(forms)
+        chosen = keys[spent.index(min(spent))]
+        tune_ms = {f"{e}/chunks{c}": round(x * 1e3, 4) for (e, c), x in zip(keys, spent)}
+        op = forms[chosen]
+        step = lambda: op(B_local, feature_chunks=chosen[1])  # noqa: E731  exchange of B + local HIP SpMM
+        B_full = ops_by_exchange.get("full", op).gather(B_local) if "full" in ops_by_exchange else op.exchange_only(B_local)
+    else:
+        fn = getattr(ops, args.op)
+        B_full = B_local
+        step = lambda: fn(rowptr, col, val, B_full)  # noqa: E731
+
+    def local_kernel():
+        if use_dist and "full" not in ops_by_exchange:
+            return op.spmm_only(B_full)
+        return ops._spmm(reduce, rowptr, col, val, B_full)[0]
 
     for _ in range(args.warmup):
         step()
@@ -229,36 +325,54 @@ def main() -> None:
 
     # dominant kernel alone (HIP events on its launch stream), after the timed region
     kern_ms = event_ms(local_kernel, args.steps)
-    gather_ms = event_ms(lambda: op.gather(B_local), max(3, args.steps // 5)) if use_dist else 0.0
 
-    # SURVEY.md §8(e) asks for both end-to-end figures: the form that was NOT
-    # timed above runs a few steps here, so the line carries serial and overlapped.
-    other_chunks = overlap_chunks if chunks <= 1 else 1
-    other_s, other_steps = 0.0, 0
-    if use_dist and F % overlap_chunks == 0:
+    # SURVEY.md §8(e) asks for the local-kernel aggregate, end-to-end serial and end-to-end
+    # overlapped: the forms that were NOT timed above run a few steps here, so the line carries all.
+    form_s = {}
+    exch_ms = {}
+    if use_dist:
         other_steps = max(3, args.steps // 5)
-        op(B_local, feature_chunks=other_chunks)
-        sync_all()
-        t1 = time.perf_counter()
-        for _ in range(other_steps):
-            op(B_local, feature_chunks=other_chunks)
-        sync_all()
-        other_s = time.perf_counter() - t1
+        for key, o in forms.items():
+            if key == chosen:
+                form_s[key] = elapsed / args.steps
+                continue
+            o(B_local, feature_chunks=key[1])
+            sync_all()
+            t1 = time.perf_counter()
+            for _ in range(other_steps):
+                o(B_local, feature_chunks=key[1])
+            sync_all()
+            form_s[key] = (time.perf_counter() - t1) / other_steps
+        for e, o in ops_by_exchange.items():
+            exch_ms[e] = event_ms(lambda: o.exchange_only(B_local), max(3, args.steps // 5))
 
-    t = torch.tensor([elapsed, kern_ms, gather_ms, other_s], dtype=torch.float64, device=device)
+    vec = [elapsed, kern_ms] + [form_s[k] for k in forms] + [exch_ms[e] for e in exch_ms]
+    t = torch.tensor(vec, dtype=torch.float64, device=device)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, kern_ms, gather_ms, other_s = (float(x) for x in t)
+    vec = [float(x) for x in t]
+    elapsed, kern_ms = vec[0], vec[1]
+    form_s = dict(zip(forms, vec[2:2 + len(forms)]))
+    exch_ms = dict(zip(exch_ms, vec[2 + len(forms):]))
+    recv_rows = {}
+    if use_dist:
+        rr = torch.tensor([o.rows_received_per_step() for o in ops_by_exchange.values()], dtype=torch.int64, device=device)
+        dist.all_reduce(rr, op=dist.ReduceOp.MAX)
+        recv_rows = dict(zip(ops_by_exchange, rr.tolist()))
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * nnz / (elapsed / args.steps) / 1e9
         alg = algorithmic_bytes(nnz, M, F, True, args.op in ("spmm_max", "spmm_min"))
         achieved = alg / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_note = None, "not collected for this configuration"
         tfile = ROOT / "profiles" / "traffic.json"
-        if tfile.exists() and world == 1:
-            traffic = json.loads(tfile.read_text()).get(f"{args.op}_c3", {}).get("hbm_bytes_per_launch")
+        if tfile.exists() and world == 1 and args.config == "c3":
+            rec = json.loads(tfile.read_text()).get(f"{args.op}_c3", {})
+            traffic = rec.get("hbm_bytes_per_launch")
+            traffic_note = (f"read from profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round "
+                            f"{rec.get('round', '?')}, {rec.get('source', '?')}); not measured in this run")
+        cfg_name = "BASELINE config 3 per GPU" if args.config == "c3" else "BASELINE config 4's per-GPU share (F = 256)"
         line = {
             "metric": f"{args.op}_gedges_per_s",
             "value": round(value, 4),
@@ -274,9 +388,9 @@ def main() -> None:
             "data": "synthetic",
             "config": {
                 "workload": f"{args.op} fwd, uniform random CSR {M}x{N} per GPU, nnz={nnz} per GPU, "
-                            f"dense F={F} fp32 (BASELINE config 3 per GPU)"
-                            + (f"; + RCCL all-gather of B ({N}x{F}) every step"
-                               + (f", in {chunks} column slices overlapped with the SpMM" if chunks > 1 else "")
+                            f"dense F={F} fp32 ({cfg_name})"
+                            + (f"; + exchange of B ({N}x{F}) every step: {chosen[0]}"
+                               + (f", in {chosen[1]} column slices overlapped with the SpMM" if chosen[1] > 1 else "")
                                if use_dist else ""),
                 "rows_per_gpu": M, "nnz_per_gpu": nnz, "feat": F, "index_dtype": "int64",
                 "variant": args.variant,
@@ -289,27 +403,29 @@ def main() -> None:
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
+                "traffic_source": traffic_note,
                 "algorithmic_bytes_per_launch": alg,
                 "kernel_ms": round(kern_ms, 4),
                 "kernel_gedges_per_s": round(nnz / (kern_ms * 1e-3) / 1e9, 4),
             },
         }
         if use_dist:
-            other = round(world * nnz / (other_s / other_steps) / 1e9, 4) if other_steps else None
-            serial, overlapped = (value, other) if chunks <= 1 else (other, value)
+            rate = lambda s_: round(world * nnz / s_ / 1e9, 4)  # noqa: E731
+            serial = {e: rate(form_s[(e, 1)]) for e in ops_by_exchange if (e, 1) in form_s}
+            overl = {e: rate(form_s[(e, c)]) for (e, c) in form_s if c > 1}
             line["multi_gpu"] = {
-                "allgather_ms": round(gather_ms, 4),
-                "feature_chunks": chunks,
-                "feature_chunks_chosen_by": "flag" if args.feature_chunks else "warmup timing (ms per step by form)",
-                "warmup_ms_per_step_by_feature_chunks": tune_ms or None,
-                "allgather_bytes_received_per_rank": (world - 1) * M * F * 4,
+                "form_timed_as_value": f"{chosen[0]}/chunks{chosen[1]}",
+                "form_chosen_by": "flags" if len(forms) == 1 else "warmup timing (ms per step by form)",
+                "warmup_ms_per_step_by_form": tune_ms or None,
                 "spmm_only_aggregate_gedges_per_s": round(world * nnz / (kern_ms * 1e-3) / 1e9, 4),
-                "end_to_end_serial_gedges_per_s": None if serial is None else round(serial, 4),
-                "end_to_end_overlapped_gedges_per_s": None if overlapped is None else round(overlapped, 4),
-                "overlapped_feature_chunks": overlap_chunks,
-                "note": "value counts the exchange of B inside every step, in the form named by feature_chunks "
-                        "(1 = one all-gather then the SpMM); spmm_only_* is the local-kernel rate with B "
-                        "already assembled",
+                "end_to_end_serial_gedges_per_s": serial,
+                "end_to_end_overlapped_gedges_per_s": overl,
+                "overlapped_feature_chunks": 4,
+                "exchange_ms": {e: round(x, 4) for e, x in exch_ms.items()},
+                "allgather_bytes_received_per_rank": (world - 1) * M * F * 4,
+                "bytes_received_per_rank_by_exchange": {e: r * F * 4 for e, r in recv_rows.items()},
+                "note": "value counts the exchange of B inside every step, in the form named by form_timed_as_value; "
+                        "spmm_only_* is the local-kernel rate with B already assembled",
             }
         if not args.no_cpu and args.op == "spmm_sum" and world == 1:  # CPU leg: N = 1 only
             info, ref, rows = cpu_baseline(rowptr, col, val, B_full)
@@ -317,6 +433,12 @@ def main() -> None:
             scale = np.abs(ref).max()
             line["cpu_baseline"] = info
             line["check_max_abs_err_vs_oracle"] = float(np.abs(got - ref).max() / scale)
+        if not args.no_extra and world == 1 and not use_dist and args.config == "c3":
+            # after the timed region: the rest of BASELINE config 3 (mean / max forward, sum / max
+            # forward + backward) and the forward on a power-law graph; headline fields unchanged
+            line["c3_other_ops"] = breadth(rowptr, col, val, B_full, max(5, args.steps // 5))
+            del out
+            line["power_law"] = power_law(device, F, max(5, args.steps // 5))
         if stdout_fd is not None:
             sys.stdout.flush()
             os.dup2(stdout_fd, 1)

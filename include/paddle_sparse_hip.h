@@ -145,7 +145,11 @@ int psa_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
  * rowptr -> col -> gather dependency chain which bounds the one-wave-per-row
  * kernels on power-law graphs.  Same results contract as psa_spmm (sums are
  * taken in edge order inside a range, so sum / mean may differ from the
- * row-wave kernels in the last bits; min / max / arg_out are identical). */
+ * row-wave kernels in the last bits; min / max / arg_out are identical).
+ * ldo: floats between consecutive rows of `out` (0 = K): out may be a K-column
+ * slice of a wider row-major matrix, so a product computed slice by slice
+ * (the feature-sliced multi-GPU exchange) lands in place with no concatenation.
+ * arg_out / arg_bytes, when given, stay dense [M, K]. */
 typedef enum psa_spmm_algo {
   PSA_SPMM_AUTO = 0,        /* today: PSA_SPMM_ROW_WAVES */
   PSA_SPMM_ROW_WAVES = 1,   /* one wavefront per CSR row (+ the long-row chunks) */
@@ -155,8 +159,8 @@ typedef enum psa_spmm_algo {
 int psa_spmm_coo(int reduce, const int64_t* rowptr, const int64_t* row,
                  const int64_t* col, const float* value, const float* mat,
                  int64_t M, int64_t N, int64_t K, int64_t nnz, float* out,
-                 int64_t* arg_out, uint8_t* arg_bytes, int algo, void* workspace,
-                 size_t workspace_bytes, psa_stream_t stream);
+                 int64_t ldo, int64_t* arg_out, uint8_t* arg_bytes, int algo,
+                 void* workspace, size_t workspace_bytes, psa_stream_t stream);
 
 /* Row-length statistics of a CSR pointer, for choosing psa_spmm_algo once per
  * matrix (the caller reads the four words back and keeps the answer with the
@@ -417,6 +421,16 @@ int psa_split_keys(const int64_t* keys, int64_t n, int64_t div, int64_t* hi,
  * tensor.py:252-257. */
 int psa_gather_rows(const void* src, const int64_t* perm, int64_t n,
                     int64_t row_bytes, void* out, psa_stream_t stream);
+
+/* psa_gather_rows on a column window of the source rows: out[i, :] = the
+ * width_bytes bytes at offset_bytes of row perm[i] of src, whose rows are
+ * src_row_bytes apart; out is dense [n, width_bytes].  Packs the rows (and the
+ * feature slice) of the dense operand another rank asked for into its send
+ * buffer (row-partitioned SpMM, halo exchange: paddle_sparse_amd/distributed.py). */
+int psa_gather_rows_window(const void* src, int64_t src_row_bytes,
+                           int64_t offset_bytes, int64_t width_bytes,
+                           const int64_t* perm, int64_t n, void* out,
+                           psa_stream_t stream);
 
 /* inv[perm[i]] = i.  Same result as the reference's second sort in csc2csr
  * (storage.py:444-445 sorts a permutation to invert it), in one pass. */

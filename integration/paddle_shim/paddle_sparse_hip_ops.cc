@@ -150,7 +150,7 @@ static std::vector<paddle::Tensor> spmm_impl(int reduce, paddle::Tensor& rowptr,
   const size_t ws_bytes = psa_spmm_workspace_bytes(reduce, K, nnz);
   auto ws = scratch(ws_bytes, mat.place());
   PSA_CALL(psa_spmm_coo(reduce, i64(rowptr), i64_or_null(row), i64(col), f32_or_null(value), f32(mat), M, N, K, nnz,
-                        out.data<float>(), minmax && want_arg ? arg.data<int64_t>() : nullptr,
+                        out.data<float>(), /*ldo=*/0, minmax && want_arg ? arg.data<int64_t>() : nullptr,
                         minmax && want_arg_bytes ? arg_bytes.data<uint8_t>() : nullptr, static_cast<int>(algo),
                         ws_bytes > 0 ? ws.data<uint8_t>() : nullptr, ws_bytes, stream_of(mat)));
   return {out, arg, arg_bytes};
@@ -416,6 +416,23 @@ std::vector<paddle::Tensor> gather_rows(paddle::Tensor& src, paddle::Tensor& per
   return {out};
 }
 PD_BUILD_OP(gather_rows).Inputs({"src", "perm"}).Outputs({"out"}).SetKernelFn(PD_KERNEL(gather_rows));
+
+// gather_rows_window: src[perm, col0:col0 + width] packed densely (halo exchange of the row-partitioned SpMM)
+std::vector<paddle::Tensor> gather_rows_window(paddle::Tensor& src, paddle::Tensor& perm, int64_t col0, int64_t width) {
+  CHECK_GPU(src);
+  CHECK_I64(perm);
+  PD_CHECK(src.shape().size() == 2, "src must be 2-D");
+  const int64_t n = perm.numel(), es = static_cast<int64_t>(paddle::SizeOf(src.dtype()));
+  auto out = paddle::empty({n, width}, src.dtype(), src.place());
+  PSA_CALL(psa_gather_rows_window(src.data(), src.shape()[1] * es, col0 * es, width * es, i64(perm), n, out.data(),
+                                  stream_of(src)));
+  return {out};
+}
+PD_BUILD_OP(gather_rows_window)
+    .Inputs({"src", "perm"})
+    .Outputs({"out"})
+    .Attrs({"col0: int64_t", "width: int64_t"})
+    .SetKernelFn(PD_KERNEL(gather_rows_window));
 
 // merge_sorted: the cat + argsort of add.py:30-47 / mul.py:57-73 / tensor.py:415-451 on two sorted halves
 std::vector<paddle::Tensor> merge_sorted(paddle::Tensor& a, paddle::Tensor& b) {

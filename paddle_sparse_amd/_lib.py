@@ -34,7 +34,7 @@ SIGNATURES = {
                          c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                          c_size_t, c_void_p]),
     "psa_spmm_coo": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
-                             c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                             c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p,
                              c_size_t, c_void_p]),
     "psa_csr_row_stats": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "psa_spmm_set_variant": (c_int, [c_int]),
@@ -80,6 +80,7 @@ SIGNATURES = {
                               c_void_p, c_void_p]),
     "psa_split_keys": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "psa_gather_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
+    "psa_gather_rows_window": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     "psa_invert_permutation": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "psa_bincount": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "psa_count2ptr_workspace_bytes": (c_size_t, [c_int64]),

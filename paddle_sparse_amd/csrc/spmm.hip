@@ -27,6 +27,12 @@ constexpr int kWaves = kThreads / 64;
 
 enum { R_SUM = 0, R_MIN = 1, R_MAX = 2 };
 
+// Output rows may sit inside a wider matrix (a column slice of it): row r starts at p + r * ld.
+struct OutView {
+  float* p;
+  int64_t ld;
+};
+
 using psa::load_vec;
 using psa::load_vec_nt;
 using psa::shfl_i64;
@@ -315,7 +321,7 @@ __global__ void __launch_bounds__(kThreads)
 spmm_row_kernel(const int64_t* __restrict__ rowptr,
                 const int64_t* __restrict__ col,
                 const float* __restrict__ val, const float* __restrict__ mat,
-                float* __restrict__ out, int64_t* __restrict__ arg_out,
+                OutView out, int64_t* __restrict__ arg_out,
                 int64_t M, int64_t K, int64_t nnz, int mean,
                 unsigned long long* __restrict__ long_ctr,
                 LongEntry* __restrict__ long_list) {
@@ -354,7 +360,7 @@ spmm_row_kernel(const int64_t* __restrict__ rowptr,
       }
       if (arg_out) store_arg_nt<VEC>(arg_out + row * K + k0, arg);
     }
-    store_vec_nt<VEC>(out + row * K + k0, acc);
+    store_vec_nt<VEC>(out.p + row * out.ld + k0, acc);
   }
 }
 
@@ -370,7 +376,7 @@ __global__ void __launch_bounds__(kThreads)
 spmm_rows_kernel(const int64_t* __restrict__ rowptr,
                  const int64_t* __restrict__ col,
                  const float* __restrict__ val, const float* __restrict__ mat,
-                 float* __restrict__ out, int64_t* __restrict__ arg_out,
+                 OutView out, int64_t* __restrict__ arg_out,
                  int64_t M, int64_t K, int64_t nnz, int mean,
                  unsigned long long* __restrict__ long_ctr,
                  LongEntry* __restrict__ long_list) {
@@ -485,7 +491,7 @@ spmm_rows_kernel(const int64_t* __restrict__ rowptr,
         }
         if (arg_out) store_arg_nt<VEC>(arg_out + row * K + k0, arg);
       }
-      store_vec_nt<VEC>(out + row * K + k0, acc);
+      store_vec_nt<VEC>(out.p + row * out.ld + k0, acc);
     }
   }
 }
@@ -627,7 +633,7 @@ template <int VEC, int LPR, int RED, int U, int MODE = M_PLAIN>
 __global__ void __launch_bounds__(kThreads)
 spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col,
                   const float* __restrict__ val, const float* __restrict__ mat,
-                  float* __restrict__ out, int64_t* __restrict__ arg_out, int64_t M,
+                  OutView out, int64_t* __restrict__ arg_out, int64_t M,
                   int64_t K, int64_t nnz, int mean,
                   const unsigned long long* __restrict__ long_ctr,
                   const LongEntry* __restrict__ long_list, float* __restrict__ part_val,
@@ -715,8 +721,8 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
         __builtin_nontemporal_store(packed, reinterpret_cast<uint32_t*>(mask.arg_bytes_out + row * K + k0));
       }
     }
-    if (mask.temporal_out) store_vec<VEC>(out + row * K + k0, acc);
-    else store_vec_nt<VEC>(out + row * K + k0, acc);
+    if (mask.temporal_out) store_vec<VEC>(out.p + row * out.ld + k0, acc);
+    else store_vec_nt<VEC>(out.p + row * out.ld + k0, acc);
   }
 }
 
@@ -728,7 +734,7 @@ spmm_long_combine_kernel(const int64_t* __restrict__ rowptr, int64_t K, int mean
                          const LongEntry* __restrict__ long_list,
                          const float* __restrict__ part_val,
                          const int64_t* __restrict__ part_arg,
-                         float* __restrict__ out, int64_t* __restrict__ arg_out,
+                         OutView out, int64_t* __restrict__ arg_out,
                          uint8_t* __restrict__ arg_bytes) {
   const int lane = threadIdx.x & 63;
   const int nrows = static_cast<int>(*long_ctr >> 32);
@@ -786,7 +792,7 @@ spmm_long_combine_kernel(const int64_t* __restrict__ rowptr, int64_t K, int mean
             arg_bytes[ent.row * K + k] =
                 static_cast<uint8_t>(((arg[t] - rowptr[ent.row]) & 127) | (deg > kByteExact ? 0x80 : 0));
         }
-        __builtin_nontemporal_store(acc[t], out + ent.row * K + k);
+        __builtin_nontemporal_store(acc[t], out.p + ent.row * out.ld + k);
       }
     }
   }
@@ -805,7 +811,7 @@ __global__ void __launch_bounds__(kThreads)
 spmm_multirow_kernel(const int64_t* __restrict__ rowptr,
                      const int64_t* __restrict__ col,
                      const float* __restrict__ val, const float* __restrict__ mat,
-                     float* __restrict__ out, int64_t* __restrict__ arg_out,
+                     OutView out, int64_t* __restrict__ arg_out,
                      int64_t M, int64_t K, int64_t nnz, int mean,
                      unsigned long long* __restrict__ long_ctr,
                      LongEntry* __restrict__ long_list, uint8_t* __restrict__ arg_bytes) {
@@ -886,7 +892,7 @@ spmm_multirow_kernel(const int64_t* __restrict__ rowptr,
       __builtin_nontemporal_store(packed, reinterpret_cast<uint32_t*>(arg_bytes + row * K + k0));
     }
   }
-  store_vec_nt<VEC>(out + row * K + k0, acc);
+  store_vec_nt<VEC>(out.p + row * out.ld + k0, acc);
 }
 
 int g_variant = 0;
@@ -923,7 +929,7 @@ LongScratch carve(void* workspace, bool minmax, int64_t K, int64_t nnz) {
 // Second and third launch of the long-row path (no-ops when the list is empty).
 template <int VEC, int LPR, int U>
 int launch_long(int red, const int64_t* rowptr, const int64_t* col, const float* val,
-                const float* mat, float* out, int64_t* arg_out, int64_t K, int64_t nnz,
+                const float* mat, OutView out, int64_t* arg_out, int64_t K, int64_t nnz,
                 int mean, const LongScratch& w, hipStream_t s, uint8_t* arg_bytes = nullptr) {
   const dim3 grid(kLongBlocks), block(psa::kLongThreads);
 #define PSA_LONG(R)                                                                        \
@@ -947,7 +953,7 @@ constexpr int64_t kNtGatherBytes = 6ll << 30;  // dense operand size from which 
 
 template <int VEC, int LPR, int U>
 int launch_fused(int red, const int64_t* rowptr, const int64_t* col, const float* val,
-                 const float* mat, float* out, int64_t* arg_out, int64_t M, int64_t K,
+                 const float* mat, OutView out, int64_t* arg_out, int64_t M, int64_t K,
                  int64_t nnz, int mean, const LongScratch& w, hipStream_t s,
                  uint8_t* arg_bytes = nullptr, bool nt_gather = false, int k_tiles = 1) {
   const int kFusedChunkBlocks = g_variant == 20 ? 512 : g_variant == 21 ? 1024 : g_variant == 22 ? 1536 : kFusedChunkBlocksDefault;
@@ -994,7 +1000,7 @@ int launch_fused(int red, const int64_t* rowptr, const int64_t* col, const float
 // The same three launches in the MASK form (sum over the CSC view; see MaskArgs).
 template <int LPR, int U, int MODE>
 int launch_fused_masked(const int64_t* colptr, const int64_t* row_csc, const float* value,
-                        const float* grad, float* out, int64_t N, int64_t K, int64_t nnz,
+                        const float* grad, OutView out, int64_t N, int64_t K, int64_t nnz,
                         const MaskArgs& mask, const LongScratch& w, hipStream_t s) {
   const int kFusedChunkBlocks = kFusedChunkBlocksDefault;
   const int64_t gx = psa::ceil_div(N, kWaves) + kFusedChunkBlocks;
@@ -1050,7 +1056,7 @@ csc_edge_tags_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restri
 
 template <int VEC, int LPR, int U>
 int launch_multirow(int red, const int64_t* rowptr, const int64_t* col,
-                    const float* val, const float* mat, float* out,
+                    const float* val, const float* mat, OutView out,
                     int64_t* arg_out, int64_t M, int64_t K, int64_t nnz, int mean,
                     const LongScratch& w, hipStream_t s, uint8_t* arg_bytes = nullptr) {
   const int64_t gx = psa::ceil_div(M, static_cast<int64_t>(kWaves) * (64 / LPR));
@@ -1077,7 +1083,7 @@ int launch_multirow(int red, const int64_t* rowptr, const int64_t* col,
 
 template <int VEC, int LPR, int U>
 int launch_row(int red, const int64_t* rowptr, const int64_t* col,
-               const float* val, const float* mat, float* out,
+               const float* val, const float* mat, OutView out,
                int64_t* arg_out, int64_t M, int64_t K, int64_t nnz, int mean,
                const LongScratch& w, hipStream_t s) {
   const int64_t gx = psa::ceil_div(M, kWaves);
@@ -1103,7 +1109,7 @@ int launch_row(int red, const int64_t* rowptr, const int64_t* col,
 
 template <int VEC, int LPR, int U, int R>
 int launch_rows(int red, const int64_t* rowptr, const int64_t* col,
-                const float* val, const float* mat, float* out,
+                const float* val, const float* mat, OutView out,
                 int64_t* arg_out, int64_t M, int64_t K, int64_t nnz, int mean,
                 const LongScratch& w, hipStream_t s) {
   const int64_t gx = psa::ceil_div(M, static_cast<int64_t>(kWaves) * R);
@@ -1201,11 +1207,11 @@ int psa_spmm_minmax_bw_csc(const int64_t* rowptr, const int64_t* colptr,
     mask.grad_value = grad_value;
   }
   const int64_t q = K / 4;
-  if (q <= 4) return launch_fused_masked<4, 1, M_MASK>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
-  if (q <= 8) return launch_fused_masked<8, 2, M_MASK>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
-  if (q <= 16) return launch_fused_masked<16, 4, M_MASK>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
-  if (q <= 32) return launch_fused_masked<32, 4, M_MASK>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
-  return launch_fused_masked<64, 8, M_MASK>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
+  if (q <= 4) return launch_fused_masked<4, 1, M_MASK>(colptr, row_csc, value, grad, OutView{grad_mat, K}, N, K, nnz, mask, w, s);
+  if (q <= 8) return launch_fused_masked<8, 2, M_MASK>(colptr, row_csc, value, grad, OutView{grad_mat, K}, N, K, nnz, mask, w, s);
+  if (q <= 16) return launch_fused_masked<16, 4, M_MASK>(colptr, row_csc, value, grad, OutView{grad_mat, K}, N, K, nnz, mask, w, s);
+  if (q <= 32) return launch_fused_masked<32, 4, M_MASK>(colptr, row_csc, value, grad, OutView{grad_mat, K}, N, K, nnz, mask, w, s);
+  return launch_fused_masked<64, 8, M_MASK>(colptr, row_csc, value, grad, OutView{grad_mat, K}, N, K, nnz, mask, w, s);
 }
 
 size_t psa_spmm_sum_bw_csc_workspace_bytes(int64_t K, int64_t nnz) {
@@ -1246,11 +1252,11 @@ int psa_spmm_sum_bw_csc(const int64_t* colptr, const int64_t* row_csc, const int
     mask.grad_value = grad_value;
   }
   const int64_t q = K / 4;
-  if (q <= 4) return launch_fused_masked<4, 1, M_CSC>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
-  if (q <= 8) return launch_fused_masked<8, 2, M_CSC>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
-  if (q <= 16) return launch_fused_masked<16, 4, M_CSC>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
-  if (q <= 32) return launch_fused_masked<32, 4, M_CSC>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
-  return launch_fused_masked<64, 8, M_CSC>(colptr, row_csc, value, grad, grad_mat, N, K, nnz, mask, w, s);
+  if (q <= 4) return launch_fused_masked<4, 1, M_CSC>(colptr, row_csc, value, grad, OutView{grad_mat, K}, N, K, nnz, mask, w, s);
+  if (q <= 8) return launch_fused_masked<8, 2, M_CSC>(colptr, row_csc, value, grad, OutView{grad_mat, K}, N, K, nnz, mask, w, s);
+  if (q <= 16) return launch_fused_masked<16, 4, M_CSC>(colptr, row_csc, value, grad, OutView{grad_mat, K}, N, K, nnz, mask, w, s);
+  if (q <= 32) return launch_fused_masked<32, 4, M_CSC>(colptr, row_csc, value, grad, OutView{grad_mat, K}, N, K, nnz, mask, w, s);
+  return launch_fused_masked<64, 8, M_CSC>(colptr, row_csc, value, grad, OutView{grad_mat, K}, N, K, nnz, mask, w, s);
 }
 
 size_t psa_spmm_workspace_bytes(int reduce, int64_t K, int64_t nnz) {
@@ -1269,7 +1275,7 @@ namespace {
 // arg_bytes (only the fused-roles path does, the caller compresses otherwise).
 int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* row, const int64_t* col,
                   const float* value, const float* mat, int64_t M, int64_t N,
-                  int64_t K, int64_t nnz, float* out, int64_t* arg_out,
+                  int64_t K, int64_t nnz, OutView out, int64_t* arg_out,
                   void* workspace, size_t workspace_bytes, hipStream_t s,
                   uint8_t* arg_bytes, bool* bytes_done, int algo) {
   PSA_REQUIRE(reduce >= PSA_SUM && reduce <= PSA_MAX, "bad reduce");
@@ -1277,7 +1283,8 @@ int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* row, const i
   PSA_REQUIRE(M >= 0 && N >= 0 && K >= 0 && nnz >= 0, "negative size");
   if (M == 0 || K == 0) return PSA_OK;
   PSA_REQUIRE(rowptr != nullptr, "rowptr is NULL");
-  PSA_REQUIRE(out != nullptr, "out is NULL");
+  PSA_REQUIRE(out.p != nullptr, "out is NULL");
+  PSA_REQUIRE(out.ld >= K, "ldo must be at least K");
   PSA_REQUIRE(nnz == 0 || (col != nullptr && mat != nullptr),
               "col/mat is NULL");
   const bool minmax = reduce == PSA_MIN || reduce == PSA_MAX;
@@ -1288,11 +1295,11 @@ int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* row, const i
   // Variants 30-33 force it (31-33 with ranges of 128 / 512 / 1024 edges).
   const bool eb_forced = (g_variant >= 30 && g_variant <= 36) || (algo == PSA_SPMM_EDGE_RANGES && g_variant == 0);
   if (eb_forced && workspace != nullptr && N < (1ll << 31) && nnz > 0 && K % 4 == 0 && psa::aligned(mat, 16) &&
-      psa::aligned(out, 16) && psa::eb_supported(M, K, nnz)) {
+      psa::aligned(out.p, 16) && out.ld % 4 == 0 && psa::eb_supported(M, K, nnz)) {
     *bytes_done = arg_bytes != nullptr && minmax;
     const bool nt_gather = N * K * 4 >= kNtGatherBytes;
     const int range_len = g_variant == 31 ? 128 : g_variant == 32 ? 512 : g_variant == 33 ? 1024 : 0;
-    return psa::launch_spmm_eb(red, mean, rowptr, row, col, value, mat, out, arg_out,
+    return psa::launch_spmm_eb(red, mean, rowptr, row, col, value, mat, out.p, out.ld, arg_out,
                                minmax ? arg_bytes : nullptr, M, N, K, nnz, workspace, workspace_bytes,
                                nt_gather, range_len, g_variant == 34 ? 1 : g_variant == 35 ? 2 : g_variant == 36 ? 4 : 0, s);
   }
@@ -1315,7 +1322,7 @@ int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* row, const i
   return launch_row<VEC, LPR, U>(red, rowptr, col, value, mat, out, arg_out, \
                                  M, K, nnz, mean, w, s)
 
-  const bool v4 = (K % 4 == 0) && psa::aligned(mat, 16) && psa::aligned(out, 16);
+  const bool v4 = (K % 4 == 0) && psa::aligned(mat, 16) && psa::aligned(out.p, 16) && out.ld % 4 == 0;
   if (v4) {
     const int64_t q = K / 4;  // float4 per row
     if (g_variant == 2 && K % 128 == 0 && psa::aligned(mat, 8)) PSA_ROW(2, 64, 8);
@@ -1397,13 +1404,13 @@ int psa_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
              int64_t K, int64_t nnz, float* out, int64_t* arg_out,
              uint8_t* arg_bytes, void* workspace, size_t workspace_bytes,
              psa_stream_t stream) {
-  return psa_spmm_coo(reduce, rowptr, nullptr, col, value, mat, M, N, K, nnz, out, arg_out, arg_bytes,
+  return psa_spmm_coo(reduce, rowptr, nullptr, col, value, mat, M, N, K, nnz, out, 0, arg_out, arg_bytes,
                       PSA_SPMM_AUTO, workspace, workspace_bytes, stream);
 }
 
 int psa_spmm_coo(int reduce, const int64_t* rowptr, const int64_t* row, const int64_t* col,
                  const float* value, const float* mat, int64_t M, int64_t N,
-                 int64_t K, int64_t nnz, float* out, int64_t* arg_out,
+                 int64_t K, int64_t nnz, float* out, int64_t ldo, int64_t* arg_out,
                  uint8_t* arg_bytes, int algo, void* workspace, size_t workspace_bytes,
                  psa_stream_t stream) {
   const bool minmax = reduce == PSA_MIN || reduce == PSA_MAX;
@@ -1413,7 +1420,7 @@ int psa_spmm_coo(int reduce, const int64_t* rowptr, const int64_t* row, const in
   }
   hipStream_t s = psa::as_stream(stream);
   bool bytes_done = false;
-  const int st = spmm_dispatch(reduce, rowptr, row, col, value, mat, M, N, K, nnz, out, arg_out, workspace,
+  const int st = spmm_dispatch(reduce, rowptr, row, col, value, mat, M, N, K, nnz, OutView{out, ldo > 0 ? ldo : K}, arg_out, workspace,
                                workspace_bytes, s, arg_bytes, &bytes_done, algo);
   if (st != PSA_OK || arg_bytes == nullptr || !minmax || bytes_done || M == 0 || K == 0) return st;
   // the kernel that ran keeps arg_out only: one more pass turns it into bytes

@@ -60,6 +60,7 @@ struct EbArgs {
   float* part_val;    // [2 * ranges, K]: slot 2r = head partial of range r, 2r + 1 = tail partial
   int64_t* part_arg;  // same shape, winners' edge ids (min/max with tracking)
   int64_t M, K, nnz, num_ranges;
+  int64_t ldo;        // floats between output rows (>= K: out may be a column slice of a wider matrix)
   int range_len;      // edges per range, a multiple of LPR
   unsigned fill_blocks;
   int mean;
@@ -99,7 +100,7 @@ __device__ __forceinline__ void eb_fill_role(const EbArgs& a) {
       if (mine >= 0) {
         const int64_t rr = r0 + mine;
         for (int64_t q = q0; q < K4; q += P) {
-          store_vec_nt<4>(a.out + rr * a.K + 4 * q, zero);
+          store_vec_nt<4>(a.out + rr * a.ldo + 4 * q, zero);
           if (a.minmax) {
             if (a.arg_out) store_arg_nt<4>(a.arg_out + rr * a.K + 4 * q, sentinel);
             if (a.arg_bytes) __builtin_nontemporal_store(0u, reinterpret_cast<uint32_t*>(a.arg_bytes + rr * a.K + 4 * q));
@@ -150,8 +151,8 @@ __device__ __forceinline__ void eb_store_row(const EbArgs& a, int64_t row, int64
     store_vec_nt<4>(a.part_val + (row & 4095) * a.K + k0, acc);
     return;
   }
-  if (a.dbg & 2) store_vec<4>(a.out + row * a.K + k0, acc);
-  else store_vec_nt<4>(a.out + row * a.K + k0, acc);
+  if (a.dbg & 2) store_vec<4>(a.out + row * a.ldo + k0, acc);
+  else store_vec_nt<4>(a.out + row * a.ldo + k0, acc);
 }
 
 template <int RED, bool TRACK>
@@ -440,7 +441,7 @@ __global__ void __launch_bounds__(kThreads) spmm_eb_combine_kernel(EbArgs a) {
           if (a.arg_bytes)
             a.arg_bytes[r_last * a.K + k] = static_cast<uint8_t>(((arg[t] - rs) & 127) | (deg > kByteExact ? 0x80 : 0));
         }
-        __builtin_nontemporal_store(acc[t], a.out + r_last * a.K + k);
+        __builtin_nontemporal_store(acc[t], a.out + r_last * a.ldo + k);
       }
     }
   }
@@ -532,7 +533,7 @@ size_t eb_workspace_bytes(bool minmax, int64_t K, int64_t nnz) {
 }
 
 int launch_spmm_eb(int red, int mean, const int64_t* rowptr, const int64_t* row,
-                   const int64_t* col, const float* val, const float* mat, float* out,
+                   const int64_t* col, const float* val, const float* mat, float* out, int64_t ldo,
                    int64_t* arg_out, uint8_t* arg_bytes, int64_t M, int64_t N, int64_t K,
                    int64_t nnz, void* workspace, size_t workspace_bytes, bool nt_gather,
                    int range_len_override, int dbg, hipStream_t s) {
@@ -561,6 +562,7 @@ int launch_spmm_eb(int red, int mean, const int64_t* rowptr, const int64_t* row,
   a.val = val;
   a.mat = mat;
   a.out = out;
+  a.ldo = ldo;
   a.arg_out = minmax ? arg_out : nullptr;
   a.arg_bytes = minmax ? arg_bytes : nullptr;
   a.M = M;

@@ -49,12 +49,13 @@ split_keys_kernel(const int64_t* __restrict__ keys, int64_t n, int64_t div,
 template <typename T>
 __global__ void __launch_bounds__(kThreads)
 gather_rows_kernel(const T* __restrict__ src, const int64_t* __restrict__ perm,
-                   int64_t n, int64_t chunks, T* __restrict__ out) {
+                   int64_t n, int64_t chunks, int64_t stride, int64_t first, T* __restrict__ out) {
+  // rows of `stride` pieces in src, of which the window [first, first + chunks) is taken
   const int64_t g = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
   if (g >= n * chunks) return;
   const int64_t i = chunks == 1 ? g : g / chunks;
   const int64_t c = chunks == 1 ? 0 : g - i * chunks;
-  out[g] = src[perm[i] * chunks + c];
+  out[g] = src[perm[i] * stride + first + c];
 }
 
 __global__ void __launch_bounds__(kThreads)
@@ -161,13 +162,16 @@ scan_write_kernel(const int64_t* __restrict__ in, int64_t n,
 
 template <typename T>
 int launch_gather(const void* src, const int64_t* perm, int64_t n,
-                  int64_t row_bytes, void* out, hipStream_t s) {
+                  int64_t row_bytes, void* out, hipStream_t s, int64_t src_row_bytes = -1,
+                  int64_t offset_bytes = 0) {
   const int64_t chunks = row_bytes / static_cast<int64_t>(sizeof(T));
+  const int64_t stride = src_row_bytes < 0 ? chunks : src_row_bytes / static_cast<int64_t>(sizeof(T));
+  const int64_t first = offset_bytes / static_cast<int64_t>(sizeof(T));
   const int64_t blocks = psa::ceil_div(n * chunks, kThreads);
   PSA_REQUIRE(blocks <= 0x7fffffff, "too many elements for one launch");
   hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(static_cast<unsigned>(blocks)),
                      dim3(kThreads), 0, s, static_cast<const T*>(src), perm, n,
-                     chunks, static_cast<T*>(out));
+                     chunks, stride, first, static_cast<T*>(out));
   PSA_LAUNCH_CHECK();
   return PSA_OK;
 }
@@ -219,6 +223,22 @@ int psa_gather_rows(const void* src, const int64_t* perm, int64_t n,
   if (row_bytes % 2 == 0 && psa::aligned(src, 2) && psa::aligned(out, 2))
     return launch_gather<uint16_t>(src, perm, n, row_bytes, out, s);
   return launch_gather<uint8_t>(src, perm, n, row_bytes, out, s);
+}
+
+int psa_gather_rows_window(const void* src, int64_t src_row_bytes, int64_t offset_bytes,
+                           int64_t width_bytes, const int64_t* perm, int64_t n, void* out,
+                           psa_stream_t stream) {
+  PSA_REQUIRE(n >= 0 && width_bytes >= 0 && offset_bytes >= 0, "negative size");
+  PSA_REQUIRE(offset_bytes + width_bytes <= src_row_bytes, "window exceeds the source row");
+  if (n == 0 || width_bytes == 0) return PSA_OK;
+  PSA_REQUIRE(src && perm && out, "NULL pointer");
+  hipStream_t s = psa::as_stream(stream);
+  const int64_t all = src_row_bytes | offset_bytes | width_bytes;
+  if (all % 16 == 0 && psa::aligned(src, 16) && psa::aligned(out, 16))
+    return launch_gather<float4>(src, perm, n, width_bytes, out, s, src_row_bytes, offset_bytes);
+  if (all % 4 == 0 && psa::aligned(src, 4) && psa::aligned(out, 4))
+    return launch_gather<uint32_t>(src, perm, n, width_bytes, out, s, src_row_bytes, offset_bytes);
+  return launch_gather<uint8_t>(src, perm, n, width_bytes, out, s, src_row_bytes, offset_bytes);
 }
 
 int psa_bincount(const int64_t* index, int64_t n, int64_t size, int64_t* out,

@@ -95,7 +95,8 @@ def ptr2ind(ptr: torch.Tensor, E: int) -> torch.Tensor:
 
 def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
           value: Optional[torch.Tensor], mat: torch.Tensor, want_arg_bytes: bool = False,
-          want_arg: bool = True, row: Optional[torch.Tensor] = None, algo: str = "auto"):
+          want_arg: bool = True, row: Optional[torch.Tensor] = None, algo: str = "auto",
+          out: Optional[torch.Tensor] = None):
     """(out, arg_out | None) — and, with want_arg_bytes (min/max, K % 4 == 0), a
     third result: arg_out as row-local byte indices for spmm_minmax_bw_csc.
     want_arg=False (min/max) skips the int64 arg_out altogether: the kernel then
@@ -104,8 +105,10 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
     by the bytes alone (no row longer than ARG_BYTES_EXACT_ROW entries).
     `row` (the COO row ids, SparseStorage.row()) is optional: the edge-balanced
     kernels read it and derive it from rowptr when it is not given.  `algo`:
-    "auto" | "row_waves" | "edge_ranges" (psa_spmm_algo; csr_row_stats / 
-    SparseStorage._spmm_algo() choose per matrix)."""
+    "auto" | "row_waves" | "edge_ranges" (psa_spmm_algo; csr_row_stats /
+    SparseStorage._spmm_algo() choose per matrix).  `out`: write into this
+    fp32 [M, K] tensor, which may be a column slice of a wider contiguous
+    matrix (row stride = the wider matrix's width)."""
     rowptr = _index(rowptr, "rowptr")
     col = _index(col, "col")
     if row is not None:
@@ -127,7 +130,16 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
         raise ValueError("rowptr must have at least one element")
     M, (N, K), nnz = rowptr.numel() - 1, mat.shape, col.numel()
     rid = REDUCE_ID[reduce]
-    out = torch.empty((M, K), dtype=torch.float32, device=mat.device)
+    ldo = 0
+    if out is None:
+        out = torch.empty((M, K), dtype=torch.float32, device=mat.device)
+    else:
+        _gpu(out, "out")
+        if out.dtype != torch.float32 or out.shape != (M, K) or (K > 1 and out.stride(1) != 1):
+            raise ValueError("out must be float32 [M, K] with unit column stride")
+        ldo = out.stride(0) if M > 1 else K
+        if ldo < K:
+            raise ValueError("out rows overlap")
     arg = None
     minmax = rid in (_lib.MIN, _lib.MAX)
     lib = _lib.load()
@@ -146,7 +158,7 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
         arg_bytes = torch.empty((M, K), dtype=torch.uint8, device=mat.device)
     with _on(mat.device):
         check(lib.psa_spmm_coo(rid, _ptr(rowptr), _ptr(row), _ptr(col), _ptr(value), _ptr(mat),
-                               M, N, K, nnz, _ptr(out), _ptr(arg), _ptr(arg_bytes),
+                               M, N, K, nnz, _ptr(out), ldo, _ptr(arg), _ptr(arg_bytes),
                                _lib.SPMM_ALGO_ID[algo], _ptr(ws), ws_bytes, _stream()))
     if want_arg_bytes:
         return out, arg, arg_bytes
@@ -489,6 +501,27 @@ def _gather_rows_raw(src: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
         row_bytes *= s
     with _on(src.device):
         check(_lib.load().psa_gather_rows(_ptr(src), _ptr(perm), n, row_bytes, _ptr(out), _stream()))
+    return out
+
+
+def gather_rows_window(src: torch.Tensor, perm: torch.Tensor, col0: int, width: int,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """src[perm, col0:col0 + width] for a 2-D contiguous src, as a dense [n, width]
+    tensor (into `out` when given): rows and feature slice packed in one pass."""
+    _gpu(src, "src")
+    perm = _index(perm, "perm")
+    if src.dim() != 2 or not src.is_contiguous():
+        raise ValueError("src must be a contiguous 2-D tensor")
+    if not (0 <= col0 and col0 + width <= src.shape[1]):
+        raise ValueError("column window outside src")
+    n, es = perm.numel(), src.element_size()
+    if out is None:
+        out = torch.empty((n, width), dtype=src.dtype, device=src.device)
+    elif out.shape != (n, width) or out.dtype != src.dtype or not out.is_contiguous():
+        raise ValueError("out must be a contiguous [n, width] tensor of src's dtype")
+    with _on(src.device):
+        check(_lib.load().psa_gather_rows_window(_ptr(src), src.shape[1] * es, col0 * es, width * es, _ptr(perm), n,
+                                                 _ptr(out), _stream()))
     return out
 
 

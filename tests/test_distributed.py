@@ -1,8 +1,11 @@
 """CPU suite, world_size 2 over gloo: the N > 1 path of the row-partitioned
-SpMM — nnz-balanced row partition, CSR sharding, the all-gather of B and the
-concatenation of per-rank outputs.  The rank-local kernel is the HIP SpMM in
-production; here (no GPU) the oracle is plugged in AS THE CHECKER through the
-`local_spmm` test hook, so what is verified is everything around the kernel."""
+SpMM — nnz-balanced row partition, CSR sharding, both exchanges of B (one
+all-gather of everything; the halo form: one all_to_all_single of only the rows
+a rank's columns touch, column ids remapped) and the in-place feature slices.
+The rank-local kernel is the HIP SpMM in production; here (no GPU) the oracle
+is plugged in AS THE CHECKER through the `local_spmm` test hook, so what is
+verified is everything around the kernel.  A world-1 run on the device with
+the real HIP kernel is at the end (marked gpu)."""
 import os
 import socket
 import sys
@@ -25,12 +28,16 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _oracle_local_spmm(reduce, rowptr, col, value, mat):
+def _oracle_local_spmm(reduce, rowptr, col, value, mat, out=None):
     import oracle
 
-    out, _ = oracle.spmm(reduce, rowptr.numpy(), col.numpy(),
-                         None if value is None else value.numpy(), mat.numpy())
-    return torch.from_numpy(out)
+    res, _ = oracle.spmm(reduce, rowptr.numpy(), col.numpy(),
+                         None if value is None else value.numpy(), mat.contiguous().numpy())
+    res = torch.from_numpy(res)
+    if out is None:
+        return res
+    out.copy_(res)  # a column slice of the caller's output matrix
+    return out
 
 
 def _worker(rank, world, port, M, N, nnz, F, reduce, balance, result_path):
@@ -66,9 +73,30 @@ def _worker(rank, world, port, M, N, nnz, F, reduce, balance, result_path):
         out_local = op(b_local)
         ref, _ = oracle.spmm(reduce, rowptr, col, val, B)
         assert np.array_equal(out_local.numpy(), ref[s.row_begin:s.row_end])
-        # column-sliced form (all-gathers queued up front, SpMM per slice)
+        # column-sliced form (all-gathers queued up front, SpMM per slice, written in place)
         out_sliced = op(b_local, feature_chunks=5)
         assert np.array_equal(out_sliced.numpy(), out_local.numpy())
+        assert op.rows_received_per_step() == (world - 1) * pd.dense_block_rows(N, world)
+
+        # halo exchange: only the rows of B this rank's columns touch travel; same bits
+        halo = pd.RowPartitionedSpMM(s, reduce=reduce, local_spmm=_oracle_local_spmm, exchange="halo")
+        out_halo = halo(b_local)
+        assert np.array_equal(out_halo.numpy(), out_local.numpy())
+        assert np.array_equal(halo(b_local, feature_chunks=3).numpy(), out_local.numpy())
+        assert np.array_equal(halo.spmm_only(halo.exchange_only(b_local)).numpy(), out_local.numpy())
+        nb = pd.dense_block_rows(N, world)
+        mine = np.unique(col[e0:e1])
+        h = halo.halo
+        assert h.num_needed == mine.size and sum(h.need_counts) == mine.size
+        assert h.need_counts == [int(((mine // nb) == p).sum()) for p in range(world)]
+        assert halo.rows_received_per_step() == int(((mine // nb) != rank).sum())
+        assert halo.bytes_received_per_step(F) == halo.rows_received_per_step() * F * 4
+        assert halo.rows_received_per_step() <= op.rows_received_per_step()
+        # what I send to q is what q needs from me: check through a gather of the counts
+        counts = [torch.zeros(world, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(counts, torch.tensor(h.need_counts))
+        assert h.send_counts == [int(counts[q][rank]) for q in range(world)]
+        assert np.array_equal(mine[h.col_local.numpy()], col[e0:e1])
         full = pd.gather_rows_to_root(out_local, bounds)
         if rank == 0:
             assert np.array_equal(full.numpy(), ref)
@@ -91,6 +119,87 @@ def test_row_partitioned_spmm_world2_gloo(tmp_path, reduce, balance, N):
     assert sum(share) > 0
     if balance == "nnz":  # two 500-edge rows dominate: nnz balance must split them apart
         assert max(share) <= 0.75 * sum(share)
+
+
+def _worker_skewed_halo(rank, world, port, result_path):
+    """Banded graph with a few hub columns: most of a rank's columns are its own
+    rows' neighbours, so the halo is a small fraction of B; results identical."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        from paddle_sparse_amd import distributed as pd
+
+        rng = np.random.default_rng(5)
+        M = N = 600
+        F = 16
+        row = np.repeat(np.arange(M), 8)
+        col = (row + rng.integers(-20, 21, row.size)) % N          # a band around the diagonal
+        col[rng.random(row.size) < 0.05] = rng.integers(0, 4, 1)    # ... plus hub columns 0-3
+        order = np.lexsort((col, row))
+        row, col = row[order], col[order]
+        val = rng.standard_normal(row.size).astype(np.float32)
+        rowptr = np.searchsorted(row, np.arange(M + 1)).astype(np.int64)
+        B = rng.standard_normal((N, F)).astype(np.float32)
+        args = (torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val), N)
+        full = pd.RowPartitionedSpMM.from_global(*args, local_spmm=_oracle_local_spmm)
+        halo = pd.RowPartitionedSpMM.from_global(*args, local_spmm=_oracle_local_spmm, exchange="halo")
+        b_local = full.local_dense_block(torch.from_numpy(B))
+        a, b = full(b_local), halo(b_local)
+        assert np.array_equal(a.numpy(), b.numpy())
+        ref, _ = oracle.spmm("sum", rowptr, col, val, B)
+        assert np.array_equal(a.numpy(), ref[full.shard.row_begin:full.shard.row_end])
+        if rank == 0:
+            Path(result_path).write_text(f"{halo.rows_received_per_step()},{full.rows_received_per_step()}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_halo_exchange_moves_a_fraction_of_b_on_a_graph_with_locality(tmp_path):
+    import oracle
+
+    oracle.build()
+    result = tmp_path / "rows.txt"
+    mp.spawn(_worker_skewed_halo, args=(2, _free_port(), str(result)), nprocs=2, join=True)
+    halo_rows, full_rows = map(int, result.read_text().split(","))
+    assert full_rows == 300 and halo_rows < 0.25 * full_rows  # the band's overhang (wrap-around) and the hubs
+
+
+@pytest.mark.gpu
+def test_row_partitioned_spmm_world1_on_the_device():
+    """The multi-GPU step with the real HIP kernel as the local op and RCCL as the backend,
+    at the only world size one GPU allows: full and halo exchange, with and without the
+    in-place feature slices, against the single-GPU call."""
+    from paddle_sparse_amd import distributed as pd
+    from paddle_sparse_amd import ops
+    from util import skewed_csr
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        M, N, F = 5000, 3000, 128
+        row, rowptr, col, val = skewed_csr(M, N, seed=3, long_rows=(7, 2500), long_deg=4000)
+        B = torch.from_numpy(np.random.default_rng(2).standard_normal((N, F)).astype(np.float32)).cuda()
+        t_rowptr, t_col, t_val = (torch.from_numpy(x).cuda() for x in (rowptr, col, val))
+        for reduce in ("sum", "mean", "max"):
+            want = ops._spmm(reduce, t_rowptr, t_col, t_val, B, want_arg=False)[0]
+            for exchange in ("full", "halo"):
+                op = pd.RowPartitionedSpMM.from_global(t_rowptr, t_col, t_val, N, reduce=reduce, exchange=exchange)
+                b_local = op.local_dense_block(B)
+                assert torch.equal(op(b_local), want), (reduce, exchange)
+                sliced = op(b_local, feature_chunks=4)  # K = 32 kernels: another summation order for sum / mean
+                if reduce == "max":
+                    assert torch.equal(sliced, want)
+                else:
+                    S = ops._spmm("sum", t_rowptr, t_col, t_val.abs(), B.abs())[0]
+                    assert bool(((sliced - want).abs() <= 1e-5 * S + 1e-30).all())
+                assert torch.equal(op.spmm_only(op.exchange_only(b_local)), want)
+            assert op.halo.num_needed == int(torch.unique(t_col).numel()) and op.rows_received_per_step() == 0
+    finally:
+        dist.destroy_process_group()
 
 
 def test_partition_helpers():
