@@ -130,11 +130,8 @@ class SparseTensor(object):
         return self.storage.rowptr(), self.storage.col(), self.storage.value()
 
     def csc(self):
-        perm = self.storage.csr2csc()
-        value = self.storage.value()
-        if value is not None:
-            value = ops.gather_rows(value, perm)
-        return self.storage.colptr(), self.storage._row_in_csc_order(), value
+        self.storage.csr2csc()  # first: it leaves colptr and row[csr2csc] behind
+        return self.storage.colptr(), self.storage._row_in_csc_order(), self.storage._value_in_csc_order()
 
     # ---- storage inheritance -------------------------------------------------------
     def has_value(self) -> bool:

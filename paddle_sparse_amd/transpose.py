@@ -31,7 +31,7 @@ def t(src: SparseTensor) -> SparseTensor:
         row=None if st._colptr is not None else ops.gather_rows(st.col(), to_csc),
         rowptr=st._colptr,
         col=st._row_in_csc_order(),
-        value=None if value is None else ops.gather_rows(value, to_csc),
+        value=st._value_in_csc_order(),
         csc2csr=to_csc,
         sparse_sizes=(n, m),
     )

@@ -379,3 +379,34 @@ def test_spmm_minmax_bw(reduce, K):
     only_v, none = ops.spmm_minmax_bw(dev(col), dev(val), dev(B), dev(G), dev(arg), want_mat=False)
     # float atomics: summation order differs between launches
     assert none is None and torch.allclose(only_v, gv, rtol=1e-4, atol=1e-5)
+
+
+def test_value_in_csc_order_is_kept_until_either_side_changes():
+    """value[csr2csc] (dim-0 reduction, csc(), t()) is memoised on the storage; an in-place
+    write to the values or to the memoised copy must be seen."""
+    from paddle_sparse_amd import SparseTensor
+
+    rng = np.random.default_rng(8)
+    M, N = 200, 150
+    key = np.unique(rng.integers(0, M * N, 3000))
+    row, col = key // N, key % N
+    val = rng.standard_normal(key.size).astype(np.float32)
+    v = torch.from_numpy(val).cuda()
+    a = SparseTensor(row=torch.from_numpy(row).cuda(), col=torch.from_numpy(col).cuda(), value=v, sparse_sizes=(M, N))
+    a.storage.csr2csc()
+
+    def colsum(values):
+        out = np.zeros(N, np.float64)
+        np.add.at(out, col, values.astype(np.float64))
+        return out
+
+    first = a.sum(0)
+    memo = a.storage._value_csc_memo[2]
+    assert a.storage._value_in_csc_order() is memo and a.csc()[2] is memo
+    np.testing.assert_allclose(first.cpu().numpy(), colsum(val), rtol=1e-5, atol=1e-5)
+    v.mul_(3.0)  # the values change in place: same tensor, new version
+    np.testing.assert_allclose(a.sum(0).cpu().numpy(), colsum(3 * val), rtol=1e-5, atol=1e-5)
+    assert a.storage._value_csc_memo[2] is not memo
+    t = a.t()
+    t.storage.value().add_(1.0)  # the transposed tensor owns what was the memo: written in place
+    np.testing.assert_allclose(a.sum(0).cpu().numpy(), colsum(3 * val), rtol=1e-5, atol=1e-5)
