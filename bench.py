@@ -161,6 +161,12 @@ def breadth(rowptr, col, val, B, reps: int):
         fn = getattr(ops, op)
         fn(rowptr, col, val, B)
         put(f"{op}_fwd", event_ms(lambda: fn(rowptr, col, val, B), reps), nb)
+    # half-width dense operand (bf16 B and out, fp32 sums): 2 F of every (12 + 2 F) bytes per edge
+    Bh = B.to(torch.bfloat16)
+    half_bytes = nnz * (8 + 4 + 2 * F) + M * (8 + 2 * F)
+    ops._spmm("sum", rowptr, col, val, Bh)
+    put("spmm_sum_bf16_fwd", event_ms(lambda: ops._spmm("sum", rowptr, col, val, Bh), reps), half_bytes)
+    del Bh
     row = ops.ptr2ind(rowptr, nnz)
     G = torch.randn(M, F, device=B.device)
     v = val.clone().requires_grad_()

@@ -162,6 +162,27 @@ int psa_spmm_coo(int reduce, const int64_t* rowptr, const int64_t* row,
                  int64_t ldo, int64_t* arg_out, uint8_t* arg_bytes, int algo,
                  void* workspace, size_t workspace_bytes, psa_stream_t stream);
 
+/* psa_spmm with half-width dense operands: mat and out are fp16 (PSA_F16) or
+ * bf16 (PSA_BF16) [N, K] / [M, K] row-major, every product and sum is fp32 and
+ * the result is rounded to the 2-byte type once, on store (round to nearest
+ * even).  The reference parametrises its tests over float16 / bfloat16 / float32
+ * / float64 values (paddle_sparse/testing.py:12-21).  value: fp32[nnz]
+ * (value_dtype = PSA_F32), or `dtype`[nnz] (value_dtype = dtype), or NULL.
+ * arg_out int64[M, K] or NULL (MIN / MAX).  The gathered rows are half as wide:
+ * 2 M x 2 M, 20 M entries, K = 128 moves 6.4 GB instead of 11.5 GB.
+ * Needs K % 8 == 0 and 16-byte aligned mat / out (PSA_ERR_UNSUPPORTED
+ * otherwise: callers widen to fp32 and use psa_spmm).  One wavefront per row,
+ * rows of any length on their own wave (no long-row scratch, no workspace). */
+int psa_spmm_half(int reduce, int dtype, const int64_t* rowptr,
+                  const int64_t* col, const void* value, int value_dtype,
+                  const void* mat, int64_t M, int64_t N, int64_t K, int64_t nnz,
+                  void* out, int64_t* arg_out, psa_stream_t stream);
+
+/* Test/bench hook: 0 = default (one row per wave), 1 = several rows per wave for
+ * K <= 128, 2 = one row per wave with 8 gather steps in flight.  Returns the
+ * previous value. */
+int psa_spmm_half_set_variant(int variant);
+
 /* Row-length statistics of a CSR pointer, for choosing psa_spmm_algo once per
  * matrix (the caller reads the four words back and keeps the answer with the
  * matrix, like the reference keeps rowcount: paddle_sparse/storage.py:373-381).

@@ -173,6 +173,29 @@ PSA_SPMM_OP(spmm_mean, PSA_MEAN)
 PSA_SPMM_OP(spmm_min, PSA_MIN)
 PSA_SPMM_OP(spmm_max, PSA_MAX)
 
+// spmm with fp16 / bf16 dense operands (fp32 sums): `value` fp32 or mat's dtype or absent
+std::vector<paddle::Tensor> spmm_half(paddle::Tensor& rowptr, paddle::Tensor& col,
+                                      const paddle::optional<paddle::Tensor>& value, paddle::Tensor& mat,
+                                      int64_t reduce, bool want_arg) {
+  CHECK_GPU(mat);
+  CHECK_I64(rowptr);
+  CHECK_I64(col);
+  const int64_t M = rowptr.numel() - 1, N = mat.shape()[0], K = mat.shape()[1], nnz = col.numel();
+  const bool minmax = reduce == PSA_MIN || reduce == PSA_MAX;
+  auto out = paddle::empty({M, K}, mat.dtype(), mat.place());
+  auto arg = minmax && want_arg ? paddle::empty({M, K}, paddle::DataType::INT64, mat.place())
+                                : paddle::empty({0}, paddle::DataType::INT64, mat.place());
+  PSA_CALL(psa_spmm_half(static_cast<int>(reduce), dtype_id_of(mat), i64(rowptr), i64(col),
+                         value ? value.get().data() : nullptr, value ? dtype_id_of(value.get()) : 0, mat.data(), M, N, K,
+                         nnz, out.data(), minmax && want_arg ? arg.data<int64_t>() : nullptr, stream_of(mat)));
+  return {out, arg};
+}
+PD_BUILD_OP(spmm_half)
+    .Inputs({"rowptr", "col", paddle::Optional("value"), "mat"})
+    .Outputs({"out", "arg_out"})
+    .Attrs({"reduce: int64_t", "want_arg: bool"})
+    .SetKernelFn(PD_KERNEL(spmm_half));
+
 // {rows without entries, rows of 1-2 entries, rows above 128 entries, longest row}: read once per
 // matrix by the Python layer to pick `algo` (paddle_sparse_amd/storage.py::_spmm_algo).
 std::vector<paddle::Tensor> csr_row_stats(paddle::Tensor& rowptr) {

@@ -36,6 +36,9 @@ SIGNATURES = {
     "psa_spmm_coo": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                              c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p,
                              c_size_t, c_void_p]),
+    "psa_spmm_half": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64,
+                              c_int64, c_void_p, c_void_p, c_void_p]),
+    "psa_spmm_half_set_variant": (c_int, [c_int]),
     "psa_csr_row_stats": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "psa_spmm_set_variant": (c_int, [c_int]),
     "psa_spmm_value_bw_workspace_bytes": (c_size_t, [c_int64]),

@@ -1,0 +1,419 @@
+// CSR x dense SpMM forward with HALF-WIDTH dense operands (fp16 / bf16 `mat` and
+// `out`, fp32 accumulation), gfx950.
+//
+// The reference parametrises its tests over float16 / bfloat16 / float32 /
+// float64 values (paddle_sparse/testing.py:12-21); its SpMM is absent
+// (README.md:47-50), semantics as in spmm.hip.  Why a second dtype on this path:
+// the forward is a pure HBM gather of dense rows, 4 K of every (12 + 4 K) bytes
+// per edge — storing B and the output in 2-byte floats halves the dominant
+// stream, the only ~2x lever left on a kernel that already moves fp32 rows at
+// 0.9 of the HBM peak.  Products and sums are fp32 (the 2-byte inputs are
+// widened exactly; the result is rounded to the 2-byte type once, on store).
+//
+// Same structure as the fp32 row kernels: one wavefront per CSR row, the row's
+// col / value entries read once, coalesced, and handed to the gather loop by
+// cross-lane moves; LPR lanes x 16 bytes (8 elements) cover the K tile, the
+// G = 64 / LPR lane groups take different edges of a step (K = 128: 16 lanes per
+// dense row, FOUR edges per global_load_dwordx4 instruction), U steps in flight.
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
+
+enum { R_SUM = 0, R_MIN = 1, R_MAX = 2 };
+
+struct F16 {};
+struct BF16 {};
+
+// 8 packed 2-byte floats (one 16-byte load) -> 8 fp32, exactly
+template <typename T>
+__device__ __forceinline__ void widen8(const uint4& raw, float (&f)[8]) {
+  const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if constexpr (std::is_same<T, BF16>::value) {
+      f[2 * i] = __uint_as_float(w[i] << 16);
+      f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    } else {
+      const __half2 h = *reinterpret_cast<const __half2*>(&w[i]);
+      const float2 v = __half22float2(h);
+      f[2 * i] = v.x;
+      f[2 * i + 1] = v.y;
+    }
+  }
+}
+
+// 8 fp32 -> 8 packed 2-byte floats, round to nearest even
+template <typename T>
+__device__ __forceinline__ uint4 narrow8(const float (&f)[8]) {
+  uint32_t w[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if constexpr (std::is_same<T, BF16>::value) {
+      const __hip_bfloat162 p = __float22bfloat162_rn(make_float2(f[2 * i], f[2 * i + 1]));
+      w[i] = *reinterpret_cast<const uint32_t*>(&p);
+    } else {
+      const __half2 p = __floats2half2_rn(f[2 * i], f[2 * i + 1]);
+      w[i] = *reinterpret_cast<const uint32_t*>(&p);
+    }
+  }
+  return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <typename T>
+__device__ __forceinline__ float widen1(const void* p, int64_t i) {
+  const uint16_t h = static_cast<const uint16_t*>(p)[i];
+  if constexpr (std::is_same<T, BF16>::value) return __uint_as_float(static_cast<uint32_t>(h) << 16);
+  else return __half2float(*reinterpret_cast<const __half*>(&h));
+}
+
+__device__ __forceinline__ int64_t shfl_i64(int64_t x, int src) {
+  return __shfl(static_cast<long long>(x), src);
+}
+
+// value: fp32[nnz] (VAL32) or the same 2-byte type as mat, or NULL (weights 1)
+template <typename T, int LPR, int RED, int U, bool TRACK, bool VAL32>
+__global__ void __launch_bounds__(kThreads)
+spmm_half_row_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col,
+                     const void* __restrict__ val, const uint16_t* __restrict__ mat,
+                     uint16_t* __restrict__ out, int64_t* __restrict__ arg_out, int64_t M, int64_t K,
+                     int64_t nnz, int mean) {
+  constexpr int G = 64 / LPR;
+  static_assert(64 % (G * U) == 0, "edge batch must divide the wave");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * kWaves + wave;
+  if (row >= M) return;
+  const int g = lane / LPR;
+  const int l = lane % LPR;
+  const int64_t k0 = (static_cast<int64_t>(blockIdx.y) * LPR + l) * 8;
+  const bool kact = k0 < K;  // K % 8 == 0 (dispatch guarantees it)
+  const uint16_t* matk = mat + k0;
+  const int64_t s = rowptr[row], e = rowptr[row + 1];
+
+  float acc[8];
+  int64_t arg[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    acc[i] = RED == R_SUM ? 0.f : (RED == R_MAX ? -__FLT_MAX__ : __FLT_MAX__);
+    arg[i] = nnz;
+  }
+  for (int64_t base = s; base < e; base += 64) {
+    const int n = (e - base) < 64 ? static_cast<int>(e - base) : 64;
+    int64_t c_l = 0;
+    float v_l = 1.f;
+    if (lane < n) {
+      c_l = col[base + lane];
+      if (val != nullptr) v_l = VAL32 ? static_cast<const float*>(val)[base + lane] : widen1<T>(val, base + lane);
+    }
+    for (int j = 0; j < n; j += G * U) {
+      uint4 raw[U];
+      float w[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = j + u * G + g;  // < 64
+        const int64_t c = shfl_i64(c_l, idx);
+        w[u] = __shfl(v_l, idx);
+        ok[u] = (idx < n) && kact;
+        raw[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (ok[u]) raw[u] = *reinterpret_cast<const uint4*>(matk + c * K);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        float b[8];
+        widen8<T>(raw[u], b);
+        if (RED == R_SUM) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[i] += w[u] * b[i];  // a masked slot adds w * 0
+        } else if (ok[u]) {
+          const int64_t eid = base + j + u * G + g;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const float x = w[u] * b[i];
+            const bool better = RED == R_MAX ? (x > acc[i]) : (x < acc[i]);
+            if (better) {
+              acc[i] = x;
+              if (TRACK) arg[i] = eid;
+            }
+          }
+        }
+      }
+    }
+  }
+  // fold the G edge slots
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float o = __shfl_xor(acc[i], off);
+      if (RED == R_SUM) {
+        acc[i] += o;
+      } else if (!TRACK) {
+        if (RED == R_MAX ? (o > acc[i]) : (o < acc[i])) acc[i] = o;
+      } else {
+        const int64_t oa = shfl_i64(arg[i], lane ^ off);
+        const bool better = RED == R_MAX ? (o > acc[i]) : (o < acc[i]);
+        if (better || (o == acc[i] && oa < arg[i])) {  // first winner in edge order
+          acc[i] = o;
+          arg[i] = oa;
+        }
+      }
+    }
+  }
+  if (g == 0 && kact) {
+    const int64_t deg = e - s;
+    if (RED == R_SUM) {
+      if (mean && deg > 1) {
+        const float d = static_cast<float>(deg);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = acc[i] / d;
+      }
+    } else {
+      if (deg == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+      }
+      if (TRACK && arg_out != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+          typedef long V2 __attribute__((ext_vector_type(2)));
+          V2 v;
+          v[0] = arg[i];
+          v[1] = arg[i + 1];
+          __builtin_nontemporal_store(v, reinterpret_cast<V2*>(arg_out + row * K + k0 + i));
+        }
+      }
+    }
+    const uint4 packed = narrow8<T>(acc);
+    typedef unsigned int U4 __attribute__((ext_vector_type(4)));
+    U4 st;
+    st[0] = packed.x;
+    st[1] = packed.y;
+    st[2] = packed.z;
+    st[3] = packed.w;
+    __builtin_nontemporal_store(st, reinterpret_cast<U4*>(out + row * K + k0));
+  }
+}
+
+// A/B variant (psa_spmm_half_set_variant(1)), K <= 128: G = 64 / LPR ROWS per wave, as the
+// fp32 multirow kernel does for K <= 64 — every lane group owns a whole CSR row and walks its
+// edges in order with U gathers in flight.  Measured on config 3 in bf16: 1.45 ms against
+// 1.02 ms for one row per wave (whose col / value reads are coalesced), so it is not the default.
+template <typename T, int LPR, int RED, int U, bool TRACK, bool VAL32>
+__global__ void __launch_bounds__(kThreads)
+spmm_half_multirow_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col,
+                          const void* __restrict__ val, const uint16_t* __restrict__ mat,
+                          uint16_t* __restrict__ out, int64_t* __restrict__ arg_out, int64_t M, int64_t K,
+                          int64_t nnz, int mean) {
+  constexpr int G = 64 / LPR;
+  const int lane = threadIdx.x & 63;
+  const int g = lane / LPR;
+  const int l = lane % LPR;
+  const int64_t row = (static_cast<int64_t>(blockIdx.x) * kWaves + (threadIdx.x >> 6)) * G + g;
+  const int64_t k0 = static_cast<int64_t>(l) * 8;
+  if (row >= M || k0 >= K) return;  // no wave-level operation below
+  const uint16_t* matk = mat + k0;
+  const int64_t s = rowptr[row], e = rowptr[row + 1];
+  float acc[8];
+  int64_t arg[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    acc[i] = RED == R_SUM ? 0.f : (RED == R_MAX ? -__FLT_MAX__ : __FLT_MAX__);
+    arg[i] = nnz;
+  }
+  for (int64_t p = s; p < e; p += U) {
+    uint4 raw[U];
+    float w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      w[u] = 0.f;
+      raw[u] = make_uint4(0u, 0u, 0u, 0u);
+      if (p + u < e) {
+        const int64_t c = col[p + u];
+        w[u] = val == nullptr ? 1.f : (VAL32 ? static_cast<const float*>(val)[p + u] : widen1<T>(val, p + u));
+        raw[u] = *reinterpret_cast<const uint4*>(matk + c * K);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float b[8];
+      widen8<T>(raw[u], b);
+      if (RED == R_SUM) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] += w[u] * b[i];
+      } else if (p + u < e) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float x = w[u] * b[i];
+          const bool better = RED == R_MAX ? (x > acc[i]) : (x < acc[i]);
+          if (better) {
+            acc[i] = x;
+            if (TRACK) arg[i] = p + u;
+          }
+        }
+      }
+    }
+  }
+  const int64_t deg = e - s;
+  if (RED == R_SUM) {
+    if (mean && deg > 1) {
+      const float d = static_cast<float>(deg);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = acc[i] / d;
+    }
+  } else {
+    if (deg == 0) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    }
+    if (TRACK && arg_out != nullptr) {
+#pragma unroll
+      for (int i = 0; i < 8; i += 2) {
+        typedef long V2 __attribute__((ext_vector_type(2)));
+        V2 v;
+        v[0] = arg[i];
+        v[1] = arg[i + 1];
+        __builtin_nontemporal_store(v, reinterpret_cast<V2*>(arg_out + row * K + k0 + i));
+      }
+    }
+  }
+  const uint4 packed = narrow8<T>(acc);
+  typedef unsigned int U4 __attribute__((ext_vector_type(4)));
+  U4 st;
+  st[0] = packed.x;
+  st[1] = packed.y;
+  st[2] = packed.z;
+  st[3] = packed.w;
+  __builtin_nontemporal_store(st, reinterpret_cast<U4*>(out + row * K + k0));
+}
+
+int g_half_variant = 0;  // A/B hook: 0 = one row per wave (U = 4 at K = 128), 1 = several rows per wave for K <= 128, 2 = one row per wave with U = 8
+
+template <typename T, int LPR, int U>
+int launch_half_multirow(int red, bool track, bool val32, const int64_t* rowptr, const int64_t* col, const void* val,
+                         const uint16_t* mat, uint16_t* out, int64_t* arg_out, int64_t M, int64_t K, int64_t nnz,
+                         int mean, hipStream_t s) {
+  const int64_t gx = psa::ceil_div(M, static_cast<int64_t>(kWaves) * (64 / LPR));
+  PSA_REQUIRE(gx <= 0x7fffffff, "problem too large for one launch");
+  const dim3 grid(static_cast<unsigned>(gx)), block(kThreads);
+#define PSA_H(R, TR, V32)                                                                                   \
+  hipLaunchKernelGGL((spmm_half_multirow_kernel<T, LPR, R, U, TR, V32>), grid, block, 0, s, rowptr, col, val, mat, \
+                     out, arg_out, M, K, nnz, mean)
+#define PSA_HV(R, TR)              \
+  do {                             \
+    if (val32) PSA_H(R, TR, true); \
+    else PSA_H(R, TR, false);      \
+  } while (0)
+  if (red == R_SUM) PSA_HV(R_SUM, false);
+  else if (red == R_MIN) {
+    if (track) PSA_HV(R_MIN, true);
+    else PSA_HV(R_MIN, false);
+  } else {
+    if (track) PSA_HV(R_MAX, true);
+    else PSA_HV(R_MAX, false);
+  }
+#undef PSA_HV
+#undef PSA_H
+  PSA_LAUNCH_CHECK();
+  return PSA_OK;
+}
+
+template <typename T, int LPR, int U>
+int launch_half(int red, bool track, bool val32, const int64_t* rowptr, const int64_t* col, const void* val,
+                const uint16_t* mat, uint16_t* out, int64_t* arg_out, int64_t M, int64_t K, int64_t nnz, int mean,
+                hipStream_t s) {
+  const int64_t gx = psa::ceil_div(M, kWaves);
+  const int64_t gy = psa::ceil_div(K, static_cast<int64_t>(LPR) * 8);
+  PSA_REQUIRE(gx <= 0x7fffffff && gy <= 65535, "problem too large for one launch");
+  const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(gy)), block(kThreads);
+#define PSA_H(R, TR, V32)                                                                              \
+  hipLaunchKernelGGL((spmm_half_row_kernel<T, LPR, R, U, TR, V32>), grid, block, 0, s, rowptr, col, val, mat, out, \
+                     arg_out, M, K, nnz, mean)
+#define PSA_HV(R, TR)        \
+  do {                       \
+    if (val32) PSA_H(R, TR, true); \
+    else PSA_H(R, TR, false);      \
+  } while (0)
+  if (red == R_SUM) PSA_HV(R_SUM, false);
+  else if (red == R_MIN) {
+    if (track) PSA_HV(R_MIN, true);
+    else PSA_HV(R_MIN, false);
+  } else {
+    if (track) PSA_HV(R_MAX, true);
+    else PSA_HV(R_MAX, false);
+  }
+#undef PSA_HV
+#undef PSA_H
+  PSA_LAUNCH_CHECK();
+  return PSA_OK;
+}
+
+template <typename T>
+int dispatch_half(int red, bool track, bool val32, const int64_t* rowptr, const int64_t* col, const void* val,
+                  const uint16_t* mat, uint16_t* out, int64_t* arg_out, int64_t M, int64_t K, int64_t nnz, int mean,
+                  hipStream_t s) {
+  const int64_t q = K / 8;  // 16-byte pieces per dense row
+#define PSA_MULTI(LPR, U) return launch_half_multirow<T, LPR, U>(red, track, val32, rowptr, col, val, mat, out, arg_out, M, K, nnz, mean, s)
+  if (g_half_variant == 1) {
+    if (q <= 1) PSA_MULTI(1, 4);
+    if (q <= 2) PSA_MULTI(2, 8);
+    if (q <= 4) PSA_MULTI(4, 8);
+    if (q <= 8) PSA_MULTI(8, 8);
+    if (q <= 16) PSA_MULTI(16, 8);
+  }
+#undef PSA_MULTI
+#define PSA_GO(LPR, U) return launch_half<T, LPR, U>(red, track, val32, rowptr, col, val, mat, out, arg_out, M, K, nnz, mean, s)
+  if (q <= 1) PSA_GO(1, 1);
+  if (q <= 2) PSA_GO(2, 2);
+  if (q <= 4) PSA_GO(4, 4);
+  if (q <= 8) PSA_GO(8, 4);
+  if (q <= 16 && g_half_variant == 2) PSA_GO(16, 8);
+  if (q <= 16) PSA_GO(16, 4);   // K = 128: 4 edges per gather instruction, 16 in flight
+  if (q <= 32) PSA_GO(32, 4);
+  PSA_GO(64, 8);                // wider K: tiles of 512 columns over grid.y
+#undef PSA_GO
+}
+
+}  // namespace
+
+extern "C" int psa_spmm_half_set_variant(int v) {
+  const int prev = g_half_variant;
+  g_half_variant = v;
+  return prev;
+}
+
+extern "C" int psa_spmm_half(int reduce, int dtype, const int64_t* rowptr, const int64_t* col, const void* value,
+                             int value_dtype, const void* mat, int64_t M, int64_t N, int64_t K, int64_t nnz,
+                             void* out, int64_t* arg_out, psa_stream_t stream) {
+  (void)N;
+  PSA_REQUIRE(reduce >= PSA_SUM && reduce <= PSA_MAX, "bad reduce");
+  PSA_REQUIRE(M >= 0 && K >= 0 && nnz >= 0, "negative size");
+  if (dtype != PSA_F16 && dtype != PSA_BF16) {
+    psa::set_error("psa_spmm_half: dtype must be PSA_F16 or PSA_BF16");
+    return PSA_ERR_UNSUPPORTED;
+  }
+  if (K % 8 != 0 || !psa::aligned(mat, 16) || !psa::aligned(out, 16)) {
+    psa::set_error("psa_spmm_half: needs K % 8 == 0 and 16-byte aligned operands");
+    return PSA_ERR_UNSUPPORTED;
+  }
+  PSA_REQUIRE(value == nullptr || value_dtype == PSA_F32 || value_dtype == dtype, "value must be fp32 or mat's dtype");
+  if (M == 0 || K == 0) return PSA_OK;
+  PSA_REQUIRE(rowptr != nullptr && out != nullptr, "NULL pointer");
+  PSA_REQUIRE(nnz == 0 || (col != nullptr && mat != nullptr), "col/mat is NULL");
+  const bool minmax = reduce == PSA_MIN || reduce == PSA_MAX;
+  const int red = reduce == PSA_MIN ? R_MIN : (reduce == PSA_MAX ? R_MAX : R_SUM);
+  const bool track = minmax && arg_out != nullptr;
+  const bool val32 = value != nullptr && value_dtype == PSA_F32;
+  hipStream_t s = psa::as_stream(stream);
+  const uint16_t* m = static_cast<const uint16_t*>(mat);
+  uint16_t* o = static_cast<uint16_t*>(out);
+  if (dtype == PSA_BF16)
+    return dispatch_half<BF16>(red, track, val32, rowptr, col, value, m, o, arg_out, M, K, nnz, reduce == PSA_MEAN, s);
+  return dispatch_half<F16>(red, track, val32, rowptr, col, value, m, o, arg_out, M, K, nnz, reduce == PSA_MEAN, s);
+}

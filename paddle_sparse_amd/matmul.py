@@ -45,6 +45,15 @@ class _SpMM(torch.autograd.Function):
     def forward(ctx, value: Optional[torch.Tensor], mat: torch.Tensor,
                 storage: SparseStorage, reduce: str, track: bool = True):
         rowptr, col = storage.rowptr(), storage.col()
+        if mat.dtype in (torch.float16, torch.bfloat16):
+            # half-width dense operand: 2-byte gathers and stores, fp32 sums (psa_spmm_half).  The
+            # backward runs the fp32 kernels on widened operands and narrows the gradients.
+            need = track and (ctx.needs_input_grad[1] or (value is not None and ctx.needs_input_grad[0]))
+            out, arg = ops._spmm(reduce, rowptr, col, value, mat, want_arg=need and reduce in ("min", "max"))
+            ctx.storage, ctx.reduce, ctx.half = storage, reduce, mat.dtype
+            ctx.save_for_backward(value, mat, arg, None)
+            return out
+        ctx.half = None
         algo = storage._spmm_algo()  # per-matrix choice, read once
         row = storage.row() if algo == "edge_ranges" else None  # the COO row ids the edge-balanced kernels walk
         arg = arg_bytes = None
@@ -76,6 +85,16 @@ class _SpMM(torch.autograd.Function):
         need_value = value is not None and ctx.needs_input_grad[0]
         need_mat = ctx.needs_input_grad[1]
         grad_out = grad_out.contiguous()
+        if ctx.half is not None:
+            gv, gm = _SpMM._backward_fp32(st, reduce, None if value is None else value.float(), mat.float(),
+                                          grad_out.float(), arg, None, need_value, need_mat)
+            return (None if gv is None else gv.to(value.dtype), None if gm is None else gm.to(ctx.half),
+                    None, None, None)
+        gv, gm = _SpMM._backward_fp32(st, reduce, value, mat, grad_out, arg, arg_bytes, need_value, need_mat)
+        return gv, gm, None, None, None
+
+    @staticmethod
+    def _backward_fp32(st, reduce, value, mat, grad_out, arg, arg_bytes, need_value, need_mat):
         grad_value = grad_mat = None
         if reduce in ("min", "max"):
             # With grad_mat wanted and a K tile the kernel takes, both gradients
@@ -104,7 +123,7 @@ class _SpMM(torch.autograd.Function):
                 grad_value, grad_mat = ops.spmm_sum_bw_csc(st.colptr(), st._row_in_csc_order(), csr2csc,
                                                            value, mat, grad_out, True, csc2csr=st.csc2csr(),
                                                            row_scale=scale)
-                return grad_value, grad_mat, None, None, None
+                return grad_value, grad_mat
             if need_value:
                 grad_value = ops.spmm_value_bw(None, st.rowptr(), st.col(), mat, grad_out,
                                                "mean" if mean else "sum")
@@ -115,7 +134,7 @@ class _SpMM(torch.autograd.Function):
                 if value is not None or mean:
                     w = _csc_weights(st, value, csr2csc, row_csc, mean)
                 grad_mat = ops.spmm_sum(st.colptr(), row_csc, w, grad_out)
-        return grad_value, grad_mat, None, None, None
+        return grad_value, grad_mat
 
 
 def spmm_sparse(src: SparseTensor, other: torch.Tensor, reduce: str = "sum") -> torch.Tensor:

@@ -116,8 +116,13 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
         if row.numel() != col.numel():
             raise ValueError("row must have one entry per edge")
     _gpu(mat, "mat")
+    if mat.dtype in (torch.float16, torch.bfloat16):
+        if out is not None or want_arg_bytes:
+            raise ValueError("the half-width SpMM takes neither `out` nor arg_bytes")
+        res = _spmm_half(reduce, rowptr, col, value, mat, want_arg)
+        return res
     if mat.dtype != torch.float32:
-        raise TypeError(f"spmm is fp32 in this build (mat is {mat.dtype})")
+        raise TypeError(f"spmm takes float32, float16 or bfloat16 dense operands (mat is {mat.dtype})")
     if mat.dim() != 2:
         raise ValueError("mat must be 2-D [N, K]")
     mat = mat.contiguous()
@@ -162,6 +167,33 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
                                _lib.SPMM_ALGO_ID[algo], _ptr(ws), ws_bytes, _stream()))
     if want_arg_bytes:
         return out, arg, arg_bytes
+    return out, arg
+
+
+def _spmm_half(reduce: str, rowptr, col, value, mat, want_arg: bool = True):
+    """fp16 / bf16 `mat` -> (out in mat's dtype, arg_out | None): fp32 products and sums,
+    one rounding on store (psa_spmm_half).  value: None, float32[nnz] or mat's dtype[nnz].
+    K % 8 != 0 widens to fp32 and rounds the fp32 kernel's result instead."""
+    if mat.dim() != 2:
+        raise ValueError("mat must be 2-D [N, K]")
+    mat = mat.contiguous()
+    M, (N, K), nnz = rowptr.numel() - 1, mat.shape, col.numel()
+    rid = REDUCE_ID[reduce]
+    minmax = rid in (_lib.MIN, _lib.MAX)
+    if value is not None:
+        _gpu(value, "value")
+        if value.dtype not in (torch.float32, mat.dtype) or value.dim() != 1 or value.numel() != nnz:
+            raise ValueError("value must be float32[nnz] or mat's dtype[nnz]")
+        value = value.contiguous()
+    if K % 8 != 0:
+        res = _spmm(reduce, rowptr, col, None if value is None else value.float(), mat.float(), want_arg=want_arg)
+        return res[0].to(mat.dtype), res[1]
+    out = torch.empty((M, K), dtype=mat.dtype, device=mat.device)
+    arg = torch.empty((M, K), dtype=torch.int64, device=mat.device) if minmax and want_arg else None
+    with _on(mat.device):
+        check(_lib.load().psa_spmm_half(rid, _DTYPE_ID[mat.dtype], _ptr(rowptr), _ptr(col), _ptr(value),
+                                        _DTYPE_ID[value.dtype] if value is not None else 0, _ptr(mat), M, N, K, nnz,
+                                        _ptr(out), _ptr(arg), _stream()))
     return out, arg
 
 

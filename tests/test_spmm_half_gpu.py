@@ -1,0 +1,128 @@
+"""GPU parity: psa_spmm_half (fp16 / bf16 dense operands, fp32 accumulation)
+against the fp32 oracle run on the SAME 2-byte-rounded inputs.
+
+Tolerance, stated: the kernel's fp32 sum is within 1e-5 * S of the oracle's
+(S = sum of the absolute terms, the north-star bar for fp32 reductions) and is
+then rounded ONCE to the 2-byte type: |got - ref| <= 1e-5 * S + eps * |ref| with
+eps = 2^-8 for bf16 (8 significant bits), 2^-11 for fp16 (plus half the fp16
+subnormal spacing, 2^-25, where |ref| < 6.1e-5).  For min / max the
+winner's product is exact in fp32, so out == round(ref) and arg_out is identical
+wherever the fp32 winner is unique."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from util import random_csr, skewed_csr
+
+pytestmark = pytest.mark.gpu
+
+EPS = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}
+TINY = {torch.bfloat16: 0.0, torch.float16: 2.0 ** -25}  # half the subnormal spacing of the 2-byte type
+
+
+def rounded(a, dtype):
+    """float32 numpy array -> (torch 2-byte tensor on the GPU, its exact float32 image)."""
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dtype)
+    return t.cuda(), t.float().numpy()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max"])
+@pytest.mark.parametrize("K", [8, 16, 64, 128, 136, 256, 520])
+@pytest.mark.parametrize("variant", [0, 1, 2])  # one row per wave / several rows per wave (K <= 128) / U = 8
+def test_half_vs_oracle_on_rounded_inputs(dtype, reduce, K, variant):
+    from paddle_sparse_amd import _lib, ops
+
+    if variant != 0 and K > 128:
+        pytest.skip("same kernel as variant 0")
+    _lib.load().psa_spmm_half_set_variant(variant)
+    try:
+        _half_case(dtype, reduce, K)
+    finally:
+        _lib.load().psa_spmm_half_set_variant(0)
+
+
+def _half_case(dtype, reduce, K):
+    from paddle_sparse_amd import ops
+
+    M, N = 700, 500
+    row, rowptr, col, val = skewed_csr(M, N, seed=K, long_rows=(0, 350), long_deg=900)
+    B = np.random.default_rng(K).standard_normal((N, K)).astype(np.float32)
+    Bd, Bf = rounded(B, dtype)
+    d = lambda x: torch.from_numpy(x).cuda()  # noqa: E731
+    for vmode in ("f32", "half", "none"):
+        if vmode == "f32":
+            vd, vf = d(val), val
+        elif vmode == "half":
+            vd, vf = rounded(val, dtype)
+        else:
+            vd, vf = None, None
+        out, arg = ops._spmm(reduce, d(rowptr), d(col), vd, Bd)
+        assert out.dtype == dtype
+        ref, ref_arg = oracle.spmm(reduce, rowptr, col, vf, Bf)
+        S = oracle.spmm_abs_sum(rowptr, col, vf, Bf)
+        got = out.float().cpu().numpy()
+        assert np.all(np.abs(got - ref) <= 1e-5 * S + EPS[dtype] * np.abs(ref) + TINY[dtype] + 1e-30), (vmode, reduce)
+        if reduce in ("min", "max"):
+            want = torch.from_numpy(ref).to(dtype).float().numpy()  # one rounding of the exact winner
+            assert np.array_equal(got, want)
+            assert np.array_equal(arg.cpu().numpy(), ref_arg)
+
+
+def test_half_falls_back_for_odd_widths_and_keeps_autograd():
+    from paddle_sparse_amd import SparseTensor, ops
+
+    row, rowptr, col, val = random_csr(300, 200, 2500, seed=1, sort_cols=True)
+    keep = np.concatenate([[True], (row[1:] != row[:-1]) | (col[1:] != col[:-1])])
+    row, col, val = row[keep], col[keep], val[keep]
+    rowptr = oracle.ind2ptr(row, 300)
+    d = lambda x: torch.from_numpy(x).cuda()  # noqa: E731
+    B = np.random.default_rng(0).standard_normal((200, 12)).astype(np.float32)  # K % 8 != 0: widened path
+    Bd, Bf = rounded(B, torch.bfloat16)
+    out, _ = ops._spmm("sum", d(rowptr), d(col), d(val), Bd)
+    ref, _ = oracle.spmm("sum", rowptr, col, val, Bf)
+    S = oracle.spmm_abs_sum(rowptr, col, val, Bf)
+    assert out.dtype == torch.bfloat16
+    assert np.all(np.abs(out.float().cpu().numpy() - ref) <= 1e-5 * S + 2.0 ** -8 * np.abs(ref) + 1e-30)
+    # autograd: forward in bf16, gradients computed by the fp32 kernels on widened operands
+    B = np.random.default_rng(2).standard_normal((200, 32)).astype(np.float32)
+    G = np.random.default_rng(3).standard_normal((300, 32)).astype(np.float32)
+    Bd, Bf = rounded(B, torch.bfloat16)
+    Gd, Gf = rounded(G, torch.bfloat16)
+    Bt = Bd.clone().requires_grad_()
+    v = d(val).requires_grad_()
+    a = SparseTensor(row=d(row), col=d(col), value=v, sparse_sizes=(300, 200), is_sorted=True)
+    a.matmul(Bt, "sum").backward(Gd)
+    gB = oracle.spmm_mat_bw("sum", row, rowptr, col, val, Gf, 200)
+    sB = oracle.spmm_mat_bw("sum", row, rowptr, col, np.abs(val), np.abs(Gf), 200)
+    gV = oracle.spmm_value_bw("sum", row, rowptr, col, Bf, Gf)
+    sV = oracle.spmm_value_bw("sum", row, rowptr, col, np.abs(Bf), np.abs(Gf))
+    assert Bt.grad.dtype == torch.bfloat16 and v.grad.dtype == torch.float32
+    assert np.all(np.abs(Bt.grad.float().cpu().numpy() - gB) <= 1e-5 * sB + 2.0 ** -8 * np.abs(gB) + 1e-30)
+    assert np.all(np.abs(v.grad.cpu().numpy() - gV) <= 1e-5 * sV + 1e-30)
+
+
+def test_half_full_size_properties():
+    """BASELINE config 3 size in bf16: A @ ones == row sums of the values, linearity in B
+    up to the stated rounding."""
+    from paddle_sparse_amd import ops
+
+    M = N = 2_000_000
+    nnz, K = 20_000_000, 128
+    g = torch.Generator(device="cuda").manual_seed(2)
+    row = torch.sort(torch.randint(0, M, (nnz,), generator=g, device="cuda"))[0]
+    col = torch.randint(0, N, (nnz,), generator=g, device="cuda")
+    val = torch.randn(nnz, generator=g, device="cuda")
+    rowptr = ops.ind2ptr(row, M)
+    ones = torch.ones(N, K, device="cuda", dtype=torch.bfloat16)
+    o = ops._spmm("sum", rowptr, col, val, ones)[0]
+    rs = torch.zeros(M, device="cuda", dtype=torch.float64).index_add_(0, row, val.double())
+    scale = torch.zeros(M, device="cuda", dtype=torch.float64).index_add_(0, row, val.abs().double())
+    assert bool(((o[:, 0].double() - rs).abs() <= 1e-5 * scale + 2.0 ** -8 * rs.abs() + 1e-30).all())
+    assert bool((o == o[:, :1]).all())
+    B = torch.randn(N, K, generator=g, device="cuda").to(torch.bfloat16)
+    o1 = ops._spmm("sum", rowptr, col, val, B)[0].float()
+    o32 = ops.spmm_sum(rowptr, col, val, B.float())  # the fp32 kernel on the same (widened) operand
+    S = ops.spmm_sum(rowptr, col, val.abs(), B.float().abs())
+    assert bool(((o1 - o32).abs() <= 2e-5 * S + 2.0 ** -8 * o32.abs() + 1e-30).all())
