@@ -85,3 +85,20 @@ def test_roundtrip_full_size():
     assert bool((rowptr[1:] >= rowptr[:-1]).all())
     assert torch.equal(rowptr, torch.searchsorted(row, torch.arange(M + 1, device="cuda")))
     assert torch.equal(ops.ptr2ind(rowptr, nnz), row)
+
+
+def test_ptr2ind_blocks_dominated_by_hub_rows():
+    """64-row blocks with far more entries than rows take the row-by-row fill (no search):
+    odd and even starts, hub rows next to empty and one-entry rows, the last partial block."""
+    from paddle_sparse_amd import ops
+
+    rng = np.random.default_rng(3)
+    for M in (1, 63, 64, 65, 200):
+        deg = rng.integers(0, 3, M)
+        deg[rng.integers(0, M, max(M // 20, 1))] = rng.integers(5000, 40000, max(M // 20, 1))
+        deg[0] = 4097 + (M % 2)  # an odd start for the second row of block 0
+        ptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+        E = int(ptr[-1])
+        got = ops.ptr2ind(torch.from_numpy(ptr).cuda(), E).cpu().numpy()
+        assert np.array_equal(got, np.repeat(np.arange(M), deg))
+        assert np.array_equal(got, oracle.ptr2ind(ptr, E))
