@@ -201,7 +201,17 @@ def power_law(device, F: int, reps: int):
                 fn(rowptr, col, val, B, row=row, algo=algo)
                 ms = event_ms(lambda: fn(rowptr, col, val, B, row=row, algo=algo), reps)
                 entry[f"{op}_{algo}_ms"] = round(ms, 4)
-        entry["algo_chosen_by_row_stats"] = "edge_ranges" if 5 * sum(ops.csr_row_stats(rowptr)[:2]) > 2 * N else "row_waves"
+        # the tensor surface: per-matrix choice of the kernel family and, for hub columns, the
+        # compact copy of the hot rows of B (packed inside every call)
+        from paddle_sparse_amd import SparseTensor
+
+        a = SparseTensor(row=row, rowptr=rowptr, col=col, value=val, sparse_sizes=(N, N), is_sorted=True, trust_data=True)
+        for reduce in ("sum", "max"):
+            with torch.no_grad():
+                a.matmul(B, reduce)
+                entry[f"spmm_{reduce}_tensor_surface_ms"] = round(event_ms(lambda: a.matmul(B, reduce), reps), 4)
+        entry["algo_chosen_by_row_stats"] = a.storage._spmm_algo()
+        entry["hot_column_copy_rows"] = 0 if a.storage._hot_columns() is None else int(a.storage._hot_columns()[0].numel())
         res["rmat21_relabelled_columns" if relabel else "rmat21_as_generated"] = entry
         del B
     return res

@@ -131,11 +131,13 @@ PD_BUILD_OP(index_sort)
 // `value` and `row` are optional; Paddle's paddle::optional<Tensor> input
 // (anticipated by PD_DISPATCH_HAS_VALUE, csrc/cpu/utils.h:11-20) maps to a NULL
 // pointer in the C-ABI.  `row` = SparseStorage.row() when it is cached; `algo` =
-// psa_spmm_algo, chosen once per matrix from csr_row_stats below.
+// psa_spmm_algo, chosen once per matrix from csr_row_stats below; `hot_rows` = the
+// compact copy of the hub rows of mat that `col` (then the redirected array) points into.
 static std::vector<paddle::Tensor> spmm_impl(int reduce, paddle::Tensor& rowptr, paddle::Tensor& col,
                                              const paddle::optional<paddle::Tensor>& value,
                                              const paddle::optional<paddle::Tensor>& row, paddle::Tensor& mat,
-                                             int64_t algo, bool want_arg, bool want_arg_bytes) {
+                                             const paddle::optional<paddle::Tensor>& hot_rows, int64_t algo,
+                                             bool want_arg, bool want_arg_bytes) {
   CHECK_GPU(mat);
   CHECK_I64(rowptr);
   CHECK_I64(col);
@@ -149,7 +151,8 @@ static std::vector<paddle::Tensor> spmm_impl(int reduce, paddle::Tensor& rowptr,
                                             : paddle::empty({0}, paddle::DataType::UINT8, mat.place());
   const size_t ws_bytes = psa_spmm_workspace_bytes(reduce, K, nnz);
   auto ws = scratch(ws_bytes, mat.place());
-  PSA_CALL(psa_spmm_coo(reduce, i64(rowptr), i64_or_null(row), i64(col), f32_or_null(value), f32(mat), M, N, K, nnz,
+  PSA_CALL(psa_spmm_coo(reduce, i64(rowptr), i64_or_null(row), i64(col), f32_or_null(value), f32(mat),
+                        f32_or_null(hot_rows), hot_rows ? hot_rows.get().shape()[0] : 0, M, N, K, nnz,
                         out.data<float>(), /*ldo=*/0, minmax && want_arg ? arg.data<int64_t>() : nullptr,
                         minmax && want_arg_bytes ? arg_bytes.data<uint8_t>() : nullptr, static_cast<int>(algo),
                         ws_bytes > 0 ? ws.data<uint8_t>() : nullptr, ws_bytes, stream_of(mat)));
@@ -159,12 +162,15 @@ static std::vector<paddle::Tensor> spmm_impl(int reduce, paddle::Tensor& rowptr,
   std::vector<paddle::Tensor> NAME(paddle::Tensor& rowptr, paddle::Tensor& col,                \
                                    const paddle::optional<paddle::Tensor>& value,             \
                                    const paddle::optional<paddle::Tensor>& row,               \
-                                   paddle::Tensor& mat, int64_t algo, bool want_arg,          \
-                                   bool want_arg_bytes) {                                     \
-    return spmm_impl(RED, rowptr, col, value, row, mat, algo, want_arg, want_arg_bytes);      \
+                                   paddle::Tensor& mat,                                       \
+                                   const paddle::optional<paddle::Tensor>& hot_rows,          \
+                                   int64_t algo, bool want_arg, bool want_arg_bytes) {        \
+    return spmm_impl(RED, rowptr, col, value, row, mat, hot_rows, algo, want_arg,             \
+                     want_arg_bytes);                                                         \
   }                                                                                           \
   PD_BUILD_OP(NAME)                                                                           \
-      .Inputs({"rowptr", "col", paddle::Optional("value"), paddle::Optional("row"), "mat"})   \
+      .Inputs({"rowptr", "col", paddle::Optional("value"), paddle::Optional("row"), "mat",     \
+               paddle::Optional("hot_rows")})                                                 \
       .Outputs({"out", "arg_out", "arg_bytes"})                                               \
       .Attrs({"algo: int64_t", "want_arg: bool", "want_arg_bytes: bool"})                     \
       .SetKernelFn(PD_KERNEL(NAME));

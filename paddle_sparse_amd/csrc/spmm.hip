@@ -1277,8 +1277,10 @@ int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* row, const i
                   const float* value, const float* mat, int64_t M, int64_t N,
                   int64_t K, int64_t nnz, OutView out, int64_t* arg_out,
                   void* workspace, size_t workspace_bytes, hipStream_t s,
-                  uint8_t* arg_bytes, bool* bytes_done, int algo) {
+                  uint8_t* arg_bytes, bool* bytes_done, int algo, const float* hot_rows = nullptr,
+                  int64_t num_hot = 0) {
   PSA_REQUIRE(reduce >= PSA_SUM && reduce <= PSA_MAX, "bad reduce");
+  PSA_REQUIRE(num_hot >= 0 && (num_hot == 0 || hot_rows != nullptr), "hot_rows is NULL");
   PSA_REQUIRE(algo >= PSA_SPMM_AUTO && algo <= PSA_SPMM_EDGE_RANGES, "bad algo");
   PSA_REQUIRE(M >= 0 && N >= 0 && K >= 0 && nnz >= 0, "negative size");
   if (M == 0 || K == 0) return PSA_OK;
@@ -1300,10 +1302,15 @@ int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* row, const i
     const bool nt_gather = N * K * 4 >= kNtGatherBytes;
     const int range_len = g_variant == 31 ? 128 : g_variant == 32 ? 512 : g_variant == 33 ? 1024 : 0;
     return psa::launch_spmm_eb(red, mean, rowptr, row, col, value, mat, out.p, out.ld, arg_out,
-                               minmax ? arg_bytes : nullptr, M, N, K, nnz, workspace, workspace_bytes,
+                               minmax ? arg_bytes : nullptr, M, N, K, nnz, hot_rows, num_hot, workspace, workspace_bytes,
                                nt_gather, range_len, g_variant == 34 ? 1 : g_variant == 35 ? 2 : g_variant == 36 ? 4 : 0, s);
   }
 
+  if (num_hot > 0) {
+    psa::set_error("psa_spmm_coo: hot_rows is served by the edge-range kernels only (algo = PSA_SPMM_EDGE_RANGES, "
+                   "K % 4 == 0, 16-byte aligned operands, a workspace)");
+    return PSA_ERR_UNSUPPORTED;
+  }
   // Long-row path: on when the caller brings a workspace (NULL keeps every row
   // on its own wave: same results, slow on power-law graphs).
   LongScratch w;
@@ -1404,12 +1411,12 @@ int psa_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
              int64_t K, int64_t nnz, float* out, int64_t* arg_out,
              uint8_t* arg_bytes, void* workspace, size_t workspace_bytes,
              psa_stream_t stream) {
-  return psa_spmm_coo(reduce, rowptr, nullptr, col, value, mat, M, N, K, nnz, out, 0, arg_out, arg_bytes,
+  return psa_spmm_coo(reduce, rowptr, nullptr, col, value, mat, nullptr, 0, M, N, K, nnz, out, 0, arg_out, arg_bytes,
                       PSA_SPMM_AUTO, workspace, workspace_bytes, stream);
 }
 
 int psa_spmm_coo(int reduce, const int64_t* rowptr, const int64_t* row, const int64_t* col,
-                 const float* value, const float* mat, int64_t M, int64_t N,
+                 const float* value, const float* mat, const float* hot_rows, int64_t num_hot, int64_t M, int64_t N,
                  int64_t K, int64_t nnz, float* out, int64_t ldo, int64_t* arg_out,
                  uint8_t* arg_bytes, int algo, void* workspace, size_t workspace_bytes,
                  psa_stream_t stream) {
@@ -1421,7 +1428,7 @@ int psa_spmm_coo(int reduce, const int64_t* rowptr, const int64_t* row, const in
   hipStream_t s = psa::as_stream(stream);
   bool bytes_done = false;
   const int st = spmm_dispatch(reduce, rowptr, row, col, value, mat, M, N, K, nnz, OutView{out, ldo > 0 ? ldo : K}, arg_out, workspace,
-                               workspace_bytes, s, arg_bytes, &bytes_done, algo);
+                               workspace_bytes, s, arg_bytes, &bytes_done, algo, hot_rows, num_hot);
   if (st != PSA_OK || arg_bytes == nullptr || !minmax || bytes_done || M == 0 || K == 0) return st;
   // the kernel that ran keeps arg_out only: one more pass turns it into bytes
   PSA_REQUIRE(arg_out != nullptr, "arg_bytes without arg_out needs a K tile whose kernel writes the bytes itself (K % 4 == 0, K <= 256)");

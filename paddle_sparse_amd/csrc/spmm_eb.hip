@@ -54,6 +54,8 @@ struct EbArgs {
   const int64_t* col;
   const float* val;
   const float* mat;
+  const float* hot;   // compact copy of the most referenced rows of mat, or NULL: column ids >= ncols index it
+  int64_t ncols;      // rows of mat (INT64_MAX without a hot copy: no id is "hot")
   float* out;
   int64_t* arg_out;
   uint8_t* arg_bytes;
@@ -235,6 +237,7 @@ __global__ void __launch_bounds__(kThreads) spmm_eb_kernel(EbArgs a) {
   const int64_t k0 = (static_cast<int64_t>(blockIdx.y) * LPR + l) * 4;
   const bool kact = k0 < a.K;
   const float* matk = a.mat + (kact ? k0 : 0);  // idle K lanes gather (and drop) column 0
+  const float* hotk = a.hot + (kact ? k0 : 0);
   const int64_t rg = ((static_cast<int64_t>(blockIdx.x) - a.fill_blocks) * kWaves + wave) * G + g;
   const int64_t start = rg * a.range_len;
   const bool active = start < a.nnz;
@@ -290,7 +293,9 @@ __global__ void __launch_bounds__(kThreads) spmm_eb_kernel(EbArgs a) {
       const float wv = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(sel, s.v));
       w[B][u] = has_val ? wv : 1.f;
       rr[B][u] = __builtin_amdgcn_ds_bpermute(sel, s.r);
-      asm_gather16<NT>(b[B][u], matk + c * a.K);
+      // ids at or above ncols name a row of the compact hot copy (psa_spmm_coo, hot_rows)
+      const bool is_hot = c >= a.ncols;
+      asm_gather16<NT>(b[B][u], (is_hot ? hotk : matk) + (is_hot ? c - a.ncols : c) * a.K);
     }
   };
   auto consume = [&](auto buf, int local0) {
@@ -535,9 +540,9 @@ size_t eb_workspace_bytes(bool minmax, int64_t K, int64_t nnz) {
 int launch_spmm_eb(int red, int mean, const int64_t* rowptr, const int64_t* row,
                    const int64_t* col, const float* val, const float* mat, float* out, int64_t ldo,
                    int64_t* arg_out, uint8_t* arg_bytes, int64_t M, int64_t N, int64_t K,
-                   int64_t nnz, void* workspace, size_t workspace_bytes, bool nt_gather,
-                   int range_len_override, int dbg, hipStream_t s) {
-  (void)N;
+                   int64_t nnz, const float* hot_rows, int64_t num_hot, void* workspace, size_t workspace_bytes,
+                   bool nt_gather, int range_len_override, int dbg, hipStream_t s) {
+  PSA_REQUIRE(num_hot >= 0 && N + num_hot < (1ll << 31), "column ids (with the hot copy) must fit 31 bits");
   PSA_REQUIRE(eb_supported(M, K, nnz), "shape not served by the edge-balanced kernels");
   const bool minmax = red != R_SUM;
   if (workspace == nullptr || workspace_bytes < eb_workspace_bytes(minmax, K, nnz)) {
@@ -561,6 +566,8 @@ int launch_spmm_eb(int red, int mean, const int64_t* rowptr, const int64_t* row,
   a.col = col;
   a.val = val;
   a.mat = mat;
+  a.hot = num_hot > 0 ? hot_rows : nullptr;
+  a.ncols = num_hot > 0 ? N : INT64_MAX;
   a.out = out;
   a.ldo = ldo;
   a.arg_out = minmax ? arg_out : nullptr;

@@ -56,6 +56,14 @@ class _SpMM(torch.autograd.Function):
         ctx.half = None
         algo = storage._spmm_algo()  # per-matrix choice, read once
         row = storage.row() if algo == "edge_ranges" else None  # the COO row ids the edge-balanced kernels walk
+        hot_rows = None
+        plan = storage._hot_columns() if algo == "edge_ranges" and mat.shape[1] % 4 == 0 else None
+        if plan is not None:
+            # hub columns: their rows of `mat` are gathered once into a compact copy (13 us for
+            # 65 536 rows) and every reference goes there — consecutive addresses that stay cache
+            # resident, instead of rows that may share a few memory channels
+            hot_rows = ops.gather_rows(mat.detach(), plan[0])
+            col = plan[1]
         arg = arg_bytes = None
         if reduce in ("min", "max"):
             # What the backward will read decides what the forward stores.  The
@@ -70,10 +78,10 @@ class _SpMM(torch.autograd.Function):
             bytes_only = csc_bw and storage._longest_row() <= ops.ARG_BYTES_EXACT_ROW
             want_arg = (need_value or need_mat) and not bytes_only
             res = ops._spmm(reduce, rowptr, col, value, mat, want_arg_bytes=csc_bw, want_arg=want_arg,
-                            row=row, algo=algo)
+                            row=row, algo=algo, hot_rows=hot_rows)
             out, arg, arg_bytes = res if csc_bw else (*res, None)
         else:
-            out = ops._spmm(reduce, rowptr, col, value, mat, row=row, algo=algo)[0]
+            out = ops._spmm(reduce, rowptr, col, value, mat, row=row, algo=algo, hot_rows=hot_rows)[0]
         ctx.storage, ctx.reduce = storage, reduce
         ctx.save_for_backward(value, mat, arg, arg_bytes)
         return out

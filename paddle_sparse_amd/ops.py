@@ -96,7 +96,7 @@ def ptr2ind(ptr: torch.Tensor, E: int) -> torch.Tensor:
 def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
           value: Optional[torch.Tensor], mat: torch.Tensor, want_arg_bytes: bool = False,
           want_arg: bool = True, row: Optional[torch.Tensor] = None, algo: str = "auto",
-          out: Optional[torch.Tensor] = None):
+          out: Optional[torch.Tensor] = None, hot_rows: Optional[torch.Tensor] = None):
     """(out, arg_out | None) — and, with want_arg_bytes (min/max, K % 4 == 0), a
     third result: arg_out as row-local byte indices for spmm_minmax_bw_csc.
     want_arg=False (min/max) skips the int64 arg_out altogether: the kernel then
@@ -108,7 +108,9 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
     "auto" | "row_waves" | "edge_ranges" (psa_spmm_algo; csr_row_stats /
     SparseStorage._spmm_algo() choose per matrix).  `out`: write into this
     fp32 [M, K] tensor, which may be a column slice of a wider contiguous
-    matrix (row stride = the wider matrix's width)."""
+    matrix (row stride = the wider matrix's width).  `hot_rows` (edge_ranges
+    only): float32 [h, K] compact copy of rows of mat; column ids in [N, N + h)
+    name its rows (SparseStorage._hot_columns builds the redirected col)."""
     rowptr = _index(rowptr, "rowptr")
     col = _index(col, "col")
     if row is not None:
@@ -135,6 +137,12 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
         raise ValueError("rowptr must have at least one element")
     M, (N, K), nnz = rowptr.numel() - 1, mat.shape, col.numel()
     rid = REDUCE_ID[reduce]
+    num_hot = 0
+    if hot_rows is not None:
+        _gpu(hot_rows, "hot_rows")
+        if hot_rows.dtype != torch.float32 or hot_rows.dim() != 2 or hot_rows.shape[1] != K or not hot_rows.is_contiguous():
+            raise ValueError("hot_rows must be a contiguous float32 [h, K] tensor")
+        num_hot = hot_rows.shape[0]
     ldo = 0
     if out is None:
         out = torch.empty((M, K), dtype=torch.float32, device=mat.device)
@@ -163,7 +171,7 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
         arg_bytes = torch.empty((M, K), dtype=torch.uint8, device=mat.device)
     with _on(mat.device):
         check(lib.psa_spmm_coo(rid, _ptr(rowptr), _ptr(row), _ptr(col), _ptr(value), _ptr(mat),
-                               M, N, K, nnz, _ptr(out), ldo, _ptr(arg), _ptr(arg_bytes),
+                               _ptr(hot_rows) if num_hot else None, num_hot, M, N, K, nnz, _ptr(out), ldo, _ptr(arg), _ptr(arg_bytes),
                                _lib.SPMM_ALGO_ID[algo], _ptr(ws), ws_bytes, _stream()))
     if want_arg_bytes:
         return out, arg, arg_bytes

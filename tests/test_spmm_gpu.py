@@ -348,3 +348,59 @@ def test_edge_ranges_bitwise_reproducible():
         o1, a1 = getattr(ops, f"spmm_{red}")(d[0], d[1], d[2], d[3], algo="row_waves")
         o2, a2 = getattr(ops, f"spmm_{red}")(d[0], d[1], d[2], d[3], row=d[4], algo="edge_ranges")
         assert torch.equal(o1, o2) and torch.equal(a1, a2)
+
+
+def test_hot_column_copy_gives_the_same_bits():
+    """Hub columns: references redirected into a compact copy of their rows of the dense
+    operand (psa_spmm_coo hot_rows; SparseStorage._hot_columns).  Same edges, same order,
+    same kernel — the result is identical to the plain edge-range forward."""
+    from paddle_sparse_amd import SparseTensor, ops
+    from paddle_sparse_amd import storage as st_mod
+
+    once()
+    rng = np.random.default_rng(17)
+    M, N, K = 6000, 5000, 128
+    deg = rng.integers(0, 3, M)
+    deg[rng.integers(0, M, 30)] = 700  # skewed rows: the edge-range forward is chosen
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    nnz = int(rowptr[-1])
+    col = rng.integers(0, N, nnz)
+    hubs = rng.integers(0, N, 40)
+    pick = rng.random(nnz) < 0.5
+    col[pick] = hubs[rng.integers(0, 40, int(pick.sum()))]  # half of all entries point at 40 hub columns
+    row = np.repeat(np.arange(M), deg)
+    order = np.lexsort((col, row))
+    col = col[order].astype(np.int64)
+    val = rng.standard_normal(nnz).astype(np.float32)
+    B = torch.from_numpy(rng.standard_normal((N, K)).astype(np.float32)).cuda()
+    a = SparseTensor(rowptr=dev(rowptr), col=dev(col), value=dev(val), sparse_sizes=(M, N), is_sorted=True, trust_data=True)
+    assert a.storage._spmm_algo() == "edge_ranges"
+    old = st_mod.HOT_COLUMNS
+    st_mod.HOT_COLUMNS = 256
+    try:
+        plan = a.storage._hot_columns()
+    finally:
+        st_mod.HOT_COLUMNS = old
+    assert plan is not None
+    hot, col_eff = plan
+    assert hot.numel() == 256 and set(hubs.tolist()) <= set(hot.tolist())
+    back = torch.where(col_eff >= N, hot[(col_eff - N).clamp(min=0)], col_eff)
+    assert torch.equal(back, dev(col))
+    for reduce in ("sum", "mean", "min", "max"):
+        plain = ops._spmm(reduce, a.storage.rowptr(), a.storage.col(), a.storage.value(), B, row=a.storage.row(),
+                          algo="edge_ranges")
+        hot_rows = ops.gather_rows(B, hot)
+        redirected = ops._spmm(reduce, a.storage.rowptr(), col_eff, a.storage.value(), B, row=a.storage.row(),
+                               algo="edge_ranges", hot_rows=hot_rows)
+        assert torch.equal(plain[0], redirected[0])
+        if plain[1] is not None:
+            assert torch.equal(plain[1], redirected[1])
+        via_api = a.matmul(B, reduce)  # the tensor surface takes the plan by itself
+        assert torch.equal(via_api, plain[0])
+    with pytest.raises(Exception, match="edge-range"):
+        ops._spmm("sum", a.storage.rowptr(), col_eff, a.storage.value(), B, algo="row_waves", hot_rows=hot_rows)
+    # a matrix without hub columns builds no plan
+    row2, rowptr2, col2, val2 = skewed_csr(3000, 2000, seed=5, long_rows=(1,), long_deg=2000, base_deg=1)
+    flat = SparseTensor(rowptr=dev(rowptr2), col=dev(col2), value=dev(val2), sparse_sizes=(3000, 2000), is_sorted=True,
+                        trust_data=True)
+    assert flat.storage._spmm_algo() == "edge_ranges" and flat.storage._hot_columns() is None
