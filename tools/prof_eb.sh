@@ -9,7 +9,7 @@ for V in $VARS; do
   mkdir -p $OUT
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $REPO/tools/pmc_eb.py $G $V $OP 10 > $OUT/stats.log 2>&1
   i=0
-  for CTRS in ${PASSES:-"FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS" "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_WRITE_REQ_sum"}; do
+  for CTRS in ${PASSES:-"FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum"}; do
     i=$((i+1))
     rocprofv3 --pmc $CTRS --output-format csv -d $OUT/pmc$i -- python3 $REPO/tools/pmc_eb.py $G $V $OP 3 > $OUT/pmc$i.log 2>&1 || echo "pass $i failed"
   done
