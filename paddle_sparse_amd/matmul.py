@@ -40,6 +40,19 @@ def _csc_weights(st: SparseStorage, value: Optional[torch.Tensor], csr2csc, row_
     return w
 
 
+def _spmm_sum_planned(st: SparseStorage, weights: Optional[torch.Tensor], mat: torch.Tensor) -> torch.Tensor:
+    """spmm_sum of the matrix `st` describes (values `weights`, given separately) with the
+    storage's per-matrix choices: kernel family, COO row ids, compact copy of the hub rows."""
+    algo = st._spmm_algo()
+    col, row, hot_rows = st.col(), None, None
+    if algo == "edge_ranges":
+        row = st.row()
+        plan = st._hot_columns() if mat.shape[1] % 4 == 0 else None
+        if plan is not None:
+            hot_rows, col = ops.gather_rows(mat, plan[0]), plan[1]
+    return ops._spmm("sum", st.rowptr(), col, weights, mat, row=row, algo=algo, hot_rows=hot_rows)[0]
+
+
 class _SpMM(torch.autograd.Function):
     @staticmethod
     def forward(ctx, value: Optional[torch.Tensor], mat: torch.Tensor,
@@ -141,7 +154,9 @@ class _SpMM(torch.autograd.Function):
                 w = None
                 if value is not None or mean:
                     w = _csc_weights(st, value, csr2csc, row_csc, mean)
-                grad_mat = ops.spmm_sum(st.colptr(), row_csc, w, grad_out)
+                # A^T grad_out = a forward SpMM over the CSC view, with that view's own choices
+                # (edge ranges and the hub-row copy when the transpose is a power-law matrix too)
+                grad_mat = _spmm_sum_planned(st._csc_view(), w, grad_out)
         return grad_value, grad_mat
 
 

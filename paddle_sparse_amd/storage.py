@@ -123,6 +123,7 @@ class SparseStorage(object):
         self._spmm_algo_memo: Optional[str] = None  # SpMM forward kernel family for this row structure
         self._value_csc_memo = None  # (value, version, value[csr2csc]): see _value_in_csc_order
         self._hot_memo = None  # False | (hot column ids, col redirected into the compact copy): see _hot_columns
+        self._csc_view_memo = None  # SparseStorage of the transpose over the CSC caches: see _csc_view
 
         # storage.py:158-171 — sort by (row, col) unless told it is sorted
         if not is_sorted and nnz > 0:
@@ -311,6 +312,20 @@ class SparseStorage(object):
             self._row_csc = ops.gather_rows(self.row(), self.csr2csc())
         return self._row_csc
 
+    def _csc_view(self):
+        """The CSC view of this matrix as the CSR storage of its transpose (structure only,
+        memoised): rowptr = colptr, col = row[csr2csc], colcount = rowcount.  The backward of
+        SpMM wrt the dense operand is a forward SpMM over it (matmul.py), and it brings its own
+        per-matrix choices with it — a power-law matrix has a power-law transpose, whose hub
+        columns are this matrix's hub ROWS."""
+        if getattr(self, "_csc_view_memo", None) is None:
+            self.csr2csc()  # leaves colptr and row[csr2csc] behind
+            M, N = self._sparse_sizes
+            self._csc_view_memo = SparseStorage(row=None, rowptr=self.colptr(), col=self._row_in_csc_order(),
+                                                value=None, sparse_sizes=(N, M), colcount=self.rowcount(),
+                                                is_sorted=True, trust_data=True)
+        return self._csc_view_memo
+
     def _longest_row(self) -> int:
         """Entries of the longest row (memoised; the min/max forward asks whether
         the one-byte form of arg_out is complete, i.e. no row above 128)."""
@@ -429,6 +444,7 @@ class SparseStorage(object):
         self._spmm_algo_memo = None
         self._value_csc_memo = None
         self._hot_memo = None
+        self._csc_view_memo = None
         return self
 
     def cached_keys(self) -> List[str]:
@@ -449,6 +465,7 @@ class SparseStorage(object):
             out._max_rowcount = self._max_rowcount
             out._spmm_algo_memo = self._spmm_algo_memo
             out._hot_memo = self._hot_memo
+            out._csc_view_memo = self._csc_view_memo
         return out
 
     def _map(self, fn: Callable[[torch.Tensor], torch.Tensor]):

@@ -484,3 +484,36 @@ def test_value_gradients_flow_through_t_coalesce_and_friends():
     # detached paths still take the fast routes
     with torch.no_grad():
         assert ps.coalesce(idx(np.stack([dup_r, dup_c])), torch.from_numpy(w).cuda(), M, N)[1].requires_grad is False
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean"])
+def test_grad_mat_over_a_power_law_csc_view(reduce):
+    """Fixed adjacency with hub rows AND hub columns: the backward wrt the dense operand is a
+    forward SpMM over the CSC view, which picks the edge-range kernels and the hub-row copy for
+    itself (SparseStorage._csc_view); gradients against the oracle."""
+    from paddle_sparse_amd import SparseTensor
+
+    rng = np.random.default_rng(44)
+    M, N, K = 5000, 4000, 64
+    deg = rng.integers(0, 3, M)
+    deg[rng.integers(0, M, 25)] = 600
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    nnz = int(rowptr[-1])
+    row = np.repeat(np.arange(M), deg)
+    col = rng.integers(0, N, nnz)
+    hubs = rng.integers(0, N, 30)
+    pick = rng.random(nnz) < 0.6
+    col[pick] = hubs[rng.integers(0, 30, int(pick.sum()))]
+    key = np.unique(row * N + col)
+    row, col = key // N, key % N
+    val = rng.standard_normal(key.size).astype(np.float32)
+    rowptr = oracle.ind2ptr(row, M)
+    G = rng.standard_normal((M, K)).astype(np.float32)
+    a = SparseTensor(row=idx(row), col=idx(col), value=torch.from_numpy(val).cuda(), sparse_sizes=(M, N), is_sorted=True)
+    Bt = torch.zeros(N, K, device="cuda", requires_grad=True)
+    a.matmul(Bt, reduce).backward(torch.from_numpy(G).cuda())
+    view = a.storage._csc_view()
+    assert view._spmm_algo() == "edge_ranges" and view.sparse_sizes() == (N, M)
+    want = oracle.spmm_mat_bw(reduce, row, rowptr, col, val, G, N)
+    scale = oracle.spmm_mat_bw(reduce, row, rowptr, col, np.abs(val), np.abs(G), N)
+    assert np.all(np.abs(Bt.grad.cpu().numpy() - want) <= 1e-5 * scale + 1e-30)

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Forward + backward of spmm_sum / spmm_mean on R-MAT scale 21 through the tensor surface:
+fixed adjacency (gradient wrt the dense operand only) and trained edge values."""
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+from bench import event_ms, rmat_graph  # noqa: E402
+from paddle_sparse_amd import SparseTensor  # noqa: E402
+
+dev = torch.device("cuda", 0)
+F = 128
+for relabel in (False, True):
+    N, rowptr, row, col, val = rmat_graph(21, 20_000_000, dev, relabel=relabel)
+    B = torch.randn(N, F, device=dev, requires_grad=True)
+    G = torch.randn(N, F, device=dev)
+    name = "R-MAT 21, columns relabelled" if relabel else "R-MAT 21 as generated"
+    for trained in (False, True):
+        v = val.clone().requires_grad_(trained)
+        a = SparseTensor(row=row, rowptr=rowptr, col=col, value=v, sparse_sizes=(N, N), is_sorted=True, trust_data=True)
+        a.storage.csr2csc(), a.storage.csc2csr()
+        for reduce in ("sum", "max"):
+            def step():
+                B.grad = None
+                v.grad = None
+                a.matmul(B, reduce).backward(G)
+            step()
+            ms = event_ms(step, 10)
+            print(f"{name}: spmm_{reduce} fwd+bwd, {'trained values' if trained else 'fixed adjacency'}: {ms:.3f} ms", flush=True)
