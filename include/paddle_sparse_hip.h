@@ -395,7 +395,9 @@ int psa_coalesce_small(const int64_t* row, const int64_t* col, int64_t n,
  * status = the first two int64 words of the workspace: status[0] = number of
  * distinct (row, col) pairs; status[1] = flags, bit 0: some row/col lies outside
  * [0, M) x [0, N) (the reference asserts this, storage.py:78-91: raise, the
- * outputs are unspecified then), bit 1: the input was not sorted by (row, col).
+ * outputs are unspecified then), bit 1: the input was not sorted by (row, col),
+ * bit 2: an inter-workgroup wait of the sort gave up (never expected; the outputs
+ * are invalid — the same word psa_index_sort_status reads).
  * psa_coalesce_write takes the count from the device, so a caller may also
  * allocate worst-case outputs (n rows), enqueue both calls back to back and read
  * the status afterwards (count < 0 in the call = "not read yet").
@@ -418,6 +420,19 @@ int psa_coalesce_write(const void* value, int dtype, int64_t D, int64_t n,
                        int64_t M, int64_t N, int reduce, int64_t count,
                        const void* workspace, int64_t* index_out,
                        void* value_out, psa_stream_t stream);
+
+/* The whole coalesce in ONE launch, for n <= psa_coalesce_small_max_fused() (10 240)
+ * entries with no values or fp32 / int32 scalar values (BASELINE config 1): the
+ * one-workgroup LDS sort of the chain above also writes the contiguous [2, count]
+ * index into index_out (int64[2 n] capacity) and reduces every run of values into
+ * value_out ([n] capacity).  status int64[2] (device) = {count, flags} as above;
+ * the caller reads it once after the launch.  No workspace. */
+int psa_coalesce_small_max_fused(void);
+int psa_coalesce_small_fused(const int64_t* row, const int64_t* col,
+                             const void* value, int dtype, int64_t n, int64_t M,
+                             int64_t N, int reduce, int64_t* index_out,
+                             void* value_out, int64_t* status,
+                             psa_stream_t stream);
 
 /* psa_make_keys for (row, col) with the reference's range assertions folded in:
  * keys[i] = row[i] * N + col[i]; status int64[4] (device): status[1] gets bit 0

@@ -77,6 +77,9 @@ SIGNATURES = {
                                    c_void_p, c_size_t, c_void_p]),
     "psa_coalesce_write": (c_int, [c_void_p, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_int64,
                                    c_void_p, c_void_p, c_void_p, c_void_p]),
+    "psa_coalesce_small_max_fused": (c_int, []),
+    "psa_coalesce_small_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_int64, c_int,
+                                         c_void_p, c_void_p, c_void_p, c_void_p]),
     "psa_make_keys_checked": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,
                                       c_void_p]),
     "psa_make_keys": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p,

@@ -22,6 +22,10 @@
 #include "radix_util.h"
 #include "reduce_util.h"
 
+namespace psa {
+const uint32_t* sort_fault_word(const void* workspace, int64_t n, int64_t max_value);  // sort.hip
+}
+
 namespace {
 
 using psa::Acc;
@@ -38,7 +42,7 @@ constexpr int kSmallTile = kSmallThreads * kSmallItems;  // 10240 entries: the o
 constexpr int kSmallWaves = kSmallThreads / 64;
 
 enum { R_SUM = 0, R_MEAN = 1, R_MIN = 2, R_MAX = 3 };
-enum { F_RANGE = 1, F_UNSORTED = 2 };  // status[1] bits
+enum { F_RANGE = 1, F_UNSORTED = 2, F_SORT_FAULT = 4 };  // status[1] bits
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -61,7 +65,11 @@ small_coalesce_sort_kernel(const int64_t* __restrict__ row, const int64_t* __res
                            int64_t M, int64_t N, int n, int passes,
                            int64_t* __restrict__ out_row, int64_t* __restrict__ out_col,
                            int64_t* __restrict__ ptr, int64_t* __restrict__ perm,
-                           int64_t* __restrict__ status) {
+                           int64_t* __restrict__ status,
+                           // fused form (psa_coalesce_small_fused): the packed [2, count] index and the
+                           // reduced 4-byte scalar values straight from this launch; NULL = two-call form
+                           int64_t* __restrict__ index_out, const void* __restrict__ value, int vkind,
+                           int red, void* __restrict__ value_out) {
   constexpr int ITEMS = kSmallItems;
   constexpr int WAVES = kSmallWaves;
   __shared__ uint64_t lkeys[kSmallTile];
@@ -93,7 +101,10 @@ small_coalesce_sort_kernel(const int64_t* __restrict__ row, const int64_t* __res
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) {
     const int q = wbase + i * 64 + lane;
-    if (q < n) lkeys[q] = key[i];
+    if (q < n) {
+      lkeys[q] = key[i];
+      lidx[q] = static_cast<uint32_t>(q);  // stands when passes == 0 (a 1 x 1 matrix)
+    }
   }
   __syncthreads();  // lflags zeroed, input keys in the LDS
   bool unsorted = false;
@@ -185,6 +196,53 @@ small_coalesce_sort_kernel(const int64_t* __restrict__ row, const int64_t* __res
     count += wtot[w];
   }
   const bool narrow = (static_cast<uint64_t>(M) * static_cast<uint64_t>(N)) >> 32 == 0;  // 32-bit division
+  if (index_out != nullptr) {
+    // ---- fused form: run starts go to the LDS (the key array is free now), every head's
+    // thread writes its (row, col) into the packed index and reduces its run of values
+    __syncthreads();  // all head tests have read lkeys
+    uint32_t* lheads = reinterpret_cast<uint32_t*>(lkeys);
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      if (pos[i] != 0xffffffffu) lheads[before + pos[i]] = static_cast<uint32_t>(wbase + i * 64 + lane);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+      if (pos[i] == 0xffffffffu) continue;
+      const uint32_t o = before + pos[i];
+      int64_t r;
+      if (narrow) r = static_cast<uint32_t>(key[i]) / static_cast<uint32_t>(N);
+      else r = static_cast<int64_t>(key[i]) / N;
+      index_out[o] = r;
+      index_out[count + o] = static_cast<int64_t>(key[i]) - r * N;
+      if (vkind == 0) continue;
+      const uint32_t b = lheads[o], e = o + 1 < count ? lheads[o + 1] : static_cast<uint32_t>(n);
+      if (vkind == 1) {
+        const float* v = static_cast<const float*>(value);
+        float acc = v[lidx[b]];
+        for (uint32_t j = b + 1; j < e; ++j) {
+          const float x = v[lidx[j]];
+          acc = red == R_MIN ? (x < acc ? x : acc) : red == R_MAX ? (x > acc ? x : acc) : acc + x;
+        }
+        if (red == R_MEAN) acc = acc / static_cast<float>(e - b);
+        static_cast<float*>(value_out)[o] = acc;
+      } else {
+        const int32_t* v = static_cast<const int32_t*>(value);
+        int32_t acc = v[lidx[b]];
+        for (uint32_t j = b + 1; j < e; ++j) {
+          const int32_t x = v[lidx[j]];
+          acc = red == R_MIN ? (x < acc ? x : acc) : red == R_MAX ? (x > acc ? x : acc) : acc + x;
+        }
+        if (red == R_MEAN) acc = mean_div<int32_t>(acc, static_cast<int64_t>(e - b));
+        static_cast<int32_t*>(value_out)[o] = acc;
+      }
+    }
+    if (tid == 0) {
+      status[0] = count;
+      status[1] = lflags;
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < ITEMS; ++i) {
     const int q = wbase + i * 64 + lane;
@@ -284,6 +342,12 @@ __global__ void chain_flags_kernel(int64_t* __restrict__ status) {
   status[1] = (status[2] ? F_RANGE : 0) | (status[3] ? F_UNSORTED : 0);
 }
 
+// after the sort: a look-back spin that gave up (never expected) makes the order invalid — the
+// caller learns it from the status words it reads anyway instead of getting a wrong permutation
+__global__ void chain_sort_fault_kernel(const uint32_t* __restrict__ fault, int64_t* __restrict__ status) {
+  if (*fault != 0) status[1] |= F_SORT_FAULT;
+}
+
 bool small_path(int64_t n, int64_t M, int64_t N) {
   return n <= kSmallTile && M > 0 && N > 0 && static_cast<double>(M) * static_cast<double>(N) < 9.0e18;
 }
@@ -374,7 +438,9 @@ int psa_coalesce_count(const int64_t* row, const int64_t* col, const void* value
   if (small_path(n, M, N)) {
     const int passes = (bits_for(M * N) + 7) / 8;
     hipLaunchKernelGGL(small_coalesce_sort_kernel, dim3(1), dim3(kSmallThreads), 0, s, row, col, M, N,
-                       static_cast<int>(n), passes, w.a, w.b, w.ptr, w.perm, w.status);
+                       static_cast<int>(n), passes, w.a, w.b, w.ptr, w.perm, w.status,
+                       static_cast<int64_t*>(nullptr), static_cast<const void*>(nullptr), 0, 0,
+                       static_cast<void*>(nullptr));
     PSA_LAUNCH_CHECK();
     return PSA_OK;
   }
@@ -391,7 +457,32 @@ int psa_coalesce_count(const int64_t* row, const int64_t* col, const void* value
   else
     st = psa_index_sort(w.a, n, M * N, w.b, w.perm, w.sort_ws, w.sort_bytes, stream);
   if (st != PSA_OK) return st;
+  if (const uint32_t* fault = psa::sort_fault_word(w.sort_ws, n, M * N)) {
+    hipLaunchKernelGGL(chain_sort_fault_kernel, dim3(1), dim3(1), 0, s, fault, w.status);
+    PSA_LAUNCH_CHECK();
+  }
   return psa_unique_count(w.b, n, w.uniq_ws, w.uniq_bytes, w.status, stream);
+}
+
+int psa_coalesce_small_max_fused(void) { return kSmallTile; }
+
+int psa_coalesce_small_fused(const int64_t* row, const int64_t* col, const void* value, int dtype, int64_t n,
+                             int64_t M, int64_t N, int reduce, int64_t* index_out, void* value_out,
+                             int64_t* status, psa_stream_t stream) {
+  PSA_REQUIRE(n > 0 && n <= kSmallTile, "n out of range for the one-launch form");
+  PSA_REQUIRE(M > 0 && N > 0 && small_path(n, M, N), "matrix shape not served by the one-launch form");
+  PSA_REQUIRE(reduce >= PSA_SUM && reduce <= PSA_MAX, "bad reduce");
+  PSA_REQUIRE(row && col && index_out && status, "NULL pointer");
+  PSA_REQUIRE(value == nullptr || ((dtype == PSA_F32 || dtype == PSA_I32) && value_out != nullptr),
+              "the one-launch form takes fp32 / int32 scalar values (use psa_coalesce_count / _write)");
+  const int passes = (bits_for(M * N) + 7) / 8;
+  const int vkind = value == nullptr ? 0 : (dtype == PSA_F32 ? 1 : 2);
+  hipLaunchKernelGGL(small_coalesce_sort_kernel, dim3(1), dim3(kSmallThreads), 0, psa::as_stream(stream), row, col,
+                     M, N, static_cast<int>(n), passes, static_cast<int64_t*>(nullptr), static_cast<int64_t*>(nullptr),
+                     static_cast<int64_t*>(nullptr), static_cast<int64_t*>(nullptr), status, index_out, value, vkind,
+                     reduce, value_out);
+  PSA_LAUNCH_CHECK();
+  return PSA_OK;
 }
 
 int psa_make_keys_checked(const int64_t* row, const int64_t* col, int64_t n, int64_t M, int64_t N,

@@ -1148,17 +1148,30 @@ int psa_index_sort(const int64_t* keys, int64_t n, int64_t max_value,
                    nullptr, workspace, workspace_bytes, psa::as_stream(stream));
 }
 
-int psa_index_sort_status(const void* workspace, int64_t n, int64_t max_value,
-                          psa_stream_t stream) {
-  if (n <= 0 || workspace == nullptr) return 0;
+}  // extern "C"
+
+namespace psa {
+// Device address of the sort's look-back diagnostic word inside `workspace` (NULL when the
+// sort had nothing to do): non-zero after a bounded spin of a pass gave up, i.e. the order is
+// invalid.  Callers that read a count from the device anyway fold it into that read (chain.hip).
+const uint32_t* sort_fault_word(const void* workspace, int64_t n, int64_t max_value) {
+  if (n <= 0 || workspace == nullptr) return nullptr;
   const SortPlan p = make_plan(n, max_value);
-  if (p.passes == 0) return 0;
+  if (p.passes == 0) return nullptr;
   const char* os = static_cast<const char*>(workspace) + 2 * p.keys_bytes + 2 * p.idx_bytes +
                    p.counts_bytes;
   const size_t status_bytes =
-      align_up(static_cast<size_t>(psa::ceil_div(n, kOsTile)) * kRadix * sizeof(uint64_t), 256);
-  const uint32_t* err = reinterpret_cast<const uint32_t*>(os + status_bytes) +
-                        2 * kOsMaxPasses * kRadix + kOsMaxPasses;
+      align_up(static_cast<size_t>(ceil_div(n, kOsTile)) * kRadix * sizeof(uint64_t), 256);
+  return reinterpret_cast<const uint32_t*>(os + status_bytes) + 2 * kOsMaxPasses * kRadix + kOsMaxPasses;
+}
+}  // namespace psa
+
+extern "C" {
+
+int psa_index_sort_status(const void* workspace, int64_t n, int64_t max_value,
+                          psa_stream_t stream) {
+  const uint32_t* err = psa::sort_fault_word(workspace, n, max_value);
+  if (err == nullptr) return 0;
   uint32_t host = 0;
   hipStream_t s = psa::as_stream(stream);
   if (hipMemcpyAsync(&host, err, sizeof(host), hipMemcpyDeviceToHost, s) != hipSuccess ||

@@ -17,7 +17,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import REDUCE_ID, check
+from ._lib import REDUCE_ID, HipCoreError, check
 
 
 def _stream() -> int:
@@ -401,6 +401,16 @@ class IndexRangeError(AssertionError):
     row.max() < M and col.max() < N, storage.py:78-91)."""
 
 
+_FUSED_SMALL = 10_240  # entries the one-launch coalesce takes (psa_coalesce_small_max_fused)
+
+
+def _check_chain_flags(flags: int, m: int, n: int) -> None:
+    if flags & 1:
+        raise IndexRangeError(f"coalesce: an index lies outside the {m} x {n} matrix")
+    if flags & 4:
+        raise HipCoreError("coalesce: an inter-workgroup wait of the radix sort gave up; the result is invalid")
+
+
 def coalesce_chain(row: torch.Tensor, col: torch.Tensor, value: Optional[torch.Tensor], m: int, n: int,
                    op: str = "sum", read_first: bool = False):
     """coalesce of (row, col, value) of an m x n matrix in two C-ABI calls
@@ -426,9 +436,22 @@ def coalesce_chain(row: torch.Tensor, col: torch.Tensor, value: Optional[torch.T
     if nnz == 0:
         return torch.empty((2, 0), dtype=torch.int64, device=dev), value, True
     lib = _lib.load()
+    rid = REDUCE_ID[op]
+    if (nnz <= _FUSED_SMALL and not read_first and 0 < m * n < (1 << 62)
+            and (value is None or (D == 1 and value.dim() == 1 and value.dtype in (torch.float32, torch.int32)))):
+        # one launch for everything (one workgroup, sort resident in the LDS): one buffer holds the
+        # index (2 nnz words), the values (nnz 4-byte words) and the two status words
+        buf = torch.empty(3 * nnz + 2, dtype=torch.int64, device=dev)
+        status = buf[3 * nnz:]
+        out = buf[2 * nnz:3 * nnz].view(value.dtype)[:nnz] if value is not None else None
+        with _on(dev):
+            check(lib.psa_coalesce_small_fused(_ptr(row), _ptr(col), _ptr(value), dt, nnz, int(m), int(n), rid,
+                                               _ptr(buf), _ptr(out), _ptr(status), _stream()))
+        count, flags = status.tolist()
+        _check_chain_flags(flags, m, n)
+        return buf[:2 * count].view(2, count), (None if out is None else out[:count]), not (flags & 2)
     ws = _workspace(lib.psa_coalesce_workspace_bytes(nnz, int(m), int(n)), dev)
     status = ws[:16].view(torch.int64)
-    rid = REDUCE_ID[op]
     tail = tuple(value.shape[1:]) if value is not None else ()
     with _on(dev):
         check(lib.psa_coalesce_count(_ptr(row), _ptr(col), _ptr(value), dt, D, nnz, int(m), int(n),
@@ -436,8 +459,7 @@ def coalesce_chain(row: torch.Tensor, col: torch.Tensor, value: Optional[torch.T
         count = -1
         if read_first:
             count, flags = status.tolist()
-            if flags & 1:
-                raise IndexRangeError(f"coalesce: an index lies outside the {m} x {n} matrix")
+            _check_chain_flags(flags, m, n)
         rows = nnz if count < 0 else count
         index = torch.empty(2 * rows, dtype=torch.int64, device=dev)
         out = torch.empty((rows,) + tail, dtype=value.dtype, device=dev) if value is not None else None
@@ -445,8 +467,7 @@ def coalesce_chain(row: torch.Tensor, col: torch.Tensor, value: Optional[torch.T
                                      _ptr(index), _ptr(out), _stream()))
         if not read_first:
             count, flags = status.tolist()
-            if flags & 1:
-                raise IndexRangeError(f"coalesce: an index lies outside the {m} x {n} matrix")
+            _check_chain_flags(flags, m, n)
     index = index[:2 * count].view(2, count)
     if out is not None:
         out = out[:count]

@@ -114,6 +114,30 @@ def test_chain_equals_the_oracle(n, M, N, seed, read_first):
         assert was_sorted == bool(np.all(key[1:] >= key[:-1]))
 
 
+@pytest.mark.parametrize("op", ["add", "mean", "min", "max"])
+@pytest.mark.parametrize("npdtype", [np.float32, np.int32])
+@pytest.mark.parametrize("n,M,N", [(1, 1, 1), (777, 9, 11), (10_000, 1000, 1000), (10_240, 40, 50)])
+def test_one_launch_form_equals_the_two_call_chain_and_the_oracle(op, npdtype, n, M, N):
+    """psa_coalesce_small_fused (taken by coalesce_chain for <= 10240 entries with 4-byte scalar
+    values) against the oracle and against the two-call chain on the same input, bit for bit."""
+    from paddle_sparse_amd import ops
+
+    rng = np.random.default_rng(n + M)
+    row, col = rng.integers(0, M, n), rng.integers(0, N, n)
+    val = rng.integers(-9, 10, n).astype(npdtype)
+    if npdtype is np.float32 and op != "mean":
+        val = val + rng.random(n).astype(np.float32)   # sums in run order: same order in all three
+    ref_i, ref_v = so.coalesce(np.stack([row, col]), val, M, N, op)
+    one = ops.coalesce_chain(idx(row), idx(col), torch.from_numpy(val).cuda(), M, N, op)
+    two = ops.coalesce_chain(idx(row), idx(col), torch.from_numpy(val).cuda(), M, N, op, read_first=True)
+    assert np.array_equal(one[0].cpu().numpy(), ref_i) and one[0].is_contiguous()
+    assert torch.equal(one[0], two[0]) and torch.equal(one[1], two[1]) and one[2] == two[2]
+    if npdtype is np.float32:
+        np.testing.assert_allclose(one[1].cpu().numpy(), ref_v, rtol=1e-5, atol=1e-5)  # order of a float sum
+    else:
+        assert np.array_equal(one[1].cpu().numpy(), ref_v)
+
+
 def test_chain_and_functional_forms_reject_indices_outside_the_matrix():
     """The reference asserts row.max() < M and col.max() < N (storage.py:78-91);
     here the key kernels raise a flag that the one host read brings back."""
