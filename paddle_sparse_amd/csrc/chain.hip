@@ -23,7 +23,6 @@
 #include "reduce_util.h"
 
 namespace psa {
-const uint32_t* sort_fault_word(const void* workspace, int64_t n, int64_t max_value);  // sort.hip
 }
 
 namespace {
@@ -348,6 +347,57 @@ __global__ void chain_sort_fault_kernel(const uint32_t* __restrict__ fault, int6
   if (*fault != 0) status[1] |= F_SORT_FAULT;
 }
 
+// ---- the count call of the large path in 7 launches (was 12) -----------------------------------
+// Z  chain_zero_kernel       status words + the sort's look-back area, one launch
+// K  chain_keys_hist_kernel  keys, range / order flags and the digit histograms of every radix
+//                            pass from the one read of (row, col) (no separate histogram launch;
+//                            every pass scans its 256 counts itself, sort.hip)
+// P  the radix passes        psa::sort_prepared
+// U  unique_count_chain      heads per 2048-key block, then the one-block scan, which also writes
+//                            the count and folds the flag words and the sort's fault word
+// (a one-launch U — "last block scans" behind a release fence, or a decoupled look-back over the
+// blocks — measured slower at 1 M entries: 15-22 us against 5 + 5; profiles/r02_coalesce_kernels.txt)
+constexpr int kMaxPasses = 8;
+enum { S_COUNT = 0, S_FLAGS = 1, S_RANGE = 2, S_UNSORTED = 3 };
+
+__global__ void __launch_bounds__(kThreads)
+chain_zero_kernel(uint4* __restrict__ a, size_t na, uint4* __restrict__ b, size_t nb) {
+  const size_t stride = static_cast<size_t>(gridDim.x) * kThreads;
+  const uint4 z = make_uint4(0, 0, 0, 0);
+  for (size_t i = static_cast<size_t>(blockIdx.x) * kThreads + threadIdx.x; i < na + nb; i += stride) {
+    if (i < na) a[i] = z;
+    else b[i - na] = z;
+  }
+}
+
+__global__ void __launch_bounds__(kThreads)
+chain_keys_hist_kernel(const int64_t* __restrict__ row, const int64_t* __restrict__ col, int64_t n, int64_t M,
+                       int64_t N, int64_t* __restrict__ keys, int64_t* __restrict__ status, int passes,
+                       uint32_t* __restrict__ ghist) {
+  __shared__ uint32_t hist[kMaxPasses][kRadix];
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < kMaxPasses * kRadix; i += kThreads) (&hist[0][0])[i] = 0;
+  __syncthreads();
+  unsigned f = 0;
+  const int64_t stride = static_cast<int64_t>(gridDim.x) * kThreads;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kThreads + tid; i < n; i += stride) {
+    const int64_t r = row[i], c = col[i];
+    const int64_t k = r * N + c;
+    keys[i] = k;
+    if (r < 0 || r >= M || c < 0 || c >= N) f |= F_RANGE;
+    if (i > 0 && k < row[i - 1] * N + col[i - 1]) f |= F_UNSORTED;
+    for (int p = 0; p < passes; ++p) atomicAdd(&hist[p][digit_of(static_cast<uint64_t>(k), 8 * p)], 1u);
+  }
+  // plain, idempotent stores into two words of their own (see chain_keys_kernel)
+  if (__any(f & F_RANGE) && lane == 0) status[S_RANGE] = 1;
+  if (__any(f & F_UNSORTED) && lane == 0) status[S_UNSORTED] = 1;
+  __syncthreads();
+  for (int i = tid; i < passes * kRadix; i += kThreads) {
+    const uint32_t c = (&hist[0][0])[i];
+    if (c) atomicAdd(ghist + i, c);
+  }
+}
+
 bool small_path(int64_t n, int64_t M, int64_t N) {
   return n <= kSmallTile && M > 0 && N > 0 && static_cast<double>(M) * static_cast<double>(N) < 9.0e18;
 }
@@ -445,23 +495,44 @@ int psa_coalesce_count(const int64_t* row, const int64_t* col, const void* value
     return PSA_OK;
   }
   PSA_REQUIRE(static_cast<double>(M) * static_cast<double>(N) < 9.0e18, "M * N does not fit the 63-bit sort key");
-  PSA_ZERO(w.status, 32, s);
-  const int64_t blocks = psa::ceil_div(n, kThreads);
-  hipLaunchKernelGGL(chain_keys_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, s, row, col, n,
-                     M, N, w.a, w.status);
-  hipLaunchKernelGGL(chain_flags_kernel, dim3(1), dim3(1), 0, s, w.status);
-  PSA_LAUNCH_CHECK();
-  int st;
-  if (rides(value, dtype, D))
-    st = psa_sort_pairs_u32(w.a, value, n, M * N, w.b, w.perm, w.sort_ws, w.sort_bytes, stream);
-  else
-    st = psa_index_sort(w.a, n, M * N, w.b, w.perm, w.sort_ws, w.sort_bytes, stream);
-  if (st != PSA_OK) return st;
-  if (const uint32_t* fault = psa::sort_fault_word(w.sort_ws, n, M * N)) {
-    hipLaunchKernelGGL(chain_sort_fault_kernel, dim3(1), dim3(1), 0, s, fault, w.status);
+  const psa::SortAreas areas = psa::sort_areas(w.sort_ws, n, M * N);
+  if (areas.passes == 0 || !psa::sort_takes_prepared()) {
+    // a 1 x 1 matrix (nothing to sort) or an A/B variant of the sort selected: the plain sequence
+    PSA_ZERO(w.status, 64, s);
+    const int64_t blocks = psa::ceil_div(n, kThreads);
+    hipLaunchKernelGGL(chain_keys_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, s, row, col, n,
+                       M, N, w.a, w.status);
+    hipLaunchKernelGGL(chain_flags_kernel, dim3(1), dim3(1), 0, s, w.status);
     PSA_LAUNCH_CHECK();
+    int st;
+    if (rides(value, dtype, D))
+      st = psa_sort_pairs_u32(w.a, value, n, M * N, w.b, w.perm, w.sort_ws, w.sort_bytes, stream);
+    else
+      st = psa_index_sort(w.a, n, M * N, w.b, w.perm, w.sort_ws, w.sort_bytes, stream);
+    if (st != PSA_OK) return st;
+    if (const uint32_t* fault = psa::sort_fault_word(w.sort_ws, n, M * N)) {
+      hipLaunchKernelGGL(chain_sort_fault_kernel, dim3(1), dim3(1), 0, s, fault, w.status);
+      PSA_LAUNCH_CHECK();
+    }
+    return psa_unique_count(w.b, n, w.uniq_ws, w.uniq_bytes, w.status, stream);
   }
-  return psa_unique_count(w.b, n, w.uniq_ws, w.uniq_bytes, w.status, stream);
+  const size_t zero_b = areas.zero_bytes / 16;
+  const size_t zero_a = 256 / 16;
+  const size_t zero_items = zero_a + zero_b;
+  const unsigned zero_blocks = static_cast<unsigned>(psa::ceil_div(static_cast<int64_t>(zero_items), kThreads) < 1024
+                                                         ? psa::ceil_div(static_cast<int64_t>(zero_items), kThreads) : 1024);
+  hipLaunchKernelGGL(chain_zero_kernel, dim3(zero_blocks), dim3(kThreads), 0, s, reinterpret_cast<uint4*>(w.status),
+                     zero_a, static_cast<uint4*>(areas.zero_begin), zero_b);
+  const int64_t key_blocks = psa::ceil_div(n, kThreads * 8) < 2048 ? psa::ceil_div(n, kThreads * 8) : 2048;
+  hipLaunchKernelGGL(chain_keys_hist_kernel, dim3(static_cast<unsigned>(key_blocks)), dim3(kThreads), 0, s, row, col,
+                     n, M, N, w.a, w.status, areas.passes, areas.ghist);
+  PSA_LAUNCH_CHECK();
+  const bool rode = rides(value, dtype, D);
+  const int st = psa::sort_prepared(w.a, rode ? static_cast<const uint32_t*>(value) : nullptr, n, M * N, w.b,
+                                    rode ? nullptr : w.perm, rode ? reinterpret_cast<uint32_t*>(w.perm) : nullptr,
+                                    w.sort_ws, w.sort_bytes, s);
+  if (st != PSA_OK) return st;
+  return psa::unique_count_chain(w.b, n, w.uniq_ws, w.status, psa::sort_fault_word(w.sort_ws, n, M * N), s);
 }
 
 int psa_coalesce_small_max_fused(void) { return kSmallTile; }

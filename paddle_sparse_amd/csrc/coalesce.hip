@@ -87,7 +87,7 @@ unique_count_kernel(const int64_t* __restrict__ keys, int64_t n,
 // Single block: exclusive scan of block_counts[nb] in place; total -> *count.
 __global__ void __launch_bounds__(1024)
 scan_blocks_kernel(uint32_t* __restrict__ block_counts, int64_t nb,
-                   int64_t* __restrict__ count) {
+                   int64_t* __restrict__ count, int chain_status, const uint32_t* __restrict__ fault) {
   __shared__ uint32_t wtot[16];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -113,7 +113,12 @@ scan_blocks_kernel(uint32_t* __restrict__ block_counts, int64_t nb,
     block_counts[i] = run;
     run += c;
   }
-  if (tid == 1023) *count = static_cast<int64_t>(base) + incl;
+  if (tid == 1023) {
+    *count = static_cast<int64_t>(base) + incl;
+    // the coalesce chain's status words {count, flags, range seen, inversion seen} (chain.hip):
+    // flag bits folded here, with the sort's fault word, instead of in launches of their own
+    if (chain_status) count[1] = (count[2] ? 1 : 0) | (count[3] ? 2 : 0) | ((fault != nullptr && *fault != 0) ? 4 : 0);
+  }
 }
 
 __global__ void __launch_bounds__(kThreads)
@@ -306,6 +311,18 @@ int unique_write_packed(const int64_t* sorted_keys, int64_t n, int64_t N, const 
   return PSA_OK;
 }
 
+int unique_count_chain(const int64_t* sorted_keys, int64_t n, void* workspace, int64_t* status,
+                       const uint32_t* fault, hipStream_t s) {
+  PSA_REQUIRE(n > 0 && sorted_keys && workspace && status, "bad argument");
+  const int64_t nb = ceil_div(n, kTile);
+  PSA_REQUIRE(nb <= 0x7fffffff, "n too large for one launch");
+  uint32_t* bc = static_cast<uint32_t*>(workspace);
+  hipLaunchKernelGGL(unique_count_kernel, dim3(static_cast<unsigned>(nb)), dim3(kThreads), 0, s, sorted_keys, n, bc);
+  hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, bc, nb, status, 1, fault);
+  PSA_LAUNCH_CHECK();
+  return PSA_OK;
+}
+
 int segment_reduce_dev(int reduce, int dtype, const void* src, const int64_t* perm,
                        const int64_t* ptr, int64_t nseg_bound, const int64_t* nseg_dev,
                        int64_t D, int64_t n_hint, void* out, hipStream_t s) {
@@ -341,7 +358,8 @@ int psa_unique_count(const int64_t* sorted_keys, int64_t n, void* workspace,
   uint32_t* bc = static_cast<uint32_t*>(workspace);
   hipLaunchKernelGGL(unique_count_kernel, dim3(static_cast<unsigned>(nb)),
                      dim3(kThreads), 0, s, sorted_keys, n, bc);
-  hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, bc, nb, count_out);
+  hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, bc, nb, count_out, 0,
+                     static_cast<const uint32_t*>(nullptr));
   PSA_LAUNCH_CHECK();
   return PSA_OK;
 }

@@ -19,4 +19,26 @@ int segment_reduce_dev(int reduce, int dtype, const void* src, const int64_t* pe
                        const int64_t* ptr, int64_t nseg_bound, const int64_t* nseg_dev,
                        int64_t D, int64_t n_hint, void* out, hipStream_t s);
 
+// psa_unique_count for the coalesce chain: the block scan also writes the chain's status
+// words — status[0] = count, status[1] = flag bits from status[2] (range), status[3]
+// (inversion) and *fault (bit 2).
+int unique_count_chain(const int64_t* sorted_keys, int64_t n, void* workspace, int64_t* status,
+                       const uint32_t* fault, hipStream_t s);
+
+// ---- sort.hip: the radix passes on histograms the caller has built ----------------------------
+struct SortAreas {
+  void* zero_begin;   // [zero_bytes) must be zeroed first (look-back words, tickets, histograms)
+  size_t zero_bytes;
+  uint32_t* ghist;    // [passes][256] digit counts, filled by the caller
+  int passes;         // 8-bit passes for keys below max_value (0: all keys equal, nothing to do)
+};
+SortAreas sort_areas(void* workspace, int64_t n, int64_t max_value);
+// perm mode (pay_in NULL, perm_out int64) or pairs mode (pay_in / pay_out 32-bit payload), as
+// psa_index_sort / psa_sort_pairs_u32, minus their zero / histogram / scan launches
+int sort_prepared(const int64_t* keys, const uint32_t* pay_in, int64_t n, int64_t max_value,
+                  int64_t* sorted_out, int64_t* perm_out, uint32_t* pay_out, void* workspace,
+                  size_t workspace_bytes, hipStream_t s);
+bool sort_takes_prepared();  // false while an A/B variant of the sort is selected (psa_sort_set_variant)
+const uint32_t* sort_fault_word(const void* workspace, int64_t n, int64_t max_value);
+
 }  // namespace psa

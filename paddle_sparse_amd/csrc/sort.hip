@@ -30,6 +30,7 @@
 //      variants 1-4 kept for A/B (tools/sort_bench.py): 256-thread staged
 //      tile 7.6 ms, direct per-lane stores 8.9 ms, 512-thread tile 6.6 ms.
 // HBM traffic per pass: 8n (hist) + 12n read + 12n written (key64 + idx32).
+#include "coalesce_internal.h"
 #include "common.h"
 #include "radix_util.h"
 
@@ -501,7 +502,7 @@ iota_kernel(int64_t* __restrict__ out, int64_t n) {
 // ===========================================================================
 // Single-sweep passes (variant 5): the per-pass histogram kernel disappears.
 //   os_hist_kernel   ONE read of the keys builds the 256-bin histograms of all
-//                    passes; os_scan_kernel turns them into digit bases.
+//                    passes (each pass turns its 256 counts into digit bases itself).
 //   os_pass_kernel   tiles are handed out in order by an atomic ticket; a tile
 //                    publishes its 256 digit counts, then walks back over its
 //                    predecessors' published words until it meets an inclusive
@@ -544,40 +545,21 @@ os_hist_kernel(const uint64_t* __restrict__ keys, int64_t n, int passes, int fir
   }
 }
 
-// one block (256 threads) per pass: exclusive scan of its 256 bins
-__global__ void __launch_bounds__(kThreads)
-os_scan_kernel(const uint32_t* __restrict__ ghist, uint32_t* __restrict__ gbase) {
-  __shared__ uint32_t wtot[kWaves];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const uint32_t c = ghist[blockIdx.x * kRadix + tid];
-  uint32_t incl = c;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t o = __shfl_up(incl, off);
-    if (lane >= off) incl += o;
-  }
-  if (lane == 63) wtot[wave] = incl;
-  __syncthreads();
-  uint32_t base = 0;
-  for (int w = 0; w < wave; ++w) base += wtot[w];
-  gbase[blockIdx.x * kRadix + tid] = base + incl - c;
-}
-
 template <bool PASS0, bool LAST, int THREADS, int ITEMS>
 __global__ void __launch_bounds__(THREADS)
 os_pass_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
                uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
                int64_t* __restrict__ perm_out, int64_t n, int shift, int pass,
-               const uint32_t* __restrict__ gbase /*this pass: [256]*/,
+               const uint32_t* __restrict__ ghist /*this pass: [256] digit counts of the whole input*/,
                uint64_t* __restrict__ status /*[num_tiles][256]*/,
                uint32_t* __restrict__ ticket, uint32_t* __restrict__ err) {
   constexpr int WAVES = THREADS / 64;
   constexpr int TILE = THREADS * ITEMS;
-  static_assert(TILE == kOsTile, "status words are indexed by 8192-key tiles");
   __shared__ uint64_t skey[TILE];
   __shared__ uint32_t wcnt[WAVES][kRadix];
   __shared__ int32_t gofs[kRadix];
   __shared__ uint32_t wave_tot[4];
+  __shared__ uint32_t hist_tot[4];
   __shared__ uint32_t s_tile;
   uint32_t* sidx = reinterpret_cast<uint32_t*>(skey);
 
@@ -615,8 +597,10 @@ os_pass_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict_
   }
   __syncthreads();
   uint32_t tot = 0, incl = 0;
+  uint32_t hcount = 0, hincl = 0;  // digit `tid` over the whole input, and its inclusive scan
   uint64_t* my_status = status + static_cast<size_t>(tile) * kRadix + tid;
   if (tid < kRadix) {
+    hcount = ghist[tid];
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) {
       const uint32_t c = wcnt[w][tid];
@@ -627,20 +611,32 @@ os_pass_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict_
     __hip_atomic_store(my_status, os_pack(tile == 0 ? flag_incl : flag_agg, tot),
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     incl = tot;
+    hincl = hcount;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const uint32_t o = __shfl_up(incl, off);
-      if (lane >= off) incl += o;
+      const uint32_t ho = __shfl_up(hincl, off);
+      if (lane >= off) {
+        incl += o;
+        hincl += ho;
+      }
     }
-    if (lane == 63) wave_tot[wave] = incl;
+    if (lane == 63) {
+      wave_tot[wave] = incl;
+      hist_tot[wave] = hincl;
+    }
   }
   __syncthreads();
-  uint32_t dstart = 0;
+  uint32_t dstart = 0, dbase = 0;  // first slot of digit `tid` inside the tile / in the output
   if (tid < kRadix) {
-    uint32_t wprefix = 0;
+    uint32_t wprefix = 0, hprefix = 0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) wprefix += w < wave ? wave_tot[w] : 0u;
+    for (int w = 0; w < 4; ++w) {
+      wprefix += w < wave ? wave_tot[w] : 0u;
+      hprefix += w < wave ? hist_tot[w] : 0u;
+    }
     dstart = wprefix + incl - tot;
+    dbase = hprefix + hincl - hcount;
 #pragma unroll
     for (int w = 0; w < WAVES; ++w) wcnt[w][tid] += dstart;
   }
@@ -681,7 +677,7 @@ os_pass_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict_
       __hip_atomic_store(my_status, os_pack(flag_incl, excl + tot), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
     }
-    gofs[tid] = static_cast<int32_t>(gbase[tid] + excl) - static_cast<int32_t>(dstart);
+    gofs[tid] = static_cast<int32_t>(dbase + excl) - static_cast<int32_t>(dstart);
   }
   __syncthreads();
   uint32_t dst[ITEMS];
@@ -709,6 +705,15 @@ os_pass_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict_
   }
 }
 
+// Keys per tile of a single-sweep pass.  8192 keeps the store runs long once the input
+// fills the chip; a mid-size input (a few hundred thousand keys) is one wave of workgroups
+// either way and finishes sooner with less work per workgroup.
+constexpr int64_t kOsSmallBelow = int64_t{1} << 20;  // the A/B shapes (variants 8-11) apply below this
+constexpr int64_t kOsMidBelow = int64_t{1} << 19;    // production: 1024 x 4 below, 512 x 16 from here
+constexpr int kOsSmallTile = 2048;  // smallest tile any configuration uses (sizes the status words)
+
+size_t os_status_bytes(int64_t n);
+
 struct SortPlan {
   int passes;
   int64_t num_tiles;
@@ -731,6 +736,12 @@ int bits_for(int64_t max_value) {
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// look-back words of one pass: [tiles][256] x 8 bytes, sized for the smallest tile n may get
+size_t os_status_bytes(int64_t n) {
+  const int64_t tiles = psa::ceil_div(n > 0 ? n : 1, n < kOsSmallBelow ? kOsSmallTile : kOsTile);
+  return align_up(static_cast<size_t>(tiles) * kRadix * sizeof(uint64_t), 256);
+}
+
 SortPlan make_plan(int64_t n, int64_t max_value) {
   SortPlan p;
   p.passes = (bits_for(max_value) + 7) / 8;
@@ -746,8 +757,7 @@ SortPlan make_plan(int64_t n, int64_t max_value) {
   p.counts_bytes =
       align_up(sizeof(uint32_t) * kRadix * (static_cast<size_t>(p.num_blocks) + 8), 256);
   // single-sweep area: status words, histograms / bases of all passes, tickets, err
-  const size_t os_tiles = static_cast<size_t>(psa::ceil_div(n > 0 ? n : 1, kOsTile));
-  p.os_bytes = align_up(os_tiles * kRadix * sizeof(uint64_t), 256) +
+  p.os_bytes = os_status_bytes(n) +
                align_up(2 * kOsMaxPasses * kRadix * sizeof(uint32_t), 256) + 256;
   p.total_bytes = 2 * p.keys_bytes + 2 * p.idx_bytes + p.counts_bytes + p.os_bytes;
   return p;
@@ -1022,7 +1032,9 @@ size_t psa_index_sort_workspace_bytes(int64_t n, int64_t max_value) {
 static int sort_impl(const char* who, const int64_t* keys, const uint32_t* pay_in,
                      int64_t n, int64_t max_value, int64_t* sorted_out,
                      int64_t* perm_out, uint32_t* pay_out, void* workspace,
-                     size_t workspace_bytes, hipStream_t s, int first_bit = 0) {
+                     size_t workspace_bytes, hipStream_t s, int first_bit = 0, bool prepared = false) {
+  // prepared: the caller has zeroed the single-sweep area and filled the histograms and digit
+  // bases of every pass already (psa::sort_areas; the coalesce chain does both in its key pass)
   // first_bit > 0: order by the bit field (key >> first_bit) < max_value only;
   // the bits below ride along inside the key (stable, like any other payload)
   const SortPlan p = make_plan(n, max_value);
@@ -1061,22 +1073,33 @@ static int sort_impl(const char* who, const int64_t* keys, const uint32_t* pay_i
   // 0 (production) and 5: single-sweep passes with decoupled look-back
   // (0: 512 threads x 16 keys, two blocks per CU; 5: 1024 x 8, one block);
   // 1-4, 7: the three-launch-per-pass family, kept for A/B.
-  if (variant == 0 || variant == 5) {
+  PSA_REQUIRE(!prepared || variant == 0, "prepared histograms need the single-sweep passes");
+  if (variant == 0 || variant == 5 || (variant >= 8 && variant <= 11)) {
     char* os = ws + 2 * p.keys_bytes + 2 * p.idx_bytes + p.counts_bytes;
-    const size_t os_tiles = static_cast<size_t>(psa::ceil_div(n, kOsTile));
-    const size_t status_bytes = align_up(os_tiles * kRadix * sizeof(uint64_t), 256);
+    // tile shape: 0 production rule, 5 / 8-11 forced for A/B (tools/sort_tiles.py)
+    int os_threads = 512, os_items = 16;
+    if (variant == 5) os_threads = 1024, os_items = 8;
+    if (variant == 0 && n < kOsMidBelow) os_threads = 1024, os_items = 4;  // profiles/r02_sort_tiles.txt
+    if (n < kOsSmallBelow) {
+      if (variant == 8) os_threads = 512, os_items = 4;
+      if (variant == 9) os_threads = 512, os_items = 8;
+      if (variant == 10) os_threads = 256, os_items = 8;
+      if (variant == 11) os_threads = 1024, os_items = 4;
+    }
+    const int os_tile = os_threads * os_items;
+    const size_t os_tiles = static_cast<size_t>(psa::ceil_div(n, os_tile));
+    const size_t status_bytes = os_status_bytes(n);
     uint64_t* status = reinterpret_cast<uint64_t*>(os);
     uint32_t* ghist = reinterpret_cast<uint32_t*>(os + status_bytes);
-    uint32_t* gbase_all = ghist + kOsMaxPasses * kRadix;
-    uint32_t* tickets = gbase_all + kOsMaxPasses * kRadix;  // [kOsMaxPasses] + err word
+    uint32_t* tickets = ghist + 2 * kOsMaxPasses * kRadix;  // [kOsMaxPasses] + err word
     uint32_t* err = tickets + kOsMaxPasses;
-    PSA_ZERO(os, p.os_bytes, s);
-    const int hist_blocks = static_cast<int>(psa::ceil_div(n, kThreads * 16) < 2048
-                                                 ? psa::ceil_div(n, kThreads * 16) : 2048);
-    hipLaunchKernelGGL(os_hist_kernel, dim3(hist_blocks), block, 0, s, kin, n, p.passes, first_bit, ghist);
-    hipLaunchKernelGGL(os_scan_kernel, dim3(p.passes), block, 0, s, ghist, gbase_all);
-    const bool narrow = variant == 0;  // 512 threads x 16 keys, 2 blocks / CU
-    const dim3 os_grid(static_cast<unsigned>(os_tiles)), os_block(narrow ? 512 : 1024);
+    if (!prepared) {
+      PSA_ZERO(os, p.os_bytes, s);
+      const int hist_blocks = static_cast<int>(psa::ceil_div(n, kThreads * 16) < 2048
+                                                   ? psa::ceil_div(n, kThreads * 16) : 2048);
+      hipLaunchKernelGGL(os_hist_kernel, dim3(hist_blocks), block, 0, s, kin, n, p.passes, first_bit, ghist);
+    }
+    const dim3 os_grid(static_cast<unsigned>(os_tiles)), os_block(os_threads);
     for (int pass = 0; pass < p.passes; ++pass) {
       const int shift = first_bit + 8 * pass;
       const bool last = pass == p.passes - 1;
@@ -1086,12 +1109,16 @@ static int sort_impl(const char* who, const int64_t* keys, const uint32_t* pay_i
       uint32_t* iout = last ? pay_out : ibuf[pass & 1];
 #define PSA_OS1(P0, L, T, I)                                                                  \
   hipLaunchKernelGGL((os_pass_kernel<P0, L, T, I>), os_grid, os_block, 0, s, kin, iin, kout, \
-                     iout, perm_out, n, shift, pass, gbase_all + pass * kRadix, status,      \
+                     iout, perm_out, n, shift, pass, ghist + pass * kRadix, status,          \
                      tickets + pass, err)
-#define PSA_OS(P0, L)                          \
-  do {                                         \
-    if (narrow) PSA_OS1(P0, L, 512, 16);       \
-    else PSA_OS1(P0, L, 1024, 8);              \
+#define PSA_OS(P0, L)                                                   \
+  do {                                                                  \
+    if (os_threads == 512 && os_items == 16) PSA_OS1(P0, L, 512, 16);   \
+    else if (os_threads == 1024 && os_items == 8) PSA_OS1(P0, L, 1024, 8); \
+    else if (os_threads == 512 && os_items == 4) PSA_OS1(P0, L, 512, 4);  \
+    else if (os_threads == 512 && os_items == 8) PSA_OS1(P0, L, 512, 8);  \
+    else if (os_threads == 256 && os_items == 8) PSA_OS1(P0, L, 256, 8);  \
+    else PSA_OS1(P0, L, 1024, 4);                                       \
   } while (0)
       if (iota_payload && widen) PSA_OS(true, true);
       else if (iota_payload) PSA_OS(true, false);
@@ -1151,6 +1178,31 @@ int psa_index_sort(const int64_t* keys, int64_t n, int64_t max_value,
 }  // extern "C"
 
 namespace psa {
+// The words of `workspace` a caller fills to run the passes without the sort's own
+// zero / histogram / scan launches (sort_prepared below).  zero_begin[0 .. zero_bytes) must be
+// zero before anything else touches it; ghist[p * 256 + d] counts the keys whose digit p is d
+// (every pass scans its 256 counts itself).  passes == 0: nothing to prepare.
+SortAreas sort_areas(void* workspace, int64_t n, int64_t max_value) {
+  SortAreas a{};
+  if (n <= 0 || workspace == nullptr) return a;
+  const SortPlan p = make_plan(n, max_value);
+  a.passes = p.passes;
+  char* os = static_cast<char*>(workspace) + 2 * p.keys_bytes + 2 * p.idx_bytes + p.counts_bytes;
+  a.zero_begin = os;
+  a.zero_bytes = p.os_bytes;
+  a.ghist = reinterpret_cast<uint32_t*>(os + os_status_bytes(n));
+  return a;
+}
+
+bool sort_takes_prepared() { return (g_sort_variant & 15) == 0; }
+
+int sort_prepared(const int64_t* keys, const uint32_t* pay_in, int64_t n, int64_t max_value,
+                  int64_t* sorted_out, int64_t* perm_out, uint32_t* pay_out, void* workspace,
+                  size_t workspace_bytes, hipStream_t s) {
+  return sort_impl("sort_prepared", keys, pay_in, n, max_value, sorted_out, perm_out, pay_out, workspace,
+                   workspace_bytes, s, 0, true);
+}
+
 // Device address of the sort's look-back diagnostic word inside `workspace` (NULL when the
 // sort had nothing to do): non-zero after a bounded spin of a pass gave up, i.e. the order is
 // invalid.  Callers that read a count from the device anyway fold it into that read (chain.hip).
@@ -1160,9 +1212,7 @@ const uint32_t* sort_fault_word(const void* workspace, int64_t n, int64_t max_va
   if (p.passes == 0) return nullptr;
   const char* os = static_cast<const char*>(workspace) + 2 * p.keys_bytes + 2 * p.idx_bytes +
                    p.counts_bytes;
-  const size_t status_bytes =
-      align_up(static_cast<size_t>(ceil_div(n, kOsTile)) * kRadix * sizeof(uint64_t), 256);
-  return reinterpret_cast<const uint32_t*>(os + status_bytes) + 2 * kOsMaxPasses * kRadix + kOsMaxPasses;
+  return reinterpret_cast<const uint32_t*>(os + os_status_bytes(n)) + 2 * kOsMaxPasses * kRadix + kOsMaxPasses;
 }
 }  // namespace psa
 
