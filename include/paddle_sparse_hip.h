@@ -160,7 +160,9 @@ int psa_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
  * MB that stay cache resident — R-MAT scale 21 goes 2.03 -> 1.43 ms.  The caller
  * keeps, per matrix, the list of hot columns and the redirected col array
  * (paddle_sparse_amd/storage.py::_hot_columns), and per call gathers the hot
- * rows of the current mat with psa_gather_rows (13 us for 65 536 rows). */
+ * rows of the current mat with psa_gather_rows (13 us for 65 536 rows).
+ * arg_width: bytes per entry of arg_bytes, 1 (as psa_spmm) or 2 — (index in the
+ * row) & 0xffff, exact up to 65 536 entries per row; see psa_spmm_minmax_bw_csc. */
 typedef enum psa_spmm_algo {
   PSA_SPMM_AUTO = 0,        /* today: PSA_SPMM_ROW_WAVES */
   PSA_SPMM_ROW_WAVES = 1,   /* one wavefront per CSR row (+ the long-row chunks) */
@@ -171,8 +173,9 @@ int psa_spmm_coo(int reduce, const int64_t* rowptr, const int64_t* row,
                  const int64_t* col, const float* value, const float* mat,
                  const float* hot_rows, int64_t num_hot,
                  int64_t M, int64_t N, int64_t K, int64_t nnz, float* out,
-                 int64_t ldo, int64_t* arg_out, uint8_t* arg_bytes, int algo,
-                 void* workspace, size_t workspace_bytes, psa_stream_t stream);
+                 int64_t ldo, int64_t* arg_out, void* arg_bytes, int arg_width,
+                 int algo, void* workspace, size_t workspace_bytes,
+                 psa_stream_t stream);
 
 /* psa_spmm with half-width dense operands: mat and out are fp16 (PSA_F16) or
  * bf16 (PSA_BF16) [N, K] / [M, K] row-major, every product and sum is fp32 and
@@ -262,18 +265,34 @@ int psa_spmm_minmax_bw(const int64_t* col, const float* value, const float* mat,
  * puts it into the CSR order the API returns (a 4-byte scatter from inside the
  * pass costs more than that gather).
  * workspace: psa_spmm_minmax_bw_csc_workspace_bytes(M, K, nnz) bytes, 16-byte
- * aligned (M*K bytes of arg_out compressed to row-local byte indices +
- * long-column scratch).  Returns PSA_ERR_UNSUPPORTED unless K % 4 == 0 and
- * K <= 256 (callers then use psa_spmm_minmax_bw). */
+ * aligned (arg_out compressed to its row-local form + long-column scratch).
+ * Returns PSA_ERR_UNSUPPORTED unless K % 4 == 0 and K <= 256 (callers then
+ * use psa_spmm_minmax_bw).
+ *
+ * arg_width (1 or 2): bytes per entry of arg_bytes and of tag — the width
+ * psa_spmm_coo wrote and psa_csc_edge_tags was asked for.  Width 2 holds
+ * (index in the row) & 0xffff: exact for rows of up to 65 536 entries, so on a
+ * power-law graph (R-MAT scale 21: longest row 41 677) the forward stores
+ * 2 bytes per element instead of 8 + 1 and this pass needs no arg_out.
+ *
+ * hot_grad f32[num_hot, K] / hot_bytes [num_hot, K] entries / num_hot (NULL,
+ * NULL, 0 = off): compact copies of the most referenced rows of grad and of
+ * arg_bytes.  Ids in [M, M + num_hot) in row_csc then name row id - M of the
+ * copies (the hub rows of a power-law graph, as hot_rows of psa_spmm_coo;
+ * R-MAT scale 21 as generated: the pass runs 1.9 ms faster with the hubs'
+ * rows relabelled away from their crowded addresses).  Needs an exact
+ * arg_bytes (arg_out NULL). */
 int psa_csc_edge_tags(const int64_t* rowptr, const int64_t* row_csc,
-                      const int64_t* csr2csc, int64_t nnz, uint8_t* tag,
-                      psa_stream_t stream);
+                      const int64_t* csr2csc, int64_t nnz, void* tag,
+                      int width, psa_stream_t stream);
 size_t psa_spmm_minmax_bw_csc_workspace_bytes(int64_t M, int64_t K, int64_t nnz);
 int psa_spmm_minmax_bw_csc(const int64_t* rowptr, const int64_t* colptr,
                            const int64_t* row_csc, const int64_t* csr2csc,
-                           const uint8_t* tag, const float* value,
+                           const void* tag, const float* value,
                            const float* mat, const float* grad,
-                           const int64_t* arg_out, const uint8_t* arg_bytes,
+                           const int64_t* arg_out, const void* arg_bytes,
+                           int arg_width, const float* hot_grad,
+                           const void* hot_bytes, int64_t num_hot,
                            int64_t M, int64_t N,
                            int64_t K, int64_t nnz, float* grad_value_csc,
                            float* grad_mat, void* workspace,
@@ -290,14 +309,18 @@ int psa_spmm_minmax_bw_csc(const int64_t* rowptr, const int64_t* colptr,
  * row_scale[r] (mean: 1 / max(deg(r), 1), folded in per edge instead of a
  * pre-scaling pass over grad).
  * grad_value_csc: f32[nnz] in CSC order or NULL (CSR order: psa_gather_rows
- * through csc2csr, as above).  workspace:
+ * through csc2csr, as above).  hot_grad f32[num_hot, K] / num_hot (NULL / 0 =
+ * off): compact copy of the most referenced rows of grad; ids in
+ * [M, M + num_hot) in row_csc name its rows (row_scale then has M + num_hot
+ * entries, the copies' scales at the end).  M = rows of grad.  workspace:
  * psa_spmm_sum_bw_csc_workspace_bytes(K, nnz) bytes, 16-byte aligned.
  * PSA_ERR_UNSUPPORTED unless K % 4 == 0 and K <= 256. */
 size_t psa_spmm_sum_bw_csc_workspace_bytes(int64_t K, int64_t nnz);
 int psa_spmm_sum_bw_csc(const int64_t* colptr, const int64_t* row_csc,
                         const int64_t* csr2csc, const float* value,
                         const float* row_scale, const float* mat,
-                        const float* grad, int64_t N,
+                        const float* grad, const float* hot_grad,
+                        int64_t num_hot, int64_t M, int64_t N,
                         int64_t K, int64_t nnz, float* grad_value_csc,
                         float* grad_mat, void* workspace,
                         size_t workspace_bytes, psa_stream_t stream);

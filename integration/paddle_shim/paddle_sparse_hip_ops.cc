@@ -137,7 +137,11 @@ static std::vector<paddle::Tensor> spmm_impl(int reduce, paddle::Tensor& rowptr,
                                              const paddle::optional<paddle::Tensor>& value,
                                              const paddle::optional<paddle::Tensor>& row, paddle::Tensor& mat,
                                              const paddle::optional<paddle::Tensor>& hot_rows, int64_t algo,
-                                             bool want_arg, bool want_arg_bytes) {
+                                             bool want_arg, int64_t arg_width) {
+  // arg_width: 0 = no row-local form of arg_out; 1 = one byte per element (exact for rows of up to
+  // 128 entries); 2 = two bytes (exact up to 65 536: power-law graphs) -- see psa_spmm_minmax_bw_csc
+  PD_CHECK(arg_width >= 0 && arg_width <= 2, "arg_width must be 0, 1 or 2");
+  const bool want_arg_bytes = arg_width > 0;
   CHECK_GPU(mat);
   CHECK_I64(rowptr);
   CHECK_I64(col);
@@ -147,14 +151,16 @@ static std::vector<paddle::Tensor> spmm_impl(int reduce, paddle::Tensor& rowptr,
   const bool minmax = reduce == PSA_MIN || reduce == PSA_MAX;
   auto arg = minmax && want_arg ? paddle::empty({M, K}, paddle::DataType::INT64, mat.place())
                                 : paddle::empty({0}, paddle::DataType::INT64, mat.place());
-  auto arg_bytes = minmax && want_arg_bytes ? paddle::empty({M, K}, paddle::DataType::UINT8, mat.place())
-                                            : paddle::empty({0}, paddle::DataType::UINT8, mat.place());
+  const auto local_dtype = arg_width == 2 ? paddle::DataType::INT16 : paddle::DataType::UINT8;
+  auto arg_bytes = minmax && want_arg_bytes ? paddle::empty({M, K}, local_dtype, mat.place())
+                                            : paddle::empty({0}, local_dtype, mat.place());
   const size_t ws_bytes = psa_spmm_workspace_bytes(reduce, K, nnz);
   auto ws = scratch(ws_bytes, mat.place());
   PSA_CALL(psa_spmm_coo(reduce, i64(rowptr), i64_or_null(row), i64(col), f32_or_null(value), f32(mat),
                         f32_or_null(hot_rows), hot_rows ? hot_rows.get().shape()[0] : 0, M, N, K, nnz,
                         out.data<float>(), /*ldo=*/0, minmax && want_arg ? arg.data<int64_t>() : nullptr,
-                        minmax && want_arg_bytes ? arg_bytes.data<uint8_t>() : nullptr, static_cast<int>(algo),
+                        minmax && want_arg_bytes ? arg_bytes.data() : nullptr, arg_width == 2 ? 2 : 1,
+                        static_cast<int>(algo),
                         ws_bytes > 0 ? ws.data<uint8_t>() : nullptr, ws_bytes, stream_of(mat)));
   return {out, arg, arg_bytes};
 }
@@ -164,15 +170,15 @@ static std::vector<paddle::Tensor> spmm_impl(int reduce, paddle::Tensor& rowptr,
                                    const paddle::optional<paddle::Tensor>& row,               \
                                    paddle::Tensor& mat,                                       \
                                    const paddle::optional<paddle::Tensor>& hot_rows,          \
-                                   int64_t algo, bool want_arg, bool want_arg_bytes) {        \
+                                   int64_t algo, bool want_arg, int64_t arg_width) {          \
     return spmm_impl(RED, rowptr, col, value, row, mat, hot_rows, algo, want_arg,             \
-                     want_arg_bytes);                                                         \
+                     arg_width);                                                              \
   }                                                                                           \
   PD_BUILD_OP(NAME)                                                                           \
       .Inputs({"rowptr", "col", paddle::Optional("value"), paddle::Optional("row"), "mat",     \
                paddle::Optional("hot_rows")})                                                 \
       .Outputs({"out", "arg_out", "arg_bytes"})                                               \
-      .Attrs({"algo: int64_t", "want_arg: bool", "want_arg_bytes: bool"})                     \
+      .Attrs({"algo: int64_t", "want_arg: bool", "arg_width: int64_t"})                       \
       .SetKernelFn(PD_KERNEL(NAME));
 PSA_SPMM_OP(spmm_sum, PSA_SUM)
 PSA_SPMM_OP(spmm_mean, PSA_MEAN)
@@ -274,17 +280,24 @@ PD_BUILD_OP(spmm_minmax_bw)
     .SetKernelFn(PD_KERNEL(spmm_minmax_bw));
 
 // position of every CSC-ordered edge inside its CSR row (structure only: cache it with csr2csc)
-std::vector<paddle::Tensor> csc_edge_tags(paddle::Tensor& rowptr, paddle::Tensor& row_csc, paddle::Tensor& csr2csc) {
+std::vector<paddle::Tensor> csc_edge_tags(paddle::Tensor& rowptr, paddle::Tensor& row_csc, paddle::Tensor& csr2csc,
+                                          int64_t width) {
+  PD_CHECK(width == 1 || width == 2, "width must be 1 or 2");
   CHECK_GPU(csr2csc);
   CHECK_I64(rowptr);
   CHECK_I64(row_csc);
   CHECK_I64(csr2csc);
   const int64_t nnz = csr2csc.numel();
-  auto tag = paddle::empty({nnz}, paddle::DataType::UINT8, csr2csc.place());
-  PSA_CALL(psa_csc_edge_tags(i64(rowptr), i64(row_csc), i64(csr2csc), nnz, tag.data<uint8_t>(), stream_of(csr2csc)));
+  auto tag = paddle::empty({nnz}, width == 2 ? paddle::DataType::INT16 : paddle::DataType::UINT8, csr2csc.place());
+  PSA_CALL(psa_csc_edge_tags(i64(rowptr), i64(row_csc), i64(csr2csc), nnz, tag.data(), static_cast<int>(width),
+                             stream_of(csr2csc)));
   return {tag};
 }
-PD_BUILD_OP(csc_edge_tags).Inputs({"rowptr", "row_csc", "csr2csc"}).Outputs({"tag"}).SetKernelFn(PD_KERNEL(csc_edge_tags));
+PD_BUILD_OP(csc_edge_tags)
+    .Inputs({"rowptr", "row_csc", "csr2csc"})
+    .Outputs({"tag"})
+    .Attrs({"width: int64_t"})
+    .SetKernelFn(PD_KERNEL(csc_edge_tags));
 
 // min/max backward, both gradients in one pass over the CSC view, no atomics; grad_value comes back
 // in CSR order (the pass writes CSC order, one gather through csc2csr follows)
@@ -292,8 +305,13 @@ std::vector<paddle::Tensor> spmm_minmax_bw_csc(paddle::Tensor& rowptr, paddle::T
                                                paddle::Tensor& csr2csc, paddle::Tensor& csc2csr, paddle::Tensor& tag,
                                                const paddle::optional<paddle::Tensor>& value, paddle::Tensor& mat,
                                                paddle::Tensor& grad, const paddle::optional<paddle::Tensor>& arg_out,
-                                               const paddle::optional<paddle::Tensor>& arg_bytes, bool want_value) {
+                                               const paddle::optional<paddle::Tensor>& arg_bytes,
+                                               const paddle::optional<paddle::Tensor>& hot_grad,
+                                               const paddle::optional<paddle::Tensor>& hot_bytes, bool want_value) {
+  // tag / arg_bytes: UINT8 (one byte per entry) or INT16 (two); hot_grad / hot_bytes: compact copies of
+  // the rows of grad / arg_bytes that row_csc names as M + position (psa_gather_rows by the caller)
   CHECK_GPU(grad);
+  const int width = tag.dtype() == paddle::DataType::INT16 ? 2 : 1;
   const int64_t M = grad.shape()[0], K = grad.shape()[1], N = colptr.numel() - 1, nnz = csr2csc.numel();
   const auto place = grad.place();
   auto gv_csc = paddle::empty({want_value ? nnz : 0}, grad.dtype(), place);
@@ -301,9 +319,11 @@ std::vector<paddle::Tensor> spmm_minmax_bw_csc(paddle::Tensor& rowptr, paddle::T
   auto gm = paddle::empty({N, K}, grad.dtype(), place);
   const size_t ws_bytes = psa_spmm_minmax_bw_csc_workspace_bytes(M, K, nnz);
   auto ws = scratch(ws_bytes, place);
-  PSA_CALL(psa_spmm_minmax_bw_csc(i64(rowptr), i64(colptr), i64(row_csc), i64(csr2csc), tag.data<uint8_t>(),
+  PSA_CALL(psa_spmm_minmax_bw_csc(i64(rowptr), i64(colptr), i64(row_csc), i64(csr2csc), tag.data(),
                                   f32_or_null(value), want_value ? f32(mat) : nullptr, f32(grad), i64_or_null(arg_out),
-                                  arg_bytes ? arg_bytes.get().data<uint8_t>() : nullptr, M, N, K, nnz,
+                                  arg_bytes ? arg_bytes.get().data() : nullptr, width, f32_or_null(hot_grad),
+                                  hot_bytes ? hot_bytes.get().data() : nullptr,
+                                  hot_grad ? hot_grad.get().shape()[0] : 0, M, N, K, nnz,
                                   want_value ? gv_csc.data<float>() : nullptr, gm.data<float>(), ws.data<uint8_t>(),
                                   ws_bytes, stream_of(grad)));
   if (want_value) PSA_CALL(psa_gather_rows(gv_csc.data<float>(), i64(csc2csr), nnz, 4, gv.data<float>(), stream_of(grad)));
@@ -311,7 +331,8 @@ std::vector<paddle::Tensor> spmm_minmax_bw_csc(paddle::Tensor& rowptr, paddle::T
 }
 PD_BUILD_OP(spmm_minmax_bw_csc)
     .Inputs({"rowptr", "colptr", "row_csc", "csr2csc", "csc2csr", "tag", paddle::Optional("value"), "mat", "grad",
-             paddle::Optional("arg_out"), paddle::Optional("arg_bytes")})
+             paddle::Optional("arg_out"), paddle::Optional("arg_bytes"), paddle::Optional("hot_grad"),
+             paddle::Optional("hot_bytes")})
     .Outputs({"grad_value", "grad_mat"})
     .Attrs({"want_value: bool"})
     .SetKernelFn(PD_KERNEL(spmm_minmax_bw_csc));
@@ -320,9 +341,12 @@ PD_BUILD_OP(spmm_minmax_bw_csc)
 std::vector<paddle::Tensor> spmm_sum_bw_csc(paddle::Tensor& colptr, paddle::Tensor& row_csc, paddle::Tensor& csr2csc,
                                             paddle::Tensor& csc2csr, const paddle::optional<paddle::Tensor>& value,
                                             const paddle::optional<paddle::Tensor>& row_scale, paddle::Tensor& mat,
-                                            paddle::Tensor& grad, bool want_value) {
+                                            paddle::Tensor& grad, const paddle::optional<paddle::Tensor>& hot_grad,
+                                            bool want_value) {
+  // hot_grad: compact copy of the rows of grad that row_csc names as M + position (row_scale then
+  // carries their scales behind its M entries)
   CHECK_GPU(grad);
-  const int64_t K = grad.shape()[1], N = colptr.numel() - 1, nnz = csr2csc.numel();
+  const int64_t M = grad.shape()[0], K = grad.shape()[1], N = colptr.numel() - 1, nnz = csr2csc.numel();
   const auto place = grad.place();
   auto gv_csc = paddle::empty({want_value ? nnz : 0}, grad.dtype(), place);
   auto gv = paddle::empty({want_value ? nnz : 0}, grad.dtype(), place);
@@ -330,7 +354,8 @@ std::vector<paddle::Tensor> spmm_sum_bw_csc(paddle::Tensor& colptr, paddle::Tens
   const size_t ws_bytes = psa_spmm_sum_bw_csc_workspace_bytes(K, nnz);
   auto ws = scratch(ws_bytes, place);
   PSA_CALL(psa_spmm_sum_bw_csc(i64(colptr), i64(row_csc), i64(csr2csc), f32_or_null(value), f32_or_null(row_scale),
-                               want_value ? f32(mat) : nullptr, f32(grad), N, K, nnz,
+                               want_value ? f32(mat) : nullptr, f32(grad), f32_or_null(hot_grad),
+                               hot_grad ? hot_grad.get().shape()[0] : 0, M, N, K, nnz,
                                want_value ? gv_csc.data<float>() : nullptr, gm.data<float>(), ws.data<uint8_t>(),
                                ws_bytes, stream_of(grad)));
   if (want_value) PSA_CALL(psa_gather_rows(gv_csc.data<float>(), i64(csc2csr), nnz, 4, gv.data<float>(), stream_of(grad)));
@@ -338,7 +363,7 @@ std::vector<paddle::Tensor> spmm_sum_bw_csc(paddle::Tensor& colptr, paddle::Tens
 }
 PD_BUILD_OP(spmm_sum_bw_csc)
     .Inputs({"colptr", "row_csc", "csr2csc", "csc2csr", paddle::Optional("value"), paddle::Optional("row_scale"), "mat",
-             "grad"})
+             "grad", paddle::Optional("hot_grad")})
     .Outputs({"grad_value", "grad_mat"})
     .Attrs({"want_value: bool"})
     .SetKernelFn(PD_KERNEL(spmm_sum_bw_csc));

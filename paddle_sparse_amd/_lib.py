@@ -34,7 +34,7 @@ SIGNATURES = {
                          c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                          c_size_t, c_void_p]),
     "psa_spmm_coo": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
-                             c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p,
+                             c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int, c_int, c_void_p,
                              c_size_t, c_void_p]),
     "psa_spmm_half": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64,
                               c_int64, c_void_p, c_void_p, c_void_p]),
@@ -48,13 +48,15 @@ SIGNATURES = {
                                       c_int, c_void_p, c_void_p]),
     "psa_spmm_minmax_bw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                    c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
-    "psa_csc_edge_tags": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "psa_csc_edge_tags": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p]),
     "psa_spmm_minmax_bw_csc_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64]),
     "psa_spmm_minmax_bw_csc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                       c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64,
+                                       c_int64, c_int64, c_int64,
                                        c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "psa_spmm_sum_bw_csc_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "psa_spmm_sum_bw_csc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_int64, c_int64,
                                     c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                     c_size_t, c_void_p]),
     "psa_index_sort_workspace_bytes": (c_size_t, [c_int64, c_int64]),

@@ -92,7 +92,17 @@ using psa::push_long_row;
 enum { M_PLAIN = 0, M_MASK = 1, M_CSC = 2, M_NOARG = 3 };
 
 constexpr int kFusedChunkBlocksDefault = 768;
-constexpr int kByteExact = 128;  // rows up to this many edges: the one-byte form of arg_out is exact
+using psa::arg_local;
+using psa::kByteExact;
+using psa::kWordExact;
+using psa::store_arg_local1;
+using psa::store_arg_local4;
+
+// where a forward leaves the row-local form of arg_out, and how wide its entries are
+struct ArgLocal {
+  uint8_t* p = nullptr;
+  int width = 1;
+};
 
 struct MaskArgs {
   const uint8_t* bytes = nullptr;    // [M, K] at the lane's k0
@@ -103,7 +113,21 @@ struct MaskArgs {
   const float* mrow = nullptr;       // set by the kernel: mat[c, k0..] of the wave's column
   float* grad_value = nullptr;       // [nnz] in CSC order (position j <-> edge edge_id[j]), or NULL
   uint8_t* arg_bytes_out = nullptr;  // M_PLAIN min/max: also store arg_out as row-local bytes (see M_MASK)
+  int arg_width = 1;                 // bytes per entry of bytes / tag / arg_bytes_out: 1 or 2 (vec_io.h)
+  // M_MASK / M_CSC: ids >= hot_first in `col` name rows of a compact copy of the gathered operand
+  // (hot, [h, K]) and of bytes (hot_bytes): the hub rows of a power-law graph, which otherwise
+  // crowd a few memory channels
+  const float* hot = nullptr;
+  const uint8_t* hot_bytes = nullptr;
+  int64_t hot_first = INT64_MAX;
   const float* row_scale = nullptr;  // M_CSC, mean: 1 / max(deg(r), 1) per CSR row, folded into both gradients
+  // row role: inside every group of 8 consecutive row blocks, hand the blocks to the XCDs in an
+  // order hashed from the group number.  Workgroups go to the 8 XCDs round-robin, so XCD x would
+  // otherwise own the rows whose id has bits 2-4 equal to x; on a graph whose row lengths follow
+  // the bits of the id (R-MAT as generated: a column of the CSC view is heavy when its id has few
+  // bits set) XCD 0 then gets 32x the edges of XCD 7 and the launch waits for it
+  // (profiles/r02_rmat_backward.txt: same requests, same wave-cycles, 1.4x the duration).
+  int mix_xcds = 0;
   int xcd_rows = 0;                  // row role: give each XCD one contiguous eighth of the rows
   int temporal_out = 0;              // A/B hook (variant 17): ordinary instead of non-temporal output stores
   int chunk_blocks = kFusedChunkBlocksDefault;  // workgroups in the chunk role (variants 20-22 for A/B)
@@ -154,7 +178,10 @@ __device__ __forceinline__ void reduce_edge_range(
           s_l = m.row_scale[c_l];
           v_l *= s_l;
         }
-        if (MASK) id_l |= static_cast<int64_t>(m.tag[base + lane]) << 56;
+        if (MASK) {  // the tag rides in the top bits of the edge id (ids stay below 2^48)
+          if (m.arg_width == 2) id_l |= static_cast<int64_t>(reinterpret_cast<const uint16_t*>(m.tag)[base + lane]) << 48;
+          else id_l |= static_cast<int64_t>(m.tag[base + lane]) << 56;
+        }
       } else {
         v_l = val ? val[base + lane] : 1.f;
       }
@@ -163,7 +190,7 @@ __device__ __forceinline__ void reduce_edge_range(
       float b[U][VEC];
       float w[U];
       bool ok[U];
-      uint32_t mb[U];
+      uint32_t mb[U], mb2[U];  // the (row, k0 .. k0 + 3) entries of bytes: 4 x 1 byte, or 4 x 2 bytes in two words
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int idx = j + u * G + g;  // < 64 by the static_assert
@@ -172,13 +199,25 @@ __device__ __forceinline__ void reduce_edge_range(
         ok[u] = (idx < n) && kact;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) b[u][i] = 0.f;
+        const bool is_hot = INDIRECT && c >= m.hot_first;
         if (ok[u]) {
-          if (m.nt_gather) load_vec_nt<VEC>(matk + c * K, b[u]);
-          else load_vec<VEC>(matk + c * K, b[u]);
+          const float* src = is_hot ? m.hot + (c - m.hot_first) * K : matk + c * K;
+          if (m.nt_gather) load_vec_nt<VEC>(src, b[u]);
+          else load_vec<VEC>(src, b[u]);
         }
         if (MASK) {
           mb[u] = 0;
-          if (ok[u]) mb[u] = *reinterpret_cast<const uint32_t*>(m.bytes + c * K);
+          mb2[u] = 0;
+          if (ok[u]) {
+            const uint8_t* bsrc = is_hot ? m.hot_bytes + (c - m.hot_first) * K * m.arg_width : m.bytes + c * K * m.arg_width;
+            if (m.arg_width == 2) {
+              const uint2 w2 = *reinterpret_cast<const uint2*>(bsrc);
+              mb[u] = w2.x;
+              mb2[u] = w2.y;
+            } else {
+              mb[u] = *reinterpret_cast<const uint32_t*>(bsrc);
+            }
+          }
         }
       }
       if (MASK) {
@@ -191,10 +230,20 @@ __device__ __forceinline__ void reduce_edge_range(
           // edge id / row are re-read from their lanes here rather than kept in
           // registers across the gathers (88 -> fewer VGPRs, one more wave per SIMD)
           const int idx = j + u * G + g;
-          const uint32_t tag = static_cast<uint32_t>(static_cast<uint64_t>(shfl_i64(id_l, idx)) >> 56);
+          const uint64_t idw = static_cast<uint64_t>(shfl_i64(id_l, idx));
           hits[u] = 0;
+          uint32_t tag;
+          if (m.arg_width == 2) {  // exact: equal entries are the hits
+            tag = static_cast<uint32_t>(idw >> 48);
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) hits[u] |= static_cast<uint32_t>(((mb[u] >> (8 * i)) & 255u) == tag) << i;
+            for (int i = 0; i < VEC; ++i)
+              hits[u] |= static_cast<uint32_t>((((i < 2 ? mb[u] : mb2[u]) >> (16 * (i & 1))) & 0xffffu) == tag) << i;
+            tag = 0;  // no candidates to verify
+          } else {
+            tag = static_cast<uint32_t>(idw >> 56);
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) hits[u] |= static_cast<uint32_t>(((mb[u] >> (8 * i)) & 255u) == tag) << i;
+          }
           need[u] = ((tag & 0x80u) && ok[u]) ? hits[u] : 0u;
           any_need |= need[u] != 0;
         }
@@ -647,9 +696,11 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
   float acc[VEC];
   int64_t arg[VEC];
   if (MODE == M_MASK) {
-    mask.bytes += k0;
+    mask.bytes += k0 * mask.arg_width;
     mask.arg += k0;
+    if (mask.hot_bytes) mask.hot_bytes += k0 * mask.arg_width;
   }
+  if ((MODE == M_MASK || MODE == M_CSC) && mask.hot) mask.hot += k0;
   const unsigned kFusedChunkBlocks = static_cast<unsigned>(mask.chunk_blocks);
   if (blockIdx.x < kFusedChunkBlocks) {  // ---- chunk role ----
     const unsigned long long ctr = *long_ctr;
@@ -683,6 +734,7 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
     const int64_t per = (static_cast<int64_t>(gridDim.x) - kFusedChunkBlocks) / 8;
     rb = (rb % 8) * per + rb / 8;
   }
+  if (mask.mix_xcds) rb ^= static_cast<int64_t>((static_cast<uint32_t>(rb >> 3) * 0x9E3779B1u) >> 29);  // grid: whole groups of 8
   const int64_t row = rb * kWaves + wave;
   if (row >= M) return;
   const int64_t s = rowptr[row];
@@ -711,14 +763,13 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
       } else {
         store_arg_nt<VEC>(arg_out + row * K + k0, arg);
       }
-      if (MODE != M_NOARG && VEC == 4 && mask.arg_bytes_out) {  // the backward's 1-byte form, for free while arg is in registers
-        uint32_t packed = 0;
+      if constexpr (MODE != M_NOARG && VEC == 4) {
+        if (mask.arg_bytes_out) {  // the backward's row-local form, for free while arg is in registers
+          uint32_t f[4];
 #pragma unroll
-        for (int i = 0; i < VEC; ++i) {
-          const uint32_t b = static_cast<uint32_t>((arg[i] - s) & 127) | (deg > kByteExact ? 0x80u : 0u);
-          packed |= b << (8 * i);
+          for (int i = 0; i < 4; ++i) f[i] = arg_local(arg[i] - s, deg, mask.arg_width);
+          store_arg_local4(mask.arg_bytes_out, row * K + k0, f, mask.arg_width);
         }
-        __builtin_nontemporal_store(packed, reinterpret_cast<uint32_t*>(mask.arg_bytes_out + row * K + k0));
       }
     }
     if (mask.temporal_out) store_vec<VEC>(out.p + row * out.ld + k0, acc);
@@ -735,7 +786,7 @@ spmm_long_combine_kernel(const int64_t* __restrict__ rowptr, int64_t K, int mean
                          const float* __restrict__ part_val,
                          const int64_t* __restrict__ part_arg,
                          OutView out, int64_t* __restrict__ arg_out,
-                         uint8_t* __restrict__ arg_bytes) {
+                         uint8_t* __restrict__ arg_bytes, int arg_width) {
   const int lane = threadIdx.x & 63;
   const int nrows = static_cast<int>(*long_ctr >> 32);
   const int num_waves = gridDim.x * (blockDim.x >> 6);
@@ -788,9 +839,7 @@ spmm_long_combine_kernel(const int64_t* __restrict__ rowptr, int64_t K, int mean
           if (mean) acc[t] = acc[t] / static_cast<float>(deg);
         } else {
           if (arg_out) __builtin_nontemporal_store(arg[t], arg_out + ent.row * K + k);
-          if (arg_bytes)
-            arg_bytes[ent.row * K + k] =
-                static_cast<uint8_t>(((arg[t] - rowptr[ent.row]) & 127) | (deg > kByteExact ? 0x80 : 0));
+          if (arg_bytes) store_arg_local1(arg_bytes, ent.row * K + k, arg_local(arg[t] - rowptr[ent.row], deg, arg_width), arg_width);
         }
         __builtin_nontemporal_store(acc[t], out.p + ent.row * out.ld + k);
       }
@@ -814,7 +863,7 @@ spmm_multirow_kernel(const int64_t* __restrict__ rowptr,
                      OutView out, int64_t* __restrict__ arg_out,
                      int64_t M, int64_t K, int64_t nnz, int mean,
                      unsigned long long* __restrict__ long_ctr,
-                     LongEntry* __restrict__ long_list, uint8_t* __restrict__ arg_bytes) {
+                     LongEntry* __restrict__ long_list, uint8_t* __restrict__ arg_bytes, int arg_width) {
   constexpr int G = 64 / LPR;
   const int lane = threadIdx.x & 63;
   const int g = lane / LPR;
@@ -882,14 +931,13 @@ spmm_multirow_kernel(const int64_t* __restrict__ rowptr,
       for (int i = 0; i < VEC; ++i) acc[i] = 0.f;
     }
     if (arg_out) store_arg_nt<VEC>(arg_out + row * K + k0, arg);
-    if (VEC == 4 && arg_bytes) {  // row-local byte form for the one-pass backward (see MaskArgs)
-      uint32_t packed = 0;
+    if constexpr (VEC == 4) {
+      if (arg_bytes) {  // row-local form for the one-pass backward (see MaskArgs)
+        uint32_t f[4];
 #pragma unroll
-      for (int i = 0; i < VEC; ++i) {
-        const uint32_t b = static_cast<uint32_t>((arg[i] - s) & 127) | (deg > kByteExact ? 0x80u : 0u);
-        packed |= b << (8 * i);
+        for (int i = 0; i < 4; ++i) f[i] = arg_local(arg[i] - s, deg, arg_width);
+        store_arg_local4(arg_bytes, row * K + k0, f, arg_width);
       }
-      __builtin_nontemporal_store(packed, reinterpret_cast<uint32_t*>(arg_bytes + row * K + k0));
     }
   }
   store_vec_nt<VEC>(out.p + row * out.ld + k0, acc);
@@ -930,7 +978,7 @@ LongScratch carve(void* workspace, bool minmax, int64_t K, int64_t nnz) {
 template <int VEC, int LPR, int U>
 int launch_long(int red, const int64_t* rowptr, const int64_t* col, const float* val,
                 const float* mat, OutView out, int64_t* arg_out, int64_t K, int64_t nnz,
-                int mean, const LongScratch& w, hipStream_t s, uint8_t* arg_bytes = nullptr) {
+                int mean, const LongScratch& w, hipStream_t s, ArgLocal arg_bytes = {}) {
   const dim3 grid(kLongBlocks), block(psa::kLongThreads);
 #define PSA_LONG(R)                                                                        \
   do {                                                                                     \
@@ -938,7 +986,7 @@ int launch_long(int red, const int64_t* rowptr, const int64_t* col, const float*
                        col, val, mat, K, nnz, w.ctr, w.list, w.part_val, w.part_arg);      \
     hipLaunchKernelGGL((spmm_long_combine_kernel<R>), grid, block, 0, s, rowptr, K,         \
                        mean, w.ctr, w.list, w.part_val, w.part_arg, out, arg_out,          \
-                       arg_bytes);                                                         \
+                       arg_bytes.p, arg_bytes.width);                                      \
   } while (0)
   if (red == R_SUM) PSA_LONG(R_SUM);
   else if (red == R_MIN) PSA_LONG(R_MIN);
@@ -955,7 +1003,7 @@ template <int VEC, int LPR, int U>
 int launch_fused(int red, const int64_t* rowptr, const int64_t* col, const float* val,
                  const float* mat, OutView out, int64_t* arg_out, int64_t M, int64_t K,
                  int64_t nnz, int mean, const LongScratch& w, hipStream_t s,
-                 uint8_t* arg_bytes = nullptr, bool nt_gather = false, int k_tiles = 1) {
+                 ArgLocal arg_bytes = {}, bool nt_gather = false, int k_tiles = 1) {
   const int kFusedChunkBlocks = g_variant == 20 ? 512 : g_variant == 21 ? 1024 : g_variant == 22 ? 1536 : kFusedChunkBlocksDefault;
   const int64_t gx = psa::ceil_div(psa::ceil_div(M, kWaves), 8) * 8 + kFusedChunkBlocks;
   PSA_REQUIRE(gx <= 0x7fffffff, "M too large for one launch");
@@ -969,11 +1017,12 @@ int launch_fused(int red, const int64_t* rowptr, const int64_t* col, const float
   plain.temporal_out = g_variant == 17;
   plain.nt_gather = nt_gather;
   plain.chunk_blocks = kFusedChunkBlocks;
-  plain.arg_bytes_out = arg_bytes;
+  plain.arg_bytes_out = arg_bytes.p;
+  plain.arg_width = arg_bytes.width;
   // min/max with neither arg_out nor arg_bytes wanted: the instantiation that does
   // not track the winners' edge ids (the combine still folds chunk partials by
   // value; ids it reads there only break ties between equal values)
-  const bool no_arg = red != R_SUM && arg_out == nullptr && arg_bytes == nullptr && g_variant != 19;
+  const bool no_arg = red != R_SUM && arg_out == nullptr && arg_bytes.p == nullptr && g_variant != 19;
   auto launch = [&](auto red_tag) {
     constexpr int R = decltype(red_tag)::value;
     bool done = false;
@@ -988,7 +1037,7 @@ int launch_fused(int red, const int64_t* rowptr, const int64_t* col, const float
       hipLaunchKernelGGL((spmm_fused_kernel<VEC, LPR, R, U>), grid, block, 0, s, rowptr, col, val, mat, out, arg_out, M,
                          K, nnz, mean, w.ctr, w.list, w.part_val, w.part_arg, plain);
     hipLaunchKernelGGL((spmm_long_combine_kernel<R>), cgrid, cblock, 0, s, rowptr, K, mean, w.ctr, w.list, w.part_val,
-                       w.part_arg, out, arg_out, plain.arg_bytes_out);
+                       w.part_arg, out, arg_out, plain.arg_bytes_out, plain.arg_width);
   };
   if (red == R_SUM) launch(std::integral_constant<int, R_SUM>{});
   else if (red == R_MIN) launch(std::integral_constant<int, R_MIN>{});
@@ -1001,11 +1050,13 @@ int launch_fused(int red, const int64_t* rowptr, const int64_t* col, const float
 template <int LPR, int U, int MODE>
 int launch_fused_masked(const int64_t* colptr, const int64_t* row_csc, const float* value,
                         const float* grad, OutView out, int64_t N, int64_t K, int64_t nnz,
-                        const MaskArgs& mask, const LongScratch& w, hipStream_t s) {
+                        const MaskArgs& mask_in, const LongScratch& w, hipStream_t s) {
   const int kFusedChunkBlocks = kFusedChunkBlocksDefault;
-  const int64_t gx = psa::ceil_div(N, kWaves) + kFusedChunkBlocks;
+  const int64_t gx = psa::ceil_div(psa::ceil_div(N, kWaves), 8) * 8 + kFusedChunkBlocks;  // whole groups of 8 row blocks
   PSA_REQUIRE(gx <= 0x7fffffff, "N too large for one launch");
   const dim3 block(kThreads), grid(static_cast<unsigned>(gx));
+  MaskArgs mask = mask_in;
+  mask.mix_xcds = g_variant != 27;
   hipLaunchKernelGGL(find_long_rows_kernel, dim3(static_cast<unsigned>(psa::ceil_div(N, kThreads * kFindIters))),
                      block, 0, s, colptr, N, w.ctr, w.list);
   hipLaunchKernelGGL((spmm_fused_kernel<4, LPR, R_SUM, U, MODE>), grid, block, 0, s, colptr, row_csc,
@@ -1013,7 +1064,7 @@ int launch_fused_masked(const int64_t* colptr, const int64_t* row_csc, const flo
                      w.part_val, w.part_arg, mask);
   hipLaunchKernelGGL((spmm_long_combine_kernel<R_SUM>), dim3(kLongBlocks), dim3(psa::kLongThreads), 0, s,
                      colptr, K, 0, w.ctr, w.list, w.part_val, w.part_arg, out,
-                     static_cast<int64_t*>(nullptr), static_cast<uint8_t*>(nullptr));
+                     static_cast<int64_t*>(nullptr), static_cast<uint8_t*>(nullptr), 1);
   PSA_LAUNCH_CHECK();
   return PSA_OK;
 }
@@ -1023,55 +1074,52 @@ int launch_fused_masked(const int64_t* colptr, const int64_t* row_csc, const flo
 // elements per thread: 32 B in, 4 B out.
 __global__ void __launch_bounds__(kThreads)
 minmax_compress_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ arg_out,
-                       int64_t M, int64_t K, uint8_t* __restrict__ bytes) {
+                       int64_t M, int64_t K, uint8_t* __restrict__ bytes, int width) {
   const int64_t q = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;  // group of 4
   const int64_t kq = K / 4;
   if (q >= M * kq) return;
   const int64_t r = q / kq;
   const int64_t start = rowptr[r];
-  const bool big = rowptr[r + 1] - start > kByteExact;
+  const int64_t deg = rowptr[r + 1] - start;
   const longlong2 a01 = *reinterpret_cast<const longlong2*>(arg_out + 4 * q);
   const longlong2 a23 = *reinterpret_cast<const longlong2*>(arg_out + 4 * q + 2);
   const int64_t a[4] = {a01.x, a01.y, a23.x, a23.y};
-  uint32_t packed = 0;
+  uint32_t f[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const uint32_t b = static_cast<uint32_t>((a[i] - start) & 127) | (big ? 0x80u : 0u);
-    packed |= b << (8 * i);
-  }
-  *reinterpret_cast<uint32_t*>(bytes + 4 * q) = packed;
+  for (int i = 0; i < 4; ++i) f[i] = arg_local(a[i] - start, deg, width);
+  store_arg_local4(bytes, 4 * q, f, width);
 }
 
 // tag[j] = index of CSC edge j inside its CSR row, mod 128, bit 7 set for rows of more than 128 edges.
 __global__ void __launch_bounds__(kThreads)
 csc_edge_tags_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ row_csc,
                      const int64_t* __restrict__ csr2csc, int64_t nnz,
-                     uint8_t* __restrict__ tag) {
+                     uint8_t* __restrict__ tag, int width) {
   const int64_t j = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
   if (j >= nnz) return;
   const int64_t r = row_csc[j];
   const int64_t start = rowptr[r];
-  tag[j] = static_cast<uint8_t>(((csr2csc[j] - start) & 127) | (rowptr[r + 1] - start > kByteExact ? 0x80 : 0));
+  store_arg_local1(tag, j, arg_local(csr2csc[j] - start, rowptr[r + 1] - start, width), width);
 }
 
 template <int VEC, int LPR, int U>
 int launch_multirow(int red, const int64_t* rowptr, const int64_t* col,
                     const float* val, const float* mat, OutView out,
                     int64_t* arg_out, int64_t M, int64_t K, int64_t nnz, int mean,
-                    const LongScratch& w, hipStream_t s, uint8_t* arg_bytes = nullptr) {
+                    const LongScratch& w, hipStream_t s, ArgLocal arg_bytes = {}) {
   const int64_t gx = psa::ceil_div(M, static_cast<int64_t>(kWaves) * (64 / LPR));
   PSA_REQUIRE(gx <= 0x7fffffff, "M too large for one launch");
   const dim3 grid(static_cast<unsigned>(gx)), block(kThreads);
   if (red == R_SUM) {
     hipLaunchKernelGGL((spmm_multirow_kernel<VEC, LPR, R_SUM, U>), grid, block, 0, s,
                        rowptr, col, val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list,
-                       static_cast<uint8_t*>(nullptr));
+                       static_cast<uint8_t*>(nullptr), 1);
   } else if (red == R_MIN) {
     hipLaunchKernelGGL((spmm_multirow_kernel<VEC, LPR, R_MIN, U>), grid, block, 0, s,
-                       rowptr, col, val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list, arg_bytes);
+                       rowptr, col, val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list, arg_bytes.p, arg_bytes.width);
   } else {
     hipLaunchKernelGGL((spmm_multirow_kernel<VEC, LPR, R_MAX, U>), grid, block, 0, s,
-                       rowptr, col, val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list, arg_bytes);
+                       rowptr, col, val, mat, out, arg_out, M, K, nnz, mean, w.ctr, w.list, arg_bytes.p, arg_bytes.width);
   }
   PSA_LAUNCH_CHECK();
   // chunk waves split a row's edges over the 64/LPR lane groups: 8 edges per step
@@ -1144,27 +1192,29 @@ int psa_spmm_set_variant(int variant) {
 }
 
 int psa_csc_edge_tags(const int64_t* rowptr, const int64_t* row_csc, const int64_t* csr2csc,
-                      int64_t nnz, uint8_t* tag, psa_stream_t stream) {
+                      int64_t nnz, void* tag, int width, psa_stream_t stream) {
   PSA_REQUIRE(nnz >= 0, "negative size");
+  PSA_REQUIRE(width == 1 || width == 2, "width must be 1 or 2");
   if (nnz == 0) return PSA_OK;
   PSA_REQUIRE(rowptr && row_csc && csr2csc && tag, "NULL pointer");
   const int64_t blocks = psa::ceil_div(nnz, kThreads);
   PSA_REQUIRE(blocks <= 0x7fffffff, "nnz too large for one launch");
   hipLaunchKernelGGL(csc_edge_tags_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0,
-                     psa::as_stream(stream), rowptr, row_csc, csr2csc, nnz, tag);
+                     psa::as_stream(stream), rowptr, row_csc, csr2csc, nnz, static_cast<uint8_t*>(tag), width);
   PSA_LAUNCH_CHECK();
   return PSA_OK;
 }
 
 size_t psa_spmm_minmax_bw_csc_workspace_bytes(int64_t M, int64_t K, int64_t nnz) {
   if (M <= 0 || K <= 0) return 256;
-  return align256(static_cast<size_t>(M) * K) + long_workspace_bytes(false, K, nnz > 0 ? nnz : 1);
+  return align256(2 * static_cast<size_t>(M) * K) + long_workspace_bytes(false, K, nnz > 0 ? nnz : 1);
 }
 
 int psa_spmm_minmax_bw_csc(const int64_t* rowptr, const int64_t* colptr,
                            const int64_t* row_csc, const int64_t* csr2csc,
-                           const uint8_t* tag, const float* value, const float* mat,
-                           const float* grad, const int64_t* arg_out, const uint8_t* arg_bytes,
+                           const void* tag, const float* value, const float* mat,
+                           const float* grad, const int64_t* arg_out, const void* arg_bytes, int arg_width,
+                           const float* hot_grad, const void* hot_bytes, int64_t num_hot,
                            int64_t M, int64_t N, int64_t K, int64_t nnz, float* grad_value,
                            float* grad_mat, void* workspace, size_t workspace_bytes,
                            psa_stream_t stream) {
@@ -1179,6 +1229,12 @@ int psa_spmm_minmax_bw_csc(const int64_t* rowptr, const int64_t* colptr,
   PSA_REQUIRE(colptr && grad_mat, "NULL pointer");
   PSA_REQUIRE(nnz == 0 || (rowptr && row_csc && csr2csc && tag && grad), "NULL pointer");
   PSA_REQUIRE(nnz == 0 || arg_out != nullptr || arg_bytes != nullptr, "arg_out and arg_bytes are both NULL");
+  PSA_REQUIRE(arg_width == 1 || arg_width == 2, "arg_width must be 1 or 2");
+  PSA_REQUIRE(arg_bytes == nullptr || psa::aligned(arg_bytes, 4 * arg_width), "arg_bytes alignment");
+  PSA_REQUIRE(num_hot >= 0 && (num_hot == 0 || (hot_grad != nullptr && hot_bytes != nullptr)), "hot rows are NULL");
+  PSA_REQUIRE(num_hot == 0 || (arg_bytes != nullptr && arg_out == nullptr && psa::aligned(hot_grad, 16) &&
+                               psa::aligned(hot_bytes, 4 * arg_width)),
+              "hot rows go with an exact arg_bytes (no arg_out) and 16-byte aligned copies");
   PSA_REQUIRE(grad_value == nullptr || mat != nullptr || nnz == 0, "grad_value needs mat");
   PSA_REQUIRE(max_long_chunks(nnz) < (1ll << 32), "too many chunks");
   if (workspace == nullptr || workspace_bytes < psa_spmm_minmax_bw_csc_workspace_bytes(M, K, nnz)) {
@@ -1188,18 +1244,24 @@ int psa_spmm_minmax_bw_csc(const int64_t* rowptr, const int64_t* colptr,
   PSA_REQUIRE(psa::aligned(workspace, 16), "workspace must be 16-byte aligned");
   hipStream_t s = psa::as_stream(stream);
   uint8_t* bytes = static_cast<uint8_t*>(workspace);
-  const LongScratch w = carve(bytes + align256(static_cast<size_t>(M) * K), false, K, nnz > 0 ? nnz : 1);
+  const LongScratch w = carve(bytes + align256(2 * static_cast<size_t>(M) * K), false, K, nnz > 0 ? nnz : 1);
   PSA_ZERO(w.ctr, 8, s);
-  if (arg_bytes == nullptr && M > 0 && nnz > 0) {  // the forward did not leave the byte form behind
+  if (arg_bytes == nullptr && M > 0 && nnz > 0) {  // the forward did not leave the row-local form behind
     const int64_t blocks = psa::ceil_div(M * (K / 4), kThreads);
     PSA_REQUIRE(blocks <= 0x7fffffff, "M*K too large for one launch");
     hipLaunchKernelGGL(minmax_compress_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0,
-                       s, rowptr, arg_out, M, K, bytes);
+                       s, rowptr, arg_out, M, K, bytes, arg_width);
   }
   MaskArgs mask;
   mask.temporal_out = g_variant == 17;
-  mask.bytes = arg_bytes != nullptr ? arg_bytes : bytes;
-  mask.tag = tag;
+  mask.bytes = arg_bytes != nullptr ? static_cast<const uint8_t*>(arg_bytes) : bytes;
+  mask.arg_width = arg_width;
+  mask.tag = static_cast<const uint8_t*>(tag);
+  if (num_hot > 0) {
+    mask.hot = hot_grad;
+    mask.hot_bytes = static_cast<const uint8_t*>(hot_bytes);
+    mask.hot_first = M;
+  }
   mask.edge_id = csr2csc;
   mask.arg = arg_out;
   if (grad_value != nullptr && nnz > 0) {
@@ -1220,10 +1282,12 @@ size_t psa_spmm_sum_bw_csc_workspace_bytes(int64_t K, int64_t nnz) {
 
 int psa_spmm_sum_bw_csc(const int64_t* colptr, const int64_t* row_csc, const int64_t* csr2csc,
                         const float* value, const float* row_scale, const float* mat,
-                        const float* grad, int64_t N, int64_t K, int64_t nnz,
+                        const float* grad, const float* hot_grad, int64_t num_hot, int64_t M,
+                        int64_t N, int64_t K, int64_t nnz,
                         float* grad_value, float* grad_mat, void* workspace,
                         size_t workspace_bytes, psa_stream_t stream) {
-  PSA_REQUIRE(N >= 0 && K >= 0 && nnz >= 0, "negative size");
+  PSA_REQUIRE(M >= 0 && N >= 0 && K >= 0 && nnz >= 0, "negative size");
+  PSA_REQUIRE(num_hot >= 0 && (num_hot == 0 || (hot_grad != nullptr && psa::aligned(hot_grad, 16))), "hot_grad");
   if (N == 0 || K == 0) return PSA_OK;
   if (K % 4 != 0 || K > 256 || !psa::aligned(grad, 16) || !psa::aligned(grad_mat, 16) ||
       !psa::aligned(mat, 16)) {
@@ -1247,6 +1311,10 @@ int psa_spmm_sum_bw_csc(const int64_t* colptr, const int64_t* row_csc, const int
   mask.temporal_out = g_variant == 17;
   mask.edge_id = csr2csc;
   mask.row_scale = row_scale;
+  if (num_hot > 0) {
+    mask.hot = hot_grad;
+    mask.hot_first = M;
+  }
   if (grad_value != nullptr && nnz > 0) {
     mask.mat = mat;
     mask.grad_value = grad_value;
@@ -1277,7 +1345,7 @@ int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* row, const i
                   const float* value, const float* mat, int64_t M, int64_t N,
                   int64_t K, int64_t nnz, OutView out, int64_t* arg_out,
                   void* workspace, size_t workspace_bytes, hipStream_t s,
-                  uint8_t* arg_bytes, bool* bytes_done, int algo, const float* hot_rows = nullptr,
+                  ArgLocal arg_bytes, bool* bytes_done, int algo, const float* hot_rows = nullptr,
                   int64_t num_hot = 0) {
   PSA_REQUIRE(reduce >= PSA_SUM && reduce <= PSA_MAX, "bad reduce");
   PSA_REQUIRE(num_hot >= 0 && (num_hot == 0 || hot_rows != nullptr), "hot_rows is NULL");
@@ -1298,11 +1366,12 @@ int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* row, const i
   const bool eb_forced = (g_variant >= 30 && g_variant <= 36) || (algo == PSA_SPMM_EDGE_RANGES && g_variant == 0);
   if (eb_forced && workspace != nullptr && N < (1ll << 31) && nnz > 0 && K % 4 == 0 && psa::aligned(mat, 16) &&
       psa::aligned(out.p, 16) && out.ld % 4 == 0 && psa::eb_supported(M, K, nnz)) {
-    *bytes_done = arg_bytes != nullptr && minmax;
+    *bytes_done = arg_bytes.p != nullptr && minmax;
     const bool nt_gather = N * K * 4 >= kNtGatherBytes;
     const int range_len = g_variant == 31 ? 128 : g_variant == 32 ? 512 : g_variant == 33 ? 1024 : 0;
     return psa::launch_spmm_eb(red, mean, rowptr, row, col, value, mat, out.p, out.ld, arg_out,
-                               minmax ? arg_bytes : nullptr, M, N, K, nnz, hot_rows, num_hot, workspace, workspace_bytes,
+                               minmax ? arg_bytes.p : nullptr, arg_bytes.width, M, N, K, nnz, hot_rows, num_hot, workspace,
+                               workspace_bytes,
                                nt_gather, range_len, g_variant == 34 ? 1 : g_variant == 35 ? 2 : g_variant == 36 ? 4 : 0, s);
   }
 
@@ -1337,10 +1406,10 @@ int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* row, const i
     if (g_variant == 4 && K % 128 == 0) PSA_ROW(2, 64, 16);
 #define PSA_MULTI(VEC, LPR, U)                                                     \
   do {                                                                             \
-    *bytes_done = arg_bytes != nullptr && minmax;                                  \
+    *bytes_done = arg_bytes.p != nullptr && minmax;                                  \
     return launch_multirow<VEC, LPR, U>(red, rowptr, col, value, mat, out, arg_out, \
                                         M, K, nnz, mean, w, s,                     \
-                                        minmax ? arg_bytes : nullptr);             \
+                                        minmax ? arg_bytes : ArgLocal{});           \
   } while (0)
     // K <= 64: several rows per wave (multirow, 8 gathers in flight per row)
     // measured at 2M rows / 20M edges: K=16 0.58 -> 0.41 ms, K=32 0.69 -> 0.45,
@@ -1366,7 +1435,7 @@ int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* row, const i
     // variant 15 forces the separate launches
     if ((g_variant == 0 || g_variant == 14 || g_variant == 16 || g_variant == 17 || g_variant == 18 || g_variant == 19 || (g_variant >= 20 && g_variant <= 22) || g_variant == 25 || g_variant == 26) && w.list && q > 16 &&
         (q <= 64 || g_variant != 25)) {
-      *bytes_done = arg_bytes != nullptr && minmax;
+      *bytes_done = arg_bytes.p != nullptr && minmax;
       // A dense operand far beyond the 256 MiB Infinity Cache is gathered with
       // non-temporal loads: nothing of it will be hit again, and not allocating
       // the lines is worth 4-5 % at 8-16 GiB (tools/nt_gather_sweep.py: break-even
@@ -1382,10 +1451,10 @@ int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* row, const i
       const bool tiled = (K >= 192 && g_variant != 25) || (K > 128 && g_variant == 26);
       if (q <= 32 || tiled)
         return launch_fused<4, 32, 4>(red, rowptr, col, value, mat, out, arg_out, M, K, nnz, mean, w, s,
-                                      minmax ? arg_bytes : nullptr, nt_gather,
+                                      minmax ? arg_bytes : ArgLocal{}, nt_gather,
                                       static_cast<int>(psa::ceil_div(K, 128)));
       return launch_fused<4, 64, 8>(red, rowptr, col, value, mat, out, arg_out, M, K, nnz, mean, w, s,
-                                    minmax ? arg_bytes : nullptr, nt_gather);
+                                    minmax ? arg_bytes : ArgLocal{}, nt_gather);
     }
     if (g_variant == 11) { if (q <= 32) PSA_ROWS(4, 32, 4, 4); PSA_ROWS(4, 64, 8, 4); }
     if (g_variant == 12) { if (q <= 32) PSA_ROWS(4, 32, 4, 8); PSA_ROWS(4, 64, 8, 8); }
@@ -1411,16 +1480,18 @@ int psa_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
              int64_t K, int64_t nnz, float* out, int64_t* arg_out,
              uint8_t* arg_bytes, void* workspace, size_t workspace_bytes,
              psa_stream_t stream) {
-  return psa_spmm_coo(reduce, rowptr, nullptr, col, value, mat, nullptr, 0, M, N, K, nnz, out, 0, arg_out, arg_bytes,
+  return psa_spmm_coo(reduce, rowptr, nullptr, col, value, mat, nullptr, 0, M, N, K, nnz, out, 0, arg_out, arg_bytes, 1,
                       PSA_SPMM_AUTO, workspace, workspace_bytes, stream);
 }
 
 int psa_spmm_coo(int reduce, const int64_t* rowptr, const int64_t* row, const int64_t* col,
                  const float* value, const float* mat, const float* hot_rows, int64_t num_hot, int64_t M, int64_t N,
                  int64_t K, int64_t nnz, float* out, int64_t ldo, int64_t* arg_out,
-                 uint8_t* arg_bytes, int algo, void* workspace, size_t workspace_bytes,
+                 void* arg_bytes_v, int arg_width, int algo, void* workspace, size_t workspace_bytes,
                  psa_stream_t stream) {
   const bool minmax = reduce == PSA_MIN || reduce == PSA_MAX;
+  uint8_t* arg_bytes = static_cast<uint8_t*>(arg_bytes_v);
+  PSA_REQUIRE(arg_bytes == nullptr || arg_width == 1 || arg_width == 2, "arg_width must be 1 or 2");
   if (arg_bytes != nullptr && minmax && K % 4 != 0) {
     psa::set_error("psa_spmm: arg_bytes needs K % 4 == 0");
     return PSA_ERR_UNSUPPORTED;
@@ -1428,15 +1499,15 @@ int psa_spmm_coo(int reduce, const int64_t* rowptr, const int64_t* row, const in
   hipStream_t s = psa::as_stream(stream);
   bool bytes_done = false;
   const int st = spmm_dispatch(reduce, rowptr, row, col, value, mat, M, N, K, nnz, OutView{out, ldo > 0 ? ldo : K}, arg_out, workspace,
-                               workspace_bytes, s, arg_bytes, &bytes_done, algo, hot_rows, num_hot);
+                               workspace_bytes, s, ArgLocal{arg_bytes, arg_width}, &bytes_done, algo, hot_rows, num_hot);
   if (st != PSA_OK || arg_bytes == nullptr || !minmax || bytes_done || M == 0 || K == 0) return st;
   // the kernel that ran keeps arg_out only: one more pass turns it into bytes
   PSA_REQUIRE(arg_out != nullptr, "arg_bytes without arg_out needs a K tile whose kernel writes the bytes itself (K % 4 == 0, K <= 256)");
-  PSA_REQUIRE(psa::aligned(arg_out, 16) && psa::aligned(arg_bytes, 4), "arg_out / arg_bytes alignment");
+  PSA_REQUIRE(psa::aligned(arg_out, 16) && psa::aligned(arg_bytes, 4 * arg_width), "arg_out / arg_bytes alignment");
   const int64_t blocks = psa::ceil_div(M * (K / 4), kThreads);
   PSA_REQUIRE(blocks <= 0x7fffffff, "M*K too large for one launch");
   hipLaunchKernelGGL(minmax_compress_kernel, dim3(static_cast<unsigned>(blocks)), dim3(kThreads), 0, s,
-                     rowptr, arg_out, M, K, arg_bytes);
+                     rowptr, arg_out, M, K, arg_bytes, arg_width);
   PSA_LAUNCH_CHECK();
   return PSA_OK;
 }

@@ -19,7 +19,7 @@ size_t eb_workspace_bytes(bool minmax, int64_t K, int64_t nnz);
 // then derived from rowptr into the workspace (one ptr2ind launch).
 int launch_spmm_eb(int red, int mean, const int64_t* rowptr, const int64_t* row,
                    const int64_t* col, const float* val, const float* mat, float* out, int64_t ldo,
-                   int64_t* arg_out, uint8_t* arg_bytes, int64_t M, int64_t N, int64_t K,
+                   int64_t* arg_out, uint8_t* arg_bytes, int arg_width, int64_t M, int64_t N, int64_t K,
                    int64_t nnz, const float* hot_rows, int64_t num_hot, void* workspace, size_t workspace_bytes,
                    bool nt_gather, int range_len_override, int dbg, hipStream_t s);
 

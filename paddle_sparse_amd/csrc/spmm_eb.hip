@@ -44,7 +44,9 @@ using psa::store_arg_nt;
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
 constexpr int kFillRows = 1024;  // rows per workgroup of the fill role
-constexpr int kByteExact = 128;  // rows up to this many edges: the one-byte form of arg_out is exact
+using psa::arg_local;
+using psa::store_arg_local1;
+using psa::store_arg_local4;
 
 enum { R_SUM = 0, R_MIN = 1, R_MAX = 2 };
 
@@ -59,6 +61,7 @@ struct EbArgs {
   float* out;
   int64_t* arg_out;
   uint8_t* arg_bytes;
+  int arg_width;  // bytes per entry of arg_bytes: 1 or 2 (vec_io.h)
   float* part_val;    // [2 * ranges, K]: slot 2r = head partial of range r, 2r + 1 = tail partial
   int64_t* part_arg;  // same shape, winners' edge ids (min/max with tracking)
   int64_t M, K, nnz, num_ranges;
@@ -105,7 +108,10 @@ __device__ __forceinline__ void eb_fill_role(const EbArgs& a) {
           store_vec_nt<4>(a.out + rr * a.ldo + 4 * q, zero);
           if (a.minmax) {
             if (a.arg_out) store_arg_nt<4>(a.arg_out + rr * a.K + 4 * q, sentinel);
-            if (a.arg_bytes) __builtin_nontemporal_store(0u, reinterpret_cast<uint32_t*>(a.arg_bytes + rr * a.K + 4 * q));
+            if (a.arg_bytes) {
+              const uint32_t none[4] = {0u, 0u, 0u, 0u};
+              store_arg_local4(a.arg_bytes, rr * a.K + 4 * q, none, a.arg_width);
+            }
           }
         }
       }
@@ -137,13 +143,10 @@ __device__ __forceinline__ void eb_store_row(const EbArgs& a, int64_t row, int64
       store_arg_nt<4>(a.arg_out + row * a.K + k0, g);
     }
     if (a.arg_bytes) {
-      uint32_t packed = 0;
+      uint32_t f[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint32_t b = static_cast<uint32_t>((arg[i] - seg_first) & 127) | (cnt > kByteExact ? 0x80u : 0u);
-        packed |= b << (8 * i);
-      }
-      __builtin_nontemporal_store(packed, reinterpret_cast<uint32_t*>(a.arg_bytes + row * a.K + k0));
+      for (int i = 0; i < 4; ++i) f[i] = arg_local(arg[i] - seg_first, cnt, a.arg_width);
+      store_arg_local4(a.arg_bytes, row * a.K + k0, f, a.arg_width);
     }
   }
   if (a.dbg & 1) {
@@ -443,8 +446,7 @@ __global__ void __launch_bounds__(kThreads) spmm_eb_combine_kernel(EbArgs a) {
           if (a.mean) acc[t] = acc[t] / static_cast<float>(deg);
         } else if (TRACK) {
           if (a.arg_out) __builtin_nontemporal_store(arg[t], a.arg_out + r_last * a.K + k);
-          if (a.arg_bytes)
-            a.arg_bytes[r_last * a.K + k] = static_cast<uint8_t>(((arg[t] - rs) & 127) | (deg > kByteExact ? 0x80 : 0));
+          if (a.arg_bytes) store_arg_local1(a.arg_bytes, r_last * a.K + k, arg_local(arg[t] - rs, deg, a.arg_width), a.arg_width);
         }
         __builtin_nontemporal_store(acc[t], a.out + r_last * a.ldo + k);
       }
@@ -539,7 +541,7 @@ size_t eb_workspace_bytes(bool minmax, int64_t K, int64_t nnz) {
 
 int launch_spmm_eb(int red, int mean, const int64_t* rowptr, const int64_t* row,
                    const int64_t* col, const float* val, const float* mat, float* out, int64_t ldo,
-                   int64_t* arg_out, uint8_t* arg_bytes, int64_t M, int64_t N, int64_t K,
+                   int64_t* arg_out, uint8_t* arg_bytes, int arg_width, int64_t M, int64_t N, int64_t K,
                    int64_t nnz, const float* hot_rows, int64_t num_hot, void* workspace, size_t workspace_bytes,
                    bool nt_gather, int range_len_override, int dbg, hipStream_t s) {
   PSA_REQUIRE(num_hot >= 0 && N + num_hot < (1ll << 31), "column ids (with the hot copy) must fit 31 bits");
@@ -572,6 +574,7 @@ int launch_spmm_eb(int red, int mean, const int64_t* rowptr, const int64_t* row,
   a.ldo = ldo;
   a.arg_out = minmax ? arg_out : nullptr;
   a.arg_bytes = minmax ? arg_bytes : nullptr;
+  a.arg_width = arg_width;
   a.M = M;
   a.K = K;
   a.nnz = nnz;

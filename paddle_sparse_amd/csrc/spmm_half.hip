@@ -87,7 +87,12 @@ spmm_half_row_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restri
   static_assert(64 % (G * U) == 0, "edge batch must divide the wave");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t row = static_cast<int64_t>(blockIdx.x) * kWaves + wave;
+  // inside every group of 8 consecutive row blocks the blocks go to the XCDs (round-robin by
+  // blockIdx) in an order hashed from the group number: on graphs whose row lengths follow the
+  // bits of the row id, XCD 0 would otherwise own all the heavy rows (spmm.hip, MaskArgs.mix_xcds)
+  int64_t rb = blockIdx.x;
+  rb ^= static_cast<int64_t>((static_cast<uint32_t>(rb >> 3) * 0x9E3779B1u) >> 29);  // the grid holds whole groups of 8
+  const int64_t row = rb * kWaves + wave;
   if (row >= M) return;
   const int g = lane / LPR;
   const int l = lane % LPR;
@@ -328,7 +333,7 @@ template <typename T, int LPR, int U>
 int launch_half(int red, bool track, bool val32, const int64_t* rowptr, const int64_t* col, const void* val,
                 const uint16_t* mat, uint16_t* out, int64_t* arg_out, int64_t M, int64_t K, int64_t nnz, int mean,
                 hipStream_t s) {
-  const int64_t gx = psa::ceil_div(M, kWaves);
+  const int64_t gx = psa::ceil_div(psa::ceil_div(M, kWaves), 8) * 8;  // whole groups of 8 row blocks (XCD mixing)
   const int64_t gy = psa::ceil_div(K, static_cast<int64_t>(LPR) * 8);
   PSA_REQUIRE(gx <= 0x7fffffff && gy <= 65535, "problem too large for one launch");
   const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(gy)), block(kThreads);

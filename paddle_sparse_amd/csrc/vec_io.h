@@ -86,6 +86,35 @@ __device__ __forceinline__ void store_arg_nt(int64_t* p, const int64_t (&src)[VE
   }
 }
 
+// Row-local form of arg_out, the operand of the one-pass min/max backward (it compares the
+// entry of (row, k) with a per-edge tag of the same form instead of reading 8-byte edge ids):
+//   width 1  (index & 127) | 0x80 on rows of more than 128 edges, where equal bytes only name a
+//            candidate that is then tested against arg_out itself;
+//   width 2  index & 0xffff: exact for rows of up to 65 536 edges, arg_out not needed at all.
+constexpr int kByteExact = 128;      // rows up to this many edges: width 1 is exact
+constexpr int kWordExact = 65536;    // ... width 2 is exact
+
+__device__ __forceinline__ uint32_t arg_local(int64_t local_index, int64_t deg, int width) {
+  const uint32_t d = static_cast<uint32_t>(local_index);
+  return width == 2 ? (d & 0xffffu) : ((d & 127u) | (deg > kByteExact ? 0x80u : 0u));
+}
+
+// four consecutive entries (elem % 4 == 0) of the [M, K] array at `base`
+__device__ __forceinline__ void store_arg_local4(uint8_t* base, int64_t elem, const uint32_t (&f)[4], int width) {
+  if (width == 2) {
+    const unsigned long long v = static_cast<unsigned long long>(f[0] | (f[1] << 16)) |
+                                 (static_cast<unsigned long long>(f[2] | (f[3] << 16)) << 32);
+    __builtin_nontemporal_store(v, reinterpret_cast<unsigned long long*>(base + 2 * elem));
+  } else {
+    __builtin_nontemporal_store(f[0] | (f[1] << 8) | (f[2] << 16) | (f[3] << 24), reinterpret_cast<uint32_t*>(base + elem));
+  }
+}
+
+__device__ __forceinline__ void store_arg_local1(uint8_t* base, int64_t elem, uint32_t f, int width) {
+  if (width == 2) reinterpret_cast<uint16_t*>(base)[elem] = static_cast<uint16_t>(f);
+  else base[elem] = static_cast<uint8_t>(f);
+}
+
 __device__ __forceinline__ int64_t shfl_i64(int64_t x, int src) {
   return __shfl(static_cast<long long>(x), src);
 }

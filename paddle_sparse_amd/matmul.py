@@ -83,15 +83,19 @@ class _SpMM(torch.autograd.Function):
             # int64 arg_out is two thirds of the forward's output traffic (2 GB of
             # 3.3 at 2 M x 128): it is skipped when nothing will be differentiated,
             # and when the one-pass backward over the CSC view will run (grad of
-            # mat wanted, K tile supported) on a matrix whose rows all have at most
-            # 128 entries — the one-byte row-local form is then the whole answer.
+            # mat wanted, K tile supported) on a matrix whose row-local form of
+            # arg_out is exact: one byte per element for rows of up to 128 entries,
+            # two for rows of up to 65 536 (power-law graphs) — that form is then
+            # the whole answer.
             need_value = track and value is not None and ctx.needs_input_grad[0]
             need_mat = track and ctx.needs_input_grad[1]
             csc_bw = need_mat and ops.minmax_bw_csc_supported(mat.shape[1])
-            bytes_only = csc_bw and storage._longest_row() <= ops.ARG_BYTES_EXACT_ROW
+            longest = storage._longest_row() if csc_bw else 0
+            width = 2 if ops.ARG_BYTES_EXACT_ROW < longest <= ops.ARG_WORDS_EXACT_ROW else 1
+            bytes_only = csc_bw and longest <= ops.ARG_WORDS_EXACT_ROW
             want_arg = (need_value or need_mat) and not bytes_only
-            res = ops._spmm(reduce, rowptr, col, value, mat, want_arg_bytes=csc_bw, want_arg=want_arg,
-                            row=row, algo=algo, hot_rows=hot_rows)
+            res = ops._spmm(reduce, rowptr, col, value, mat, want_arg_bytes=width if csc_bw else False,
+                            want_arg=want_arg, row=row, algo=algo, hot_rows=hot_rows)
             out, arg, arg_bytes = res if csc_bw else (*res, None)
         else:
             out = ops._spmm(reduce, rowptr, col, value, mat, row=row, algo=algo, hot_rows=hot_rows)[0]
@@ -124,10 +128,15 @@ class _SpMM(torch.autograd.Function):
             # the storage keeps for the next step.
             if need_mat and ops.minmax_bw_csc_supported(grad_out.shape[1]):
                 csr2csc = st.csr2csc()  # first: it leaves colptr and row[csr2csc] behind
+                width = arg_bytes.element_size() if arg_bytes is not None else 1
+                # hub rows of a power-law matrix: the pass reads their rows of grad_out and of
+                # arg_bytes from compact copies (the CSC view's own hot "columns")
+                plan = st._csc_view()._hot_columns() if (arg is None and arg_bytes is not None) else None
                 grad_value, grad_mat = ops.spmm_minmax_bw_csc(
-                    st.rowptr(), st.colptr(), st._row_in_csc_order(), csr2csc, st._csc_edge_tags(),
-                    value, mat, grad_out, arg, want_value=need_value,
-                    csc2csr=st.csc2csr() if need_value else None, arg_bytes=arg_bytes)
+                    st.rowptr(), st.colptr(), st._row_in_csc_order() if plan is None else plan[1], csr2csc,
+                    st._csc_edge_tags(width), value, mat, grad_out, arg, want_value=need_value,
+                    csc2csr=st.csc2csr() if need_value else None, arg_bytes=arg_bytes,
+                    hot_ids=None if plan is None else plan[0])
             else:
                 grad_value, grad_mat = ops.spmm_minmax_bw(st.col(), value, mat, grad_out, arg,
                                                          want_value=need_value, want_mat=need_mat)
@@ -141,9 +150,10 @@ class _SpMM(torch.autograd.Function):
                 csr2csc = st.csr2csc()
                 # mean: 1/deg(row) multiplies both gradients, per edge, inside the pass
                 scale = (1.0 / st.rowcount().clamp(min=1).to(torch.float32)) if mean else None
-                grad_value, grad_mat = ops.spmm_sum_bw_csc(st.colptr(), st._row_in_csc_order(), csr2csc,
-                                                           value, mat, grad_out, True, csc2csr=st.csc2csr(),
-                                                           row_scale=scale)
+                plan = st._csc_view()._hot_columns()  # hub rows: grad_out rows from a compact copy
+                grad_value, grad_mat = ops.spmm_sum_bw_csc(st.colptr(), st._row_in_csc_order() if plan is None else plan[1],
+                                                           csr2csc, value, mat, grad_out, True, csc2csr=st.csc2csr(),
+                                                           row_scale=scale, hot_ids=None if plan is None else plan[0])
                 return grad_value, grad_mat
             if need_value:
                 grad_value = ops.spmm_value_bw(None, st.rowptr(), st.col(), mat, grad_out,

@@ -167,12 +167,13 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
     if minmax and want_arg:
         arg = torch.empty((M, K), dtype=torch.int64, device=mat.device)
     arg_bytes = None
+    arg_width = 2 if want_arg_bytes == 2 else 1  # True / 1: one byte per element; 2: two (exact up to 65 536-entry rows)
     if want_arg_bytes and minmax and K % 4 == 0 and (want_arg or K <= 256):
-        arg_bytes = torch.empty((M, K), dtype=torch.uint8, device=mat.device)
+        arg_bytes = torch.empty((M, K), dtype=torch.int16 if arg_width == 2 else torch.uint8, device=mat.device)
     with _on(mat.device):
         check(lib.psa_spmm_coo(rid, _ptr(rowptr), _ptr(row), _ptr(col), _ptr(value), _ptr(mat),
                                _ptr(hot_rows) if num_hot else None, num_hot, M, N, K, nnz, _ptr(out), ldo, _ptr(arg), _ptr(arg_bytes),
-                               _lib.SPMM_ALGO_ID[algo], _ptr(ws), ws_bytes, _stream()))
+                               arg_width, _lib.SPMM_ALGO_ID[algo], _ptr(ws), ws_bytes, _stream()))
     if want_arg_bytes:
         return out, arg, arg_bytes
     return out, arg
@@ -207,6 +208,8 @@ def _spmm_half(reduce: str, rowptr, col, value, mat, want_arg: bool = True):
 
 # rows up to this many entries: the one-byte form of arg_out (arg_bytes) needs no arg_out beside it
 ARG_BYTES_EXACT_ROW = 128
+# ... and the two-byte form (want_arg_bytes=2)
+ARG_WORDS_EXACT_ROW = 65_536
 
 
 def spmm_sum(rowptr, col, value, mat, row=None, algo="auto") -> torch.Tensor:
@@ -754,14 +757,17 @@ def spmm_minmax_bw(col, value, mat, grad, arg_out, want_value: bool = True, want
     return gv, gm
 
 
-def csc_edge_tags(rowptr, row_csc, csr2csc) -> torch.Tensor:
-    """uint8[nnz]: position of every CSC-ordered edge inside its CSR row (mod 128;
-    bit 7 marks rows of more than 128 edges).  Structure only — cache it next to csr2csc."""
+def csc_edge_tags(rowptr, row_csc, csr2csc, width: int = 1) -> torch.Tensor:
+    """Position of every CSC-ordered edge inside its CSR row, in the form of arg_bytes:
+    width 1 -> uint8[nnz] (mod 128; bit 7 marks rows of more than 128 edges), width 2 ->
+    int16[nnz] (mod 65 536).  Structure only — cache it next to csr2csc."""
+    if width not in (1, 2):
+        raise ValueError("width must be 1 or 2")
     rowptr, row_csc, csr2csc = _index(rowptr, "rowptr"), _index(row_csc, "row_csc"), _index(csr2csc, "csr2csc")
-    tag = torch.empty(csr2csc.numel(), dtype=torch.uint8, device=csr2csc.device)
+    tag = torch.empty(csr2csc.numel(), dtype=torch.int16 if width == 2 else torch.uint8, device=csr2csc.device)
     with _on(csr2csc.device):
         check(_lib.load().psa_csc_edge_tags(_ptr(rowptr), _ptr(row_csc), _ptr(csr2csc),
-                                            csr2csc.numel(), _ptr(tag), _stream()))
+                                            csr2csc.numel(), _ptr(tag), width, _stream()))
     return tag
 
 
@@ -771,11 +777,14 @@ def minmax_bw_csc_supported(K: int) -> bool:
 
 def spmm_minmax_bw_csc(rowptr, colptr, row_csc, csr2csc, tag, value, mat, grad, arg_out,
                        want_value: bool = True, csc2csr: Optional[torch.Tensor] = None,
-                       arg_bytes: Optional[torch.Tensor] = None):
+                       arg_bytes: Optional[torch.Tensor] = None, hot_ids: Optional[torch.Tensor] = None):
     """Backward of spmm_min / spmm_max in one pass over the CSC view, no atomics
     (see include/paddle_sparse_hip.h).  Returns (grad_value f32[nnz] | None,
     grad_mat f32[N, K]); grad_value is in CSR order (the pass writes it in CSC
-    order, `csc2csr` — computed here when not given — brings it back)."""
+    order, `csc2csr` — computed here when not given — brings it back).
+    tag / arg_bytes: uint8 (one byte per entry) or int16 (two).  hot_ids: int64[h]
+    rows of grad / arg_bytes that row_csc refers to as M + position (compact copies
+    of them are gathered here; needs arg_bytes exact, arg_out None)."""
     rowptr, colptr = _index(rowptr, "rowptr"), _index(colptr, "colptr")
     row_csc, csr2csc = _index(row_csc, "row_csc"), _index(csr2csc, "csr2csc")
     grad = _f32(grad, "grad")
@@ -787,15 +796,24 @@ def spmm_minmax_bw_csc(rowptr, colptr, row_csc, csr2csc, tag, value, mat, grad, 
     if value is not None:
         value = _f32(value, "value")
     _gpu(tag, "tag")
-    if tag.dtype != torch.uint8 or tag.numel() != csr2csc.numel():
-        raise ValueError("tag must be uint8[nnz] (ops.csc_edge_tags)")
+    if tag.dtype not in (torch.uint8, torch.int16) or tag.numel() != csr2csc.numel():
+        raise ValueError("tag must be uint8[nnz] or int16[nnz] (ops.csc_edge_tags)")
+    width = tag.element_size()
     (M, K), N, nnz = grad.shape, colptr.numel() - 1, csr2csc.numel()
     if arg_out is not None and (arg_out.shape != grad.shape or arg_out.dtype != torch.int64):
         raise ValueError("arg_out must be int64[M, K] like grad")
     if arg_bytes is not None:
         _gpu(arg_bytes, "arg_bytes")
-        if arg_bytes.dtype != torch.uint8 or arg_bytes.shape != grad.shape or not arg_bytes.is_contiguous():
-            raise ValueError("arg_bytes must be a contiguous uint8[M, K] (the third result of ops._spmm)")
+        if arg_bytes.dtype != tag.dtype or arg_bytes.shape != grad.shape or not arg_bytes.is_contiguous():
+            raise ValueError("arg_bytes must be a contiguous [M, K] tensor of the tags' dtype (the third result of ops._spmm)")
+    hot_grad = hot_bytes = None
+    num_hot = 0
+    if hot_ids is not None and hot_ids.numel():
+        if arg_bytes is None or arg_out is not None:
+            raise ValueError("hot_ids need an exact arg_bytes and no arg_out")
+        hot_ids = _index(hot_ids, "hot_ids")
+        num_hot = hot_ids.numel()
+        hot_grad, hot_bytes = _gather_rows_raw(grad, hot_ids), _gather_rows_raw(arg_bytes, hot_ids)
     gv = None
     if want_value:
         mat = _f32(mat, "mat")
@@ -809,28 +827,37 @@ def spmm_minmax_bw_csc(rowptr, colptr, row_csc, csr2csc, tag, value, mat, grad, 
         check(lib.psa_spmm_minmax_bw_csc(_ptr(rowptr), _ptr(colptr), _ptr(row_csc), _ptr(csr2csc),
                                          _ptr(tag.contiguous()), _ptr(value),
                                          _ptr(mat) if want_value else None, _ptr(grad), _ptr(arg_out),
-                                         _ptr(arg_bytes), M, N, K, nnz, _ptr(gv), _ptr(gm), _ptr(ws), ws.numel(),
-                                         _stream()))
+                                         _ptr(arg_bytes), width, _ptr(hot_grad), _ptr(hot_bytes), num_hot,
+                                         M, N, K, nnz, _ptr(gv), _ptr(gm), _ptr(ws), ws.numel(), _stream()))
     if gv is not None:
         gv = gather_rows(gv, csc2csr if csc2csr is not None else invert_permutation(csr2csc))
     return gv, gm
 
 
 def spmm_sum_bw_csc(colptr, row_csc, csr2csc, value, mat, grad, want_value: bool = True,
-                    csc2csr: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None):
+                    csc2csr: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
+                    hot_ids: Optional[torch.Tensor] = None):
     """sum backward, both gradients in one pass over the CSC view (see
     include/paddle_sparse_hip.h).  Returns (grad_value f32[nnz] | None, in CSR
     order, grad_mat f32[N, K]).  For mean, pass row_scale = 1 / max(deg, 1)
-    (f32[M]): it multiplies both gradients per edge."""
+    (f32[M]): it multiplies both gradients per edge.  hot_ids: int64[h] rows of grad
+    that row_csc refers to as M + position (a compact copy is gathered here)."""
     colptr, row_csc, csr2csc = _index(colptr, "colptr"), _index(row_csc, "row_csc"), _index(csr2csc, "csr2csc")
     grad = _f32(grad, "grad")
     if value is not None:
         value = _f32(value, "value")
-    K, N, nnz = grad.shape[1], colptr.numel() - 1, csr2csc.numel()
+    (M, K), N, nnz = grad.shape, colptr.numel() - 1, csr2csc.numel()
+    hot_grad, num_hot = None, 0
+    if hot_ids is not None and hot_ids.numel():
+        hot_ids = _index(hot_ids, "hot_ids")
+        num_hot = hot_ids.numel()
+        hot_grad = _gather_rows_raw(grad, hot_ids)
     if row_scale is not None:
         row_scale = _f32(row_scale, "row_scale")
-        if row_scale.shape != (grad.shape[0],):
+        if row_scale.shape != (M,):
             raise ValueError("row_scale must be f32[M]")
+        if num_hot:
+            row_scale = torch.cat([row_scale, row_scale[hot_ids]])
     gv = None
     if want_value:
         mat = _f32(mat, "mat")
@@ -842,7 +869,8 @@ def spmm_sum_bw_csc(colptr, row_csc, csr2csc, value, mat, grad, want_value: bool
     ws = _workspace(lib.psa_spmm_sum_bw_csc_workspace_bytes(K, nnz), grad.device)
     with _on(grad.device):
         check(lib.psa_spmm_sum_bw_csc(_ptr(colptr), _ptr(row_csc), _ptr(csr2csc), _ptr(value),
-                                      _ptr(row_scale), _ptr(mat) if want_value else None, _ptr(grad), N, K, nnz,
+                                      _ptr(row_scale), _ptr(mat) if want_value else None, _ptr(grad),
+                                      _ptr(hot_grad), num_hot, M, N, K, nnz,
                                       _ptr(gv), _ptr(gm), _ptr(ws), ws.numel(), _stream()))
     if gv is not None:
         gv = gather_rows(gv, csc2csr if csc2csr is not None else invert_permutation(csr2csc))

@@ -392,12 +392,14 @@ class SparseStorage(object):
             self._spmm_algo_memo = "edge_ranges" if 5 * (empty + tiny) > 2 * M else "row_waves"
         return self._spmm_algo_memo
 
-    def _csc_edge_tags(self) -> torch.Tensor:
-        """Position of every CSC-ordered edge inside its CSR row, one byte each
-        (ops.csc_edge_tags): structure only, memoised for the min/max backward."""
+    def _csc_edge_tags(self, width: int = 1) -> torch.Tensor:
+        """Position of every CSC-ordered edge inside its CSR row, `width` bytes each
+        (ops.csc_edge_tags): structure only, memoised per width for the min/max backward."""
         if self._edge_tags is None:
-            self._edge_tags = ops.csc_edge_tags(self.rowptr(), self._row_in_csc_order(), self.csr2csc())
-        return self._edge_tags
+            self._edge_tags = {}
+        if width not in self._edge_tags:
+            self._edge_tags[width] = ops.csc_edge_tags(self.rowptr(), self._row_in_csc_order(), self.csr2csc(), width)
+        return self._edge_tags[width]
 
     # ---- coalesce -------------------------------------------------------------
     def is_coalesced(self) -> bool:

@@ -16,7 +16,7 @@
 
 namespace paddle {
 
-enum class DataType { UINT8, INT32, INT64, FLOAT16, BFLOAT16, FLOAT32, FLOAT64 };
+enum class DataType { UINT8, INT16, INT32, INT64, FLOAT16, BFLOAT16, FLOAT32, FLOAT64 };
 inline size_t SizeOf(DataType) { return 0; }
 
 struct Place {};

@@ -517,3 +517,55 @@ def test_grad_mat_over_a_power_law_csc_view(reduce):
     want = oracle.spmm_mat_bw(reduce, row, rowptr, col, val, G, N)
     scale = oracle.spmm_mat_bw(reduce, row, rowptr, col, np.abs(val), np.abs(G), N)
     assert np.all(np.abs(Bt.grad.cpu().numpy() - want) <= 1e-5 * scale + 1e-30)
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max"])
+def test_trained_values_on_a_power_law_matrix(reduce):
+    """Hub rows and hub columns, gradients wrt the values AND the dense operand: the one-pass
+    backward over the CSC view reads the hub rows of grad_out (and of the row-local arg_out,
+    two bytes per element: the longest row has more than 128 entries) from compact copies;
+    both gradients against the oracle."""
+    from paddle_sparse_amd import SparseTensor
+
+    rng = np.random.default_rng(45)
+    M, N, K = 5000, 4000, 64
+    deg = rng.integers(0, 3, M)
+    deg[rng.integers(0, M, 25)] = 600
+    nnz = int(deg.sum())
+    row = np.repeat(np.arange(M), deg)
+    col = rng.integers(0, N, nnz)
+    hubs = rng.integers(0, N, 30)
+    pick = rng.random(nnz) < 0.6
+    col[pick] = hubs[rng.integers(0, 30, int(pick.sum()))]
+    key = np.unique(row * N + col)
+    row, col = key // N, key % N
+    val = rng.standard_normal(key.size).astype(np.float32)
+    rowptr = oracle.ind2ptr(row, M)
+    B = rng.standard_normal((N, K)).astype(np.float32)
+    G = rng.standard_normal((M, K)).astype(np.float32)
+    v = torch.from_numpy(val).cuda().requires_grad_(True)
+    a = SparseTensor(row=idx(row), col=idx(col), value=v, sparse_sizes=(M, N), is_sorted=True)
+    Bt = torch.from_numpy(B).cuda().requires_grad_(True)
+    import paddle_sparse_amd.storage as st_mod
+
+    old = st_mod.HOT_COLUMNS
+    st_mod.HOT_COLUMNS = 64  # (the production 65 536 never pays on a 5000-row test matrix)
+    try:
+        out = a.matmul(Bt, reduce)
+        out.backward(torch.from_numpy(G).cuda())
+    finally:
+        st_mod.HOT_COLUMNS = old
+    view = a.storage._csc_view()
+    assert view._hot_columns() is not None and 128 < a.storage._longest_row() <= 65_536
+    if reduce in ("sum", "mean"):
+        want_m = oracle.spmm_mat_bw(reduce, row, rowptr, col, val, G, N)
+        want_v = oracle.spmm_value_bw(reduce, row, rowptr, col, B, G)
+        scale_m = oracle.spmm_mat_bw(reduce, row, rowptr, col, np.abs(val), np.abs(G), N)
+        scale_v = oracle.spmm_value_bw(reduce, row, rowptr, col, np.abs(B), np.abs(G))
+    else:
+        ref_out, arg = oracle.spmm(reduce, rowptr, col, val, B)
+        assert np.array_equal(out.detach().cpu().numpy(), ref_out)
+        want_v, want_m = oracle.spmm_minmax_bw(col, val, B, G, arg)
+        scale_v, scale_m = oracle.spmm_minmax_bw(col, np.abs(val), np.abs(B), np.abs(G), arg)
+    assert np.all(np.abs(Bt.grad.cpu().numpy() - want_m) <= 1e-5 * scale_m + 1e-30)
+    assert np.all(np.abs(v.grad.cpu().numpy() - want_v) <= 1e-5 * scale_v + 1e-30)

@@ -297,6 +297,80 @@ def test_minmax_forward_without_arg_out(reduce, K):
 
 
 @pytest.mark.parametrize("reduce", ["min", "max"])
+@pytest.mark.parametrize("K", [4, 32, 64, 128, 256])
+@pytest.mark.parametrize("algo", ["row_waves", "edge_ranges"])
+def test_two_byte_row_local_arg(reduce, K, algo):
+    """want_arg_bytes=2: arg_out as (index in the row) & 0xffff, exact for rows of up to 65 536
+    entries, written by every forward kernel family; the one-pass backward served by it alone
+    gives the bits of the one-byte + arg_out route and the oracle's gradients."""
+    from paddle_sparse_amd import SparseStorage, ops
+
+    M, N = 900, 300
+    row, rowptr, col, val = skewed_csr(M, N, seed=K, long_rows=(0, 450, 899), long_deg=3000)
+    row2, rowptr2, col2, val2 = skewed_csr(M, N, seed=K + 1, long_rows=(3, 600), long_deg=200)
+    for r, rp, c, v in ((row, rowptr, col, val), (row2, rowptr2, col2, val2)):
+        B = np.random.default_rng(K).standard_normal((N, K)).astype(np.float32)
+        out, arg, words = ops._spmm(reduce, dev(rp), dev(c), dev(v), dev(B), want_arg_bytes=2, row=dev(r), algo=algo)
+        ref_out, ref_arg = oracle.spmm(reduce, rp, c, v, B)
+        assert np.array_equal(arg.cpu().numpy(), ref_arg) and np.array_equal(out.cpu().numpy(), ref_out)
+        live = (rp[1:] - rp[:-1]) > 0
+        want = ((ref_arg - rp[:-1, None]) & 0xffff).astype(np.uint16).view(np.int16)
+        assert words.dtype == torch.int16 and np.array_equal(words.cpu().numpy()[live], want[live])
+        only = ops._spmm(reduce, dev(rp), dev(c), dev(v), dev(B), want_arg_bytes=2, want_arg=False, row=dev(r), algo=algo)
+        assert only[1] is None and torch.equal(only[0], out) and torch.equal(only[2][dev(live)], words[dev(live)])
+        st = SparseStorage(rowptr=dev(rp), col=dev(c), value=dev(v), sparse_sizes=(M, N), is_sorted=True)
+        G = torch.randn(M, K, device="cuda")
+        head = (st.rowptr(), st.colptr(), st._row_in_csc_order(), st.csr2csc())
+        tail = (st.value(), dev(B), G)
+        gv2, gm2 = ops.spmm_minmax_bw_csc(*head, st._csc_edge_tags(2), *tail, None, csc2csr=st.csc2csr(), arg_bytes=words)
+        gv1, gm1 = ops.spmm_minmax_bw_csc(*head, st._csc_edge_tags(1), *tail, arg, csc2csr=st.csc2csr())
+        assert torch.equal(gv1, gv2) and torch.equal(gm1, gm2)
+        # ... and derived inside the call from arg_out (no forward bytes at hand)
+        gv3, gm3 = ops.spmm_minmax_bw_csc(*head, st._csc_edge_tags(2), *tail, arg, csc2csr=st.csc2csr())
+        assert torch.equal(gv1, gv3) and torch.equal(gm1, gm3)
+        ref_v, ref_m = oracle.spmm_minmax_bw(c, v, B, G.cpu().numpy(), ref_arg)
+        np.testing.assert_allclose(gm2.cpu().numpy(), ref_m, rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(gv2.cpu().numpy(), ref_v, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max"])
+@pytest.mark.parametrize("K", [16, 64, 128, 256])
+def test_csc_backward_reads_hub_rows_from_compact_copies(reduce, K):
+    """hot_ids of spmm_sum_bw_csc / spmm_minmax_bw_csc: rows of grad (and of arg_bytes) that the
+    CSC view refers to as M + position are read from compact copies — same terms in the same
+    order, so both gradients keep their bits."""
+    from paddle_sparse_amd import SparseStorage, ops
+
+    M, N = 900, 300
+    row, rowptr, col, val = skewed_csr(M, N, seed=K, long_rows=(0, 450, 899), long_deg=2500)
+    st = SparseStorage(rowptr=dev(rowptr), col=dev(col), value=dev(val), sparse_sizes=(M, N), is_sorted=True)
+    csr2csc = st.csr2csc()
+    row_csc = st._row_in_csc_order()
+    hot = torch.tensor([899, 0, 17, 450, 3, 444], device="cuda")
+    slot = torch.full((M,), -1, dtype=torch.int64, device="cuda")
+    slot[hot] = torch.arange(hot.numel(), device="cuda")
+    redirected = torch.where(slot[row_csc] >= 0, M + slot[row_csc], row_csc)
+    B = torch.randn(N, K, device="cuda")
+    G = torch.randn(M, K, device="cuda")
+    if reduce in ("sum", "mean"):
+        scale = (1.0 / st.rowcount().clamp(min=1).float()) if reduce == "mean" else None
+        plain = ops.spmm_sum_bw_csc(st.colptr(), row_csc, csr2csc, st.value(), B, G, True, csc2csr=st.csc2csr(), row_scale=scale)
+        copy = ops.spmm_sum_bw_csc(st.colptr(), redirected, csr2csc, st.value(), B, G, True, csc2csr=st.csc2csr(),
+                                   row_scale=scale, hot_ids=hot)
+    else:
+        out, _, words = ops._spmm(reduce, st.rowptr(), st.col(), st.value(), B, want_arg_bytes=2, want_arg=False)
+        tags = st._csc_edge_tags(2)
+        plain = ops.spmm_minmax_bw_csc(st.rowptr(), st.colptr(), row_csc, csr2csc, tags, st.value(), B, G, None,
+                                       csc2csr=st.csc2csr(), arg_bytes=words)
+        copy = ops.spmm_minmax_bw_csc(st.rowptr(), st.colptr(), redirected, csr2csc, tags, st.value(), B, G, None,
+                                      csc2csr=st.csc2csr(), arg_bytes=words, hot_ids=hot)
+        with pytest.raises(ValueError, match="exact arg_bytes"):
+            ops.spmm_minmax_bw_csc(st.rowptr(), st.colptr(), redirected, csr2csc, tags, st.value(), B, G,
+                                   torch.zeros(M, K, dtype=torch.int64, device="cuda"), arg_bytes=words, hot_ids=hot)
+    assert torch.equal(plain[0], copy[0]) and torch.equal(plain[1], copy[1])
+
+
+@pytest.mark.parametrize("reduce", ["min", "max"])
 def test_autograd_minmax_skips_arg_out_when_the_bytes_suffice(reduce):
     """matmul.py: short rows + grad of the dense operand -> the forward keeps the
     byte form only; long rows or value-only gradients keep arg_out; no gradient
@@ -314,7 +388,8 @@ def test_autograd_minmax_skips_arg_out_when_the_bytes_suffice(reduce):
         seen.append((k.get("want_arg_bytes", False), k.get("want_arg", True)))
         return real(*a, **k)
 
-    for long_deg, expect in ((100, (True, False)), (200, (True, True))):
+    # rows up to 128 entries: one byte per element; up to 65 536: two; beyond: one byte + arg_out
+    for long_deg, expect in ((100, (1, False)), (200, (2, False)), (66_000, (1, True))):
         row, rowptr, col, val = skewed_csr(700, 300, seed=long_deg, long_rows=(5,), long_deg=long_deg)
         B = torch.randn(300, 64, device="cuda")
         grads = []
