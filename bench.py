@@ -141,21 +141,31 @@ def rmat_graph(scale: int, n: int, device, seed: int = 4, relabel: bool = False)
 def breadth(rowptr, col, val, B, reps: int):
     """BASELINE config 3 is spmm_{sum,mean,max} forward AND backward: step times of the other
     ops of the path on the same workload, each with its algorithmic-byte fraction of the HBM
-    peak (SURVEY.md §8(d) models: forward nnz*(12+4F) + M*(8+4F) [+ M*F*8 arg_out]; backward
-    = grad of the dense operand (forward model with M and N swapped + nnz*16) + grad of the
-    values nnz*(8+8+8F+4))."""
+    peak.  Forward: SURVEY.md §8(d), nnz*(12+4F) + M*(8+4F) [+ M*F*8 arg_out].  Backward with
+    trained values: the bytes of the ONE pass over the CSC view that produces both gradients
+     — per entry the row id, the CSR edge id, the value through it, the gathered
+    grad_out row, the grad_value element and its way back to CSR order (8+8+4+4F+4+16), per column
+    colptr, its own row of the dense operand and the grad_mat row (8+8F); min/max add the
+    row-local arg_out the forward leaves (M*F bytes) and its gather (F+1 bytes per entry).
+    SURVEY §8(d)'s three-kernel model of the same gradients (`survey_model_gb`: SpMM over the
+    transpose + SDDMM-shaped value pass, each with its own full gather) is kept beside it: the
+    fused pass moves about half of that, which is why the step can beat the model's "peak"."""
     from paddle_sparse_amd import SparseTensor, ops
 
     M, F, nnz = rowptr.numel() - 1, B.shape[1], col.numel()
     N = B.shape[0]
     fwd = algorithmic_bytes(nnz, M, F, True, False)
     fwd_arg = algorithmic_bytes(nnz, M, F, True, True)
-    bwd = algorithmic_bytes(nnz, N, F, True, False) + nnz * 16 + nnz * (8 + 8 + 8 * F + 4)
+    bwd = nnz * (8 + 8 + 4 + 4 * F + 4 + 16) + N * (8 + 8 * F)
+    bwd_minmax = bwd + nnz * (F + 1)
+    survey_bwd = algorithmic_bytes(nnz, N, F, True, False) + nnz * 16 + nnz * (8 + 8 + 8 * F + 4)
     out = {}
 
-    def put(name, ms, nbytes):
+    def put(name, ms, nbytes, survey=None):
         out[name] = {"ms": round(ms, 4), "gedges_per_s": round(nnz / ms / 1e6, 3),
                      "algorithmic_gb": round(nbytes / 1e9, 3), "frac_of_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        if survey is not None:
+            out[name]["survey_model_gb"] = round(survey / 1e9, 3)
 
     for op, nb in (("spmm_mean", fwd), ("spmm_max", fwd_arg)):
         fn = getattr(ops, op)
@@ -178,9 +188,9 @@ def breadth(rowptr, col, val, B, reps: int):
         v.grad = Bt.grad = None
         a.matmul(Bt, reduce).backward(G)
 
-    for reduce, nb in (("sum", fwd + bwd), ("max", fwd_arg + bwd)):
+    for reduce, nb, sv in (("sum", fwd + bwd, fwd + survey_bwd), ("max", fwd + M * F + bwd_minmax, fwd_arg + survey_bwd)):
         fwd_bwd(reduce)
-        put(f"spmm_{reduce}_fwd_bwd", event_ms(lambda: fwd_bwd(reduce), max(3, reps // 4)), nb)
+        put(f"spmm_{reduce}_fwd_bwd", event_ms(lambda: fwd_bwd(reduce), max(3, reps // 4)), nb, sv)
     return out
 
 
@@ -210,6 +220,20 @@ def power_law(device, F: int, reps: int):
             with torch.no_grad():
                 a.matmul(B, reduce)
                 entry[f"spmm_{reduce}_tensor_surface_ms"] = round(event_ms(lambda: a.matmul(B, reduce), reps), 4)
+        if not relabel:  # a training step on the graph as generated: trained edge values, both gradients
+            v = val.clone().requires_grad_()
+            Bt = B.clone().requires_grad_()
+            G = torch.randn(N, F, device=device)
+            t = SparseTensor(row=row, rowptr=rowptr, col=col, value=v, sparse_sizes=(N, N), is_sorted=True, trust_data=True)
+
+            def step(reduce):
+                v.grad = Bt.grad = None
+                t.matmul(Bt, reduce).backward(G)
+
+            for reduce in ("sum", "max"):
+                step(reduce)
+                entry[f"spmm_{reduce}_fwd_bwd_trained_values_ms"] = round(event_ms(lambda: step(reduce), max(3, reps // 4)), 4)
+            del t, v, Bt, G
         entry["algo_chosen_by_row_stats"] = a.storage._spmm_algo()
         entry["hot_column_copy_rows"] = 0 if a.storage._hot_columns() is None else int(a.storage._hot_columns()[0].numel())
         res["rmat21_relabelled_columns" if relabel else "rmat21_as_generated"] = entry
