@@ -167,6 +167,7 @@ __device__ __forceinline__ void reduce_edge_range(
     const int n = (e - base) < 64 ? static_cast<int>(e - base) : 64;
     int64_t c_l = 0;
     float v_l = 0.f;
+    float gv_keep = 0.f;  // grad_value of this lane's edge, collected step by step
     int64_t id_l = 0;  // MASK: CSR edge id; its tag rides in the top byte
     float s_l = 1.f;   // M_CSC with row_scale: 1 / deg of this edge's CSR row
     if (lane < n) {
@@ -307,12 +308,15 @@ __device__ __forceinline__ void reduce_edge_range(
           }
 #pragma unroll
           for (int bit = U; bit < LPR; bit <<= 1) dot[0] += __shfl_xor(dot[0], bit);
-          // stored at the edge's CSC position: contiguous per wave.  (Storing
-          // straight to the CSR position, a 4-byte scatter, cost 0.8 ms more at
-          // 20 M edges than this store plus the caller's gather through csc2csr.)
-          const int slot = j + (l % U) * G + g;  // < 64
-          const float scale = MODE == M_CSC ? __shfl(s_l, slot) : 1.f;
-          if (l < U && slot < n) __builtin_nontemporal_store(dot[0] * scale, m.grad_value + base + slot);
+          // Lane l < U of group g now holds the dot of edge slot j + l * G + g.  It is handed to
+          // the lane that loaded that edge (lane == slot) and stored once per 64-edge batch, 256
+          // contiguous bytes, instead of 8 floats per step (partial-line writes).  The store goes to
+          // the edge's CSC position: contiguous per wave.  (Storing straight to the CSR position, a
+          // 4-byte scatter, cost 0.8 ms more at 20 M edges than this store plus the caller's gather
+          // through csc2csr.)
+          const unsigned rel = static_cast<unsigned>(lane - j);  // this lane's edge belongs to the step iff rel < G * U
+          const float got = __shfl(dot[0], static_cast<int>(((rel % G) * LPR + rel / G) & 63u));
+          if (rel < static_cast<unsigned>(G * U)) gv_keep = got;
         }
       }
 #pragma unroll
@@ -334,6 +338,8 @@ __device__ __forceinline__ void reduce_edge_range(
         }
       }
     }
+    if (INDIRECT && want_gv && lane < n)
+      __builtin_nontemporal_store(gv_keep * (MODE == M_CSC ? s_l : 1.f), m.grad_value + base + lane);
   }
   // Fold the G edge slots.
 #pragma unroll
