@@ -1020,6 +1020,7 @@ int launch_fused(int red, const int64_t* rowptr, const int64_t* col, const float
   const dim3 cgrid(kLongBlocks), cblock(psa::kLongThreads);
   MaskArgs plain;
   plain.xcd_rows = g_variant == 16;
+  plain.mix_xcds = g_variant == 28;  // A/B: XCD mixing of the row blocks in the forward too (tools/mix_xcds_fwd.py)
   plain.temporal_out = g_variant == 17;
   plain.nt_gather = nt_gather;
   plain.chunk_blocks = kFusedChunkBlocks;
@@ -1439,7 +1440,7 @@ int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* row, const i
     // 64 < K <= 256 with a workspace: fused roles (R-MAT scale 21: 2.55 -> 2.34 ms
     // against chunk and row launches back to back; uniform graphs unchanged);
     // variant 15 forces the separate launches
-    if ((g_variant == 0 || g_variant == 14 || g_variant == 16 || g_variant == 17 || g_variant == 18 || g_variant == 19 || (g_variant >= 20 && g_variant <= 22) || g_variant == 25 || g_variant == 26) && w.list && q > 16 &&
+    if ((g_variant == 0 || g_variant == 14 || g_variant == 16 || g_variant == 17 || g_variant == 18 || g_variant == 19 || (g_variant >= 20 && g_variant <= 22) || g_variant == 25 || g_variant == 26 || g_variant == 28) && w.list && q > 16 &&
         (q <= 64 || g_variant != 25)) {
       *bytes_done = arg_bytes.p != nullptr && minmax;
       // A dense operand far beyond the 256 MiB Infinity Cache is gathered with

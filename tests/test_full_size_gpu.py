@@ -152,3 +152,93 @@ def test_minmax_backward_properties(c3, reduce):
     gv12, gm12 = grads(G + 2 * G2)
     assert bool(((gv12 - (gv1 + 2 * gv2)).abs() <= 1e-4 * (gv1.abs() + 2 * gv2.abs()) + 1e-4).all())
     assert bool(((gm12 - (gm1 + 2 * gm2)).abs().amax(1) <= 1e-4 * (gm1.abs() + 2 * gm2.abs()).amax(1) + 1e-4).all())
+
+
+# ---- a power-law graph at scale: R-MAT scale 21 as generated (19.5 M entries, longest row 41 677) ----
+
+@pytest.fixture(scope="module")
+def rmat():
+    from paddle_sparse_amd import SparseTensor, coalesce, ops
+
+    scale, n = 21, 20_000_000
+    size = 1 << scale
+    g = torch.Generator(device="cuda").manual_seed(4)
+    row = torch.zeros(n, dtype=torch.int64, device="cuda")
+    col = torch.zeros(n, dtype=torch.int64, device="cuda")
+    for bit in range(scale):
+        r = torch.rand(n, generator=g, device="cuda")
+        row |= (r >= 0.76).to(torch.int64) << bit
+        col |= (((r >= 0.57) & (r < 0.76)) | (r >= 0.95)).to(torch.int64) << bit
+    index, val = coalesce(torch.stack([row, col]), torch.randn(n, generator=g, device="cuda"), size, size)
+    row, col = index[0].contiguous(), index[1].contiguous()
+    B = torch.randn(size, K, generator=g, device="cuda")
+    G = torch.randn(size, K, generator=g, device="cuda")
+    return dict(row=row, col=col, val=val, rowptr=ops.ind2ptr(row, size), B=B, G=G, size=size)
+
+
+@pytest.mark.parametrize("reduce", ["max", "min"])
+def test_power_law_minmax_training_step_equals_the_int64_route(rmat, reduce):
+    """The tensor surface on R-MAT 21 — edge-range forward with the hub-row copy, the two-byte
+    row-local arg_out, the one-pass backward with hub-row copies and XCD mixing — gives, bit
+    for bit, what the plain route gives: row-wave forward with the int64 arg_out, the same
+    backward pass fed with arg_out and one-byte tags, no copies."""
+    from paddle_sparse_amd import SparseStorage, SparseTensor, ops
+
+    size, row, col, rowptr = rmat["size"], rmat["row"], rmat["col"], rmat["rowptr"]
+    v = rmat["val"].clone().requires_grad_(True)
+    Bt = rmat["B"].clone().requires_grad_(True)
+    a = SparseTensor(row=row, rowptr=rowptr, col=col, value=v, sparse_sizes=(size, size), is_sorted=True, trust_data=True)
+    out = a.matmul(Bt, reduce)
+    out.backward(rmat["G"])
+    st = a.storage
+    assert st._spmm_algo() == "edge_ranges" and st._hot_columns() is not None
+    assert 128 < st._longest_row() <= 65_536 and st._csc_view()._hot_columns() is not None
+    plain_out, arg = ops._spmm(reduce, rowptr, col, rmat["val"], rmat["B"], algo="row_waves")
+    assert torch.equal(out.detach(), plain_out)
+    ref = SparseStorage(row=row, rowptr=rowptr, col=col, value=rmat["val"], sparse_sizes=(size, size), is_sorted=True,
+                        trust_data=True)
+    gv, gm = ops.spmm_minmax_bw_csc(rowptr, ref.colptr(), ref._row_in_csc_order(), ref.csr2csc(), ref._csc_edge_tags(1),
+                                    rmat["val"], rmat["B"], rmat["G"], arg, csc2csr=ref.csc2csr())
+    assert torch.equal(Bt.grad, gm) and torch.equal(v.grad, gv)
+    # the winners really win: out[r, k] == value[arg] * B[col[arg], k] on a sample of rows, hub row 0 included
+    rows = torch.cat([torch.tensor([0, 1, 2, 4], device="cuda"), torch.randint(0, size, (2000,), device="cuda")])
+    live = arg[rows] < col.numel()
+    e = arg[rows].clamp(max=col.numel() - 1)
+    want = rmat["val"][e] * torch.gather(rmat["B"][col[e].flatten()].view(*e.shape, K), 2,
+                                        torch.arange(K, device="cuda").expand(*e.shape).unsqueeze(-1)).squeeze(-1)
+    assert torch.equal(torch.where(live, want, torch.zeros_like(want)), plain_out[rows])
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean"])
+def test_power_law_sum_training_step_properties(rmat, reduce):
+    """sum / mean with trained values on R-MAT 21 through the surface (one CSC pass with hub-row
+    copies): grad_mat columns and grad_value entries against float64 recomputation on samples,
+    and the same bits from the pass without copies."""
+    from paddle_sparse_amd import SparseTensor, ops
+
+    size, row, col, rowptr = rmat["size"], rmat["row"], rmat["col"], rmat["rowptr"]
+    v = rmat["val"].clone().requires_grad_(True)
+    Bt = rmat["B"].clone().requires_grad_(True)
+    a = SparseTensor(row=row, rowptr=rowptr, col=col, value=v, sparse_sizes=(size, size), is_sorted=True, trust_data=True)
+    a.matmul(Bt, reduce).backward(rmat["G"])
+    st = a.storage
+    scale = (1.0 / st.rowcount().clamp(min=1).float()) if reduce == "mean" else None
+    gv, gm = ops.spmm_sum_bw_csc(st.colptr(), st._row_in_csc_order(), st.csr2csc(), rmat["val"], rmat["B"], rmat["G"], True,
+                                 csc2csr=st.csc2csr(), row_scale=scale)
+    assert torch.equal(Bt.grad, gm) and torch.equal(v.grad, gv)
+    # float64 on a sample of entries (grad_value) and of columns (grad_mat), hubs included
+    deg = st.rowcount().clamp(min=1).double()
+    e = torch.cat([torch.arange(0, 2000, device="cuda"), torch.randint(0, col.numel(), (20_000,), device="cuda")])
+    w = (1.0 / deg[row[e]]) if reduce == "mean" else torch.ones(e.numel(), dtype=torch.float64, device="cuda")
+    want_v = (rmat["B"][col[e]].double() * rmat["G"][row[e]].double()).sum(1) * w
+    mag_v = (rmat["B"][col[e]].double().abs() * rmat["G"][row[e]].double().abs()).sum(1) * w
+    assert bool(((v.grad[e].double() - want_v).abs() <= 1e-5 * mag_v + 1e-30).all())
+    cols = torch.cat([torch.tensor([0, 1, 2, 3, 4, 8], device="cuda"), torch.randint(0, size, (300,), device="cuda")])
+    colptr, r_csc, perm = st.colptr(), st._row_in_csc_order(), st.csr2csc()
+    for c in cols.tolist():
+        b, en = int(colptr[c]), int(colptr[c + 1])
+        rr = r_csc[b:en]
+        ww = rmat["val"][perm[b:en]].double() * ((1.0 / deg[rr]) if reduce == "mean" else 1.0)
+        want = (ww[:, None] * rmat["G"][rr].double()).sum(0)
+        mag = (ww.abs()[:, None] * rmat["G"][rr].double().abs()).sum(0)
+        assert bool(((Bt.grad[c].double() - want).abs() <= 1e-5 * mag + 1e-30).all()), c
