@@ -150,10 +150,13 @@ __device__ __forceinline__ void reduce_edge_range(
   constexpr int G = 64 / LPR;
   static_assert(64 % (G * U) == 0, "edge batch must divide the wave");
   const int g = lane / LPR;
+  // the winners are tracked as 32-bit indices local to `s` (4 VGPRs and 32-bit selects /
+  // shuffles instead of 8 and 64-bit ones); INT32_MAX = none yet, so real ones order below it
+  int32_t la[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) {
     acc[i] = RED == R_SUM ? 0.f : (RED == R_MAX ? -__FLT_MAX__ : __FLT_MAX__);
-    arg[i] = nnz;
+    la[i] = INT32_MAX;
   }
   float mr[VEC];  // MASK + grad_value: this lane's slice of mat[c, :]
 #pragma unroll
@@ -325,14 +328,14 @@ __device__ __forceinline__ void reduce_edge_range(
 #pragma unroll
           for (int i = 0; i < VEC; ++i) acc[i] += w[u] * b[u][i];
         } else if (ok[u]) {
-          const int64_t eid = base + j + u * G + g;
+          const int32_t eid = static_cast<int32_t>(base - s) + j + u * G + g;
 #pragma unroll
           for (int i = 0; i < VEC; ++i) {
             const float x = w[u] * b[u][i];
             const bool better = RED == R_MAX ? (x > acc[i]) : (x < acc[i]);
             if (better) {
               acc[i] = x;
-              if (TRACK) arg[i] = eid;
+              if (TRACK) la[i] = eid;
             }
           }
         }
@@ -353,16 +356,18 @@ __device__ __forceinline__ void reduce_edge_range(
         const bool better = RED == R_MAX ? (o > acc[i]) : (o < acc[i]);
         if (better) acc[i] = o;
       } else {
-        const int64_t oa = shfl_i64(arg[i], lane ^ off);
+        const int32_t oa = __shfl_xor(la[i], off);
         // first winner in edge order: ties go to the smaller edge id
         const bool better = RED == R_MAX ? (o > acc[i]) : (o < acc[i]);
-        if (better || (o == acc[i] && oa < arg[i])) {
+        if (better || (o == acc[i] && oa < la[i])) {
           acc[i] = o;
-          arg[i] = oa;
+          la[i] = oa;
         }
       }
     }
   }
+#pragma unroll
+  for (int i = 0; i < VEC; ++i) arg[i] = (RED == R_SUM || !TRACK || la[i] == INT32_MAX) ? nnz : s + la[i];
 }
 
 // ---------------------------------------------------------------------------
