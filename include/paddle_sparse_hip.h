@@ -193,6 +193,25 @@ int psa_spmm_half(int reduce, int dtype, const int64_t* rowptr,
                   const void* mat, int64_t M, int64_t N, int64_t K, int64_t nnz,
                   void* out, int64_t* arg_out, psa_stream_t stream);
 
+/* psa_spmm_half with the COO row ids, the kernel family and the hub-row copy of
+ * psa_spmm_coo: on a power-law graph the one-wave-per-row kernel above waits for
+ * its longest row (R-MAT scale 21, bf16, K = 128: 2.3 ms); the edge-range kernels
+ * are the same code for 16-byte lanes of 8 two-byte elements.  value: fp32[nnz]
+ * or NULL.  hot_rows: [num_hot, K] in mat's type.  algo != PSA_SPMM_EDGE_RANGES,
+ * or a shape the edge ranges do not serve (K % 8 != 0, no workspace): forwards to
+ * psa_spmm_half (hot_rows must then be NULL).  workspace:
+ * psa_spmm_half_workspace_bytes(reduce, K, nnz) bytes, 16-byte aligned.  Sums are
+ * taken in edge order inside a range, rows that cross ranges are folded from fp32
+ * partials: sum / mean may differ from psa_spmm_half in the last bit of the
+ * 2-byte result; min / max / arg_out are identical. */
+size_t psa_spmm_half_workspace_bytes(int reduce, int64_t K, int64_t nnz);
+int psa_spmm_half_coo(int reduce, int dtype, const int64_t* rowptr,
+                      const int64_t* row, const int64_t* col, const float* value,
+                      const void* mat, const void* hot_rows, int64_t num_hot,
+                      int64_t M, int64_t N, int64_t K, int64_t nnz, void* out,
+                      int64_t* arg_out, int algo, void* workspace,
+                      size_t workspace_bytes, psa_stream_t stream);
+
 /* Test/bench hook: 0 = default (one row per wave), 1 = several rows per wave for
  * K <= 128, 2 = one row per wave with 8 gather steps in flight.  Returns the
  * previous value. */

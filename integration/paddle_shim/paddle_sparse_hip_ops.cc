@@ -208,6 +208,35 @@ PD_BUILD_OP(spmm_half)
     .Attrs({"reduce: int64_t", "want_arg: bool"})
     .SetKernelFn(PD_KERNEL(spmm_half));
 
+// the same with the COO row ids, the kernel family and the hub-row copy (power-law graphs); fp32 or no values
+std::vector<paddle::Tensor> spmm_half_coo(paddle::Tensor& rowptr, paddle::Tensor& col,
+                                          const paddle::optional<paddle::Tensor>& value,
+                                          const paddle::optional<paddle::Tensor>& row, paddle::Tensor& mat,
+                                          const paddle::optional<paddle::Tensor>& hot_rows, int64_t reduce, int64_t algo,
+                                          bool want_arg) {
+  CHECK_GPU(mat);
+  CHECK_I64(rowptr);
+  CHECK_I64(col);
+  const int64_t M = rowptr.numel() - 1, N = mat.shape()[0], K = mat.shape()[1], nnz = col.numel();
+  const bool minmax = reduce == PSA_MIN || reduce == PSA_MAX;
+  auto out = paddle::empty({M, K}, mat.dtype(), mat.place());
+  auto arg = minmax && want_arg ? paddle::empty({M, K}, paddle::DataType::INT64, mat.place())
+                                : paddle::empty({0}, paddle::DataType::INT64, mat.place());
+  const size_t ws_bytes = psa_spmm_half_workspace_bytes(static_cast<int>(reduce), K, nnz);
+  auto ws = scratch(ws_bytes, mat.place());
+  PSA_CALL(psa_spmm_half_coo(static_cast<int>(reduce), dtype_id_of(mat), i64(rowptr), i64_or_null(row), i64(col),
+                             f32_or_null(value), mat.data(), hot_rows ? hot_rows.get().data() : nullptr,
+                             hot_rows ? hot_rows.get().shape()[0] : 0, M, N, K, nnz, out.data(),
+                             minmax && want_arg ? arg.data<int64_t>() : nullptr, static_cast<int>(algo),
+                             ws_bytes > 0 ? ws.data<uint8_t>() : nullptr, ws_bytes, stream_of(mat)));
+  return {out, arg};
+}
+PD_BUILD_OP(spmm_half_coo)
+    .Inputs({"rowptr", "col", paddle::Optional("value"), paddle::Optional("row"), "mat", paddle::Optional("hot_rows")})
+    .Outputs({"out", "arg_out"})
+    .Attrs({"reduce: int64_t", "algo: int64_t", "want_arg: bool"})
+    .SetKernelFn(PD_KERNEL(spmm_half_coo));
+
 // {rows without entries, rows of 1-2 entries, rows above 128 entries, longest row}: read once per
 // matrix by the Python layer to pick `algo` (paddle_sparse_amd/storage.py::_spmm_algo).
 std::vector<paddle::Tensor> csr_row_stats(paddle::Tensor& rowptr) {

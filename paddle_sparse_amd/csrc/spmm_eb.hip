@@ -1,4 +1,6 @@
-// Edge-balanced CSR x dense SpMM forward (sum / mean / min / max), fp32, gfx950.
+// Edge-balanced CSR x dense SpMM forward (sum / mean / min / max), gfx950: fp32 operands, or
+// fp16 / bf16 dense operands with fp32 products and sums (template parameter E = elements per
+// 16-byte lane load: 4 floats or 8 two-byte floats; everything else is the same kernel).
 //
 // Not present in the reference (README.md:47-50); semantics are upstream
 // pytorch_sparse spmm (README.md:267-306), restated in oracle/spmm_oracle.c.
@@ -23,6 +25,9 @@
 //   * rows without edges never show up in a range: the first `fill_blocks`
 //     workgroups of the same launch read rowptr (64 rows per wave instruction)
 //     and store their zeros (and the arg_out sentinel).
+#include <hip/hip_bf16.h>
+#include <hip/hip_fp16.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -55,17 +60,18 @@ struct EbArgs {
   const int64_t* row;
   const int64_t* col;
   const float* val;
-  const float* mat;
-  const float* hot;   // compact copy of the most referenced rows of mat, or NULL: column ids >= ncols index it
+  const void* mat;    // [N, K] fp32, or fp16 / bf16 (half != 0)
+  const void* hot;    // compact copy of the most referenced rows of mat, or NULL: column ids >= ncols index it
   int64_t ncols;      // rows of mat (INT64_MAX without a hot copy: no id is "hot")
-  float* out;
+  void* out;          // [M, K] in mat's type
+  int half;           // 0: fp32 operands; 1: fp16; 2: bf16 (mat, hot and out; sums and partials stay fp32)
   int64_t* arg_out;
   uint8_t* arg_bytes;
   int arg_width;  // bytes per entry of arg_bytes: 1 or 2 (vec_io.h)
   float* part_val;    // [2 * ranges, K]: slot 2r = head partial of range r, 2r + 1 = tail partial
   int64_t* part_arg;  // same shape, winners' edge ids (min/max with tracking)
   int64_t M, K, nnz, num_ranges;
-  int64_t ldo;        // floats between output rows (>= K: out may be a column slice of a wider matrix)
+  int64_t ldo;        // elements between output rows (>= K: out may be a column slice of a wider matrix)
   int range_len;      // edges per range, a multiple of LPR
   unsigned fill_blocks;
   int mean;
@@ -74,19 +80,85 @@ struct EbArgs {
   int dbg;  // A/B hooks: 1 = drop the row stores (timing only), 2 = ordinary instead of non-temporal stores
 };
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// E elements of one 16-byte load as floats
+template <int E>
+__device__ __forceinline__ void eb_unpack(const f32x4& raw, int half, float (&f)[E]) {
+  if constexpr (E == 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = raw[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t w = __float_as_uint(raw[i]);
+      if (half == 2) {  // bf16: the upper half of an fp32
+        f[2 * i] = __uint_as_float(w << 16);
+        f[2 * i + 1] = __uint_as_float(w & 0xffff0000u);
+      } else {
+        const float2 v = __half22float2(*reinterpret_cast<const __half2*>(&w));
+        f[2 * i] = v.x;
+        f[2 * i + 1] = v.y;
+      }
+    }
+  }
+}
+
+// E floats -> 16 bytes of the output type (round to nearest even), stored at element index `elem`
+template <int E>
+__device__ __forceinline__ void eb_store_out(void* out, int64_t elem, int half, const float (&f)[E], bool nt) {
+  f32x4 v;
+  if constexpr (E == 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = f[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint32_t w;
+      if (half == 2) {
+        const __hip_bfloat162 p = __float22bfloat162_rn(make_float2(f[2 * i], f[2 * i + 1]));
+        w = *reinterpret_cast<const uint32_t*>(&p);
+      } else {
+        const __half2 p = __floats2half2_rn(f[2 * i], f[2 * i + 1]);
+        w = *reinterpret_cast<const uint32_t*>(&p);
+      }
+      v[i] = __uint_as_float(w);
+    }
+  }
+  f32x4* dst = reinterpret_cast<f32x4*>(static_cast<char*>(out) + elem * (16 / E));
+  if (nt) __builtin_nontemporal_store(v, dst);
+  else *dst = v;
+}
+
+// one element (the combine kernel writes boundary rows k by k)
+__device__ __forceinline__ void eb_store_out1(void* out, int64_t elem, int half, float x) {
+  if (half == 0) {
+    __builtin_nontemporal_store(x, static_cast<float*>(out) + elem);
+  } else if (half == 2) {
+    const __hip_bfloat16 h = __float2bfloat16(x);
+    static_cast<uint16_t*>(out)[elem] = *reinterpret_cast<const uint16_t*>(&h);
+  } else {
+    const __half h = __float2half_rn(x);
+    static_cast<uint16_t*>(out)[elem] = *reinterpret_cast<const uint16_t*>(&h);
+  }
+}
+
 // Rows without edges: out = 0, arg_out = nnz.  One wave tests 64 rows per step
 // and zeroes the empty ones, 64 / P rows per store instruction (P lanes x 16 B
-// cover a row of K floats, or a 1 KiB slice of a wider one).
+// cover a row of K elements, or a 1 KiB slice of a wider one).
+template <int E>
 __device__ __forceinline__ void eb_fill_role(const EbArgs& a) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int64_t K4 = a.K >> 2;
+  const int64_t KU = a.K / E;  // 16-byte units per row
   int P = 1;
-  while (P < K4 && P < 64) P <<= 1;
+  while (P < KU && P < 64) P <<= 1;
   const int rps = 64 / P;
   const int sub = lane / P, q0 = lane % P;
   const int64_t base = static_cast<int64_t>(blockIdx.x) * kFillRows + wave * (kFillRows / kWaves);
-  const float zero[4] = {0.f, 0.f, 0.f, 0.f};
+  float zero[E];
+#pragma unroll
+  for (int i = 0; i < E; ++i) zero[i] = 0.f;
   const int64_t sentinel[4] = {a.nnz, a.nnz, a.nnz, a.nnz};
   for (int it = 0; it < kFillRows / kWaves / 64; ++it) {
     const int64_t r0 = base + it * 64;
@@ -104,13 +176,16 @@ __device__ __forceinline__ void eb_fill_role(const EbArgs& a) {
       }
       if (mine >= 0) {
         const int64_t rr = r0 + mine;
-        for (int64_t q = q0; q < K4; q += P) {
-          store_vec_nt<4>(a.out + rr * a.ldo + 4 * q, zero);
+        for (int64_t q = q0; q < KU; q += P) {
+          eb_store_out<E>(a.out, rr * a.ldo + E * q, a.half, zero, true);
           if (a.minmax) {
-            if (a.arg_out) store_arg_nt<4>(a.arg_out + rr * a.K + 4 * q, sentinel);
-            if (a.arg_bytes) {
-              const uint32_t none[4] = {0u, 0u, 0u, 0u};
-              store_arg_local4(a.arg_bytes, rr * a.K + 4 * q, none, a.arg_width);
+#pragma unroll
+            for (int h = 0; h < E; h += 4) {
+              if (a.arg_out) store_arg_nt<4>(a.arg_out + rr * a.K + E * q + h, sentinel);
+              if (a.arg_bytes) {
+                const uint32_t none[4] = {0u, 0u, 0u, 0u};
+                store_arg_local4(a.arg_bytes, rr * a.K + E * q + h, none, a.arg_width);
+              }
             }
           }
         }
@@ -126,47 +201,53 @@ __device__ __forceinline__ float red_init() {
 
 // One finished row of a range: out (and arg_out / arg_bytes) straight from the
 // registers of the lane group that reduced it.
-template <int RED, bool TRACK>
+template <int RED, bool TRACK, int E>
 __device__ __forceinline__ void eb_store_row(const EbArgs& a, int64_t row, int64_t k0, int64_t start,
-                                             int seg_first, int cnt, float (&acc)[4], const int (&arg)[4]) {
+                                             int seg_first, int cnt, float (&acc)[E], const int (&arg)[E]) {
   if (RED == R_SUM) {
     if (a.mean && cnt > 1) {
       const float d = static_cast<float>(cnt);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[i] = acc[i] / d;
+      for (int i = 0; i < E; ++i) acc[i] = acc[i] / d;
     }
   } else if (TRACK) {
-    if (a.arg_out) {
-      int64_t g[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) g[i] = start + arg[i];
-      store_arg_nt<4>(a.arg_out + row * a.K + k0, g);
-    }
-    if (a.arg_bytes) {
-      uint32_t f[4];
+    for (int h = 0; h < E; h += 4) {
+      if (a.arg_out) {
+        int64_t g[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) f[i] = arg_local(arg[i] - seg_first, cnt, a.arg_width);
-      store_arg_local4(a.arg_bytes, row * a.K + k0, f, a.arg_width);
+        for (int i = 0; i < 4; ++i) g[i] = start + arg[h + i];
+        store_arg_nt<4>(a.arg_out + row * a.K + k0 + h, g);
+      }
+      if (a.arg_bytes) {
+        uint32_t f[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f[i] = arg_local(arg[h + i] - seg_first, cnt, a.arg_width);
+        store_arg_local4(a.arg_bytes, row * a.K + k0 + h, f, a.arg_width);
+      }
     }
   }
   if (a.dbg & 1) {
     if (acc[0] != 12345.678f) return;
   }
   if (a.dbg & 4) {  // same store instructions, all into a cache-resident scratch (timing only)
-    store_vec_nt<4>(a.part_val + (row & 4095) * a.K + k0, acc);
+    eb_store_out<E>(a.part_val, (row & 4095) * a.K + k0, E == 4 ? 0 : a.half, acc, true);
     return;
   }
-  if (a.dbg & 2) store_vec<4>(a.out + row * a.ldo + k0, acc);
-  else store_vec_nt<4>(a.out + row * a.ldo + k0, acc);
+  eb_store_out<E>(a.out, row * a.ldo + k0, a.half, acc, !(a.dbg & 2));
 }
 
-template <int RED, bool TRACK>
+template <int RED, bool TRACK, int E>
 __device__ __forceinline__ void eb_store_partial(const EbArgs& a, int64_t slot, int64_t k0, int64_t start,
-                                                 const float (&acc)[4], const int (&arg)[4]) {
-  store_vec<4>(a.part_val + slot * a.K + k0, acc);
+                                                 const float (&acc)[E], const int (&arg)[E]) {
+#pragma unroll
+  for (int h = 0; h < E; h += 4) {
+    const float part[4] = {acc[h], acc[h + 1], acc[h + 2], acc[h + 3]};
+    store_vec<4>(a.part_val + slot * a.K + k0 + h, part);
+  }
   if (RED != R_SUM && TRACK) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) a.part_arg[slot * a.K + k0 + i] = start + arg[i];
+    for (int i = 0; i < E; ++i) a.part_arg[slot * a.K + k0 + i] = start + arg[i];
   }
 }
 
@@ -203,10 +284,8 @@ __device__ __forceinline__ void static_for(F&& f) {
 // holds on every path.  A destination register is named by the wait statement
 // that precedes its first use ("+v"), which keeps the compiler from reading it
 // early (cdna_hip_programming.md 5.7, form ii).
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 template <bool NT>
-__device__ __forceinline__ void asm_gather16(f32x4& dst, const float* p) {
+__device__ __forceinline__ void asm_gather16(f32x4& dst, const char* p) {
   if constexpr (NT) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
   else asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
@@ -221,12 +300,13 @@ __device__ __forceinline__ void asm_wait_round(f32x4 (&b)[U]) {
   else asm volatile("s_waitcnt vmcnt(%c4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "i"(N) : "memory");
 }
 
-template <int LPR, int RED, int U, int D, bool TRACK, bool NT>
+template <int LPR, int RED, int U, int D, bool TRACK, bool NT, int E>
 __global__ void __launch_bounds__(kThreads) spmm_eb_kernel(EbArgs a) {
   if (blockIdx.x < a.fill_blocks) {  // ---- fill role ----
-    if (blockIdx.y == 0) eb_fill_role(a);
+    if (blockIdx.y == 0) eb_fill_role<E>(a);
     return;
   }
+  constexpr int ESZ = 16 / E;  // bytes per element of mat / out
   // ---- range role ----
   constexpr int G = 64 / LPR;
   constexpr int RPS = LPR / U;  // rounds per staged batch of LPR edges
@@ -237,10 +317,11 @@ __global__ void __launch_bounds__(kThreads) spmm_eb_kernel(EbArgs a) {
   const int g = lane / LPR;
   const int l = lane % LPR;
   const int gsel = (lane - l) << 2;  // ds_bpermute byte address of the group's lane 0
-  const int64_t k0 = (static_cast<int64_t>(blockIdx.y) * LPR + l) * 4;
+  const int64_t k0 = (static_cast<int64_t>(blockIdx.y) * LPR + l) * E;
   const bool kact = k0 < a.K;
-  const float* matk = a.mat + (kact ? k0 : 0);  // idle K lanes gather (and drop) column 0
-  const float* hotk = a.hot + (kact ? k0 : 0);
+  const char* matk = static_cast<const char*>(a.mat) + (kact ? k0 : 0) * ESZ;  // idle K lanes gather (and drop) column 0
+  const char* hotk = static_cast<const char*>(a.hot) + (kact ? k0 : 0) * ESZ;
+  const int64_t row_bytes = a.K * ESZ;
   const int64_t rg = ((static_cast<int64_t>(blockIdx.x) - a.fill_blocks) * kWaves + wave) * G + g;
   const int64_t start = rg * a.range_len;
   const bool active = start < a.nnz;
@@ -258,13 +339,13 @@ __global__ void __launch_bounds__(kThreads) spmm_eb_kernel(EbArgs a) {
   // hand-counted part; inside the walk its vmcnt(0) would drain the ring
   asm volatile("" : "+v"(prev_row), "+v"(next_row));
 
-  float acc[4];
-  int arg[4];
+  float acc[E];
+  int arg[E];
   int cur_row = -1;        // row being reduced (-1: none yet)
   int seg_first = 0;       // range-local index of its first edge in this range
   bool head_open = false;  // cur_row came in from the previous range
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < E; ++i) {
     acc[i] = red_init<RED>();
     arg[i] = 0;
   }
@@ -298,7 +379,7 @@ __global__ void __launch_bounds__(kThreads) spmm_eb_kernel(EbArgs a) {
       rr[B][u] = __builtin_amdgcn_ds_bpermute(sel, s.r);
       // ids at or above ncols name a row of the compact hot copy (psa_spmm_coo, hot_rows)
       const bool is_hot = c >= a.ncols;
-      asm_gather16<NT>(b[B][u], (is_hot ? hotk : matk) + (is_hot ? c - a.ncols : c) * a.K);
+      asm_gather16<NT>(b[B][u], (is_hot ? hotk : matk) + (is_hot ? c - a.ncols : c) * row_bytes);
     }
   };
   auto consume = [&](auto buf, int local0) {
@@ -310,22 +391,24 @@ __global__ void __launch_bounds__(kThreads) spmm_eb_kernel(EbArgs a) {
       if (local < len) {  // uniform inside the lane group
         if (rr[B][u] != cur_row) {
           if (cur_row >= 0 && kact) {
-            if (head_open) eb_store_partial<RED, TRACK>(a, 2 * rg, k0, start, acc, arg);
-            else eb_store_row<RED, TRACK>(a, cur_row, k0, start, seg_first, local - seg_first, acc, arg);
+            if (head_open) eb_store_partial<RED, TRACK, E>(a, 2 * rg, k0, start, acc, arg);
+            else eb_store_row<RED, TRACK, E>(a, cur_row, k0, start, seg_first, local - seg_first, acc, arg);
           }
           head_open = cur_row < 0 && rr[B][u] == prev_row;
           cur_row = rr[B][u];
           seg_first = local;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[i] = red_init<RED>();
+          for (int i = 0; i < E; ++i) acc[i] = red_init<RED>();
         }
+        float bf[E];
+        eb_unpack<E>(b[B][u], a.half, bf);
         if (RED == R_SUM) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[i] += w[B][u] * b[B][u][i];
+          for (int i = 0; i < E; ++i) acc[i] += w[B][u] * bf[i];
         } else {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float x = w[B][u] * b[B][u][i];
+          for (int i = 0; i < E; ++i) {
+            const float x = w[B][u] * bf[i];
             const bool better = RED == R_MAX ? (x > acc[i]) : (x < acc[i]);
             if (better) {
               acc[i] = x;
@@ -368,9 +451,9 @@ __global__ void __launch_bounds__(kThreads) spmm_eb_kernel(EbArgs a) {
   // the D - 1 rounds requested past the end: their registers must not be reused in flight
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (cur_row >= 0 && kact) {
-    if (head_open) eb_store_partial<RED, TRACK>(a, 2 * rg, k0, start, acc, arg);
-    else if (cur_row == next_row) eb_store_partial<RED, TRACK>(a, 2 * rg + 1, k0, start, acc, arg);
-    else eb_store_row<RED, TRACK>(a, cur_row, k0, start, seg_first, len - seg_first, acc, arg);
+    if (head_open) eb_store_partial<RED, TRACK, E>(a, 2 * rg, k0, start, acc, arg);
+    else if (cur_row == next_row) eb_store_partial<RED, TRACK, E>(a, 2 * rg + 1, k0, start, acc, arg);
+    else eb_store_row<RED, TRACK, E>(a, cur_row, k0, start, seg_first, len - seg_first, acc, arg);
   }
 }
 
@@ -448,7 +531,7 @@ __global__ void __launch_bounds__(kThreads) spmm_eb_combine_kernel(EbArgs a) {
           if (a.arg_out) __builtin_nontemporal_store(arg[t], a.arg_out + r_last * a.K + k);
           if (a.arg_bytes) store_arg_local1(a.arg_bytes, r_last * a.K + k, arg_local(arg[t] - rs, deg, a.arg_width), a.arg_width);
         }
-        __builtin_nontemporal_store(acc[t], a.out + r_last * a.ldo + k);
+        eb_store_out1(a.out, r_last * a.ldo + k, a.half, acc[t]);
       }
     }
   }
@@ -498,18 +581,18 @@ struct EbPlan {
   int k_tiles;
 };
 
-EbPlan eb_plan(int64_t K, int range_len_override) {
-  const int64_t q = K / 4;
+EbPlan eb_plan(int64_t K, int range_len_override, int E = 4) {
+  const int64_t q = K / E;  // 16-byte units per row
   EbPlan p;
   p.k_tiles = 1;
   if (q <= 4) p.lpr = 4;
   else if (q <= 8) p.lpr = 8;
   else if (q <= 16) p.lpr = 16;
   else if (q <= 32) p.lpr = 32;
-  else if (K < 192) p.lpr = 64;
-  else {  // ceil(K / 128) tiles of the K = 128 form over grid.y, as the row kernels do
+  else if (q < 48) p.lpr = 64;
+  else {  // ceil(q / 32) tiles of the 32-lane form over grid.y (K = 128 fp32), as the row kernels do
     p.lpr = 32;
-    p.k_tiles = static_cast<int>(psa::ceil_div(K, 128));
+    p.k_tiles = static_cast<int>(psa::ceil_div(q, 32));
   }
   // a wave (64 / LPR ranges) takes 512 edges, a range at least 32
   p.range_len = p.lpr >= 32 ? 256 : (p.lpr == 16 ? 128 : (p.lpr == 8 ? 64 : 32));
@@ -519,8 +602,8 @@ EbPlan eb_plan(int64_t K, int range_len_override) {
 
 // The scratch holds two partial slots per range of the planned length (an
 // override for A/B runs may go down to 128 edges, not below the plan).
-int scratch_range_len(int64_t K) {
-  const int d = eb_plan(K, 0).range_len;
+int scratch_range_len(int64_t K, int E = 4) {
+  const int d = eb_plan(K, 0, E).range_len;
   return d < 128 ? d : 128;
 }
 
@@ -528,32 +611,35 @@ int scratch_range_len(int64_t K) {
 
 namespace psa {
 
-bool eb_supported(int64_t M, int64_t K, int64_t nnz) {
-  return K > 0 && K % 4 == 0 && M > 0 && M < (1ll << 31) && nnz < (1ll << 31);  // and N < 2^31: the caller checks
+bool eb_supported(int64_t M, int64_t K, int64_t nnz, int half) {
+  const int E = half ? 8 : 4;
+  return K > 0 && K % E == 0 && M > 0 && M < (1ll << 31) && nnz < (1ll << 31);  // and N < 2^31: the caller checks
 }
 
-size_t eb_workspace_bytes(bool minmax, int64_t K, int64_t nnz) {
+size_t eb_workspace_bytes(bool minmax, int64_t K, int64_t nnz, int half) {
   if (K <= 0 || nnz <= 0) return 256;
-  const size_t ranges = static_cast<size_t>(ceil_div(nnz, scratch_range_len(K)));
+  const size_t ranges = static_cast<size_t>(ceil_div(nnz, scratch_range_len(K, half ? 8 : 4)));
   return align256(static_cast<size_t>(nnz) * sizeof(int64_t)) + align256(2 * ranges * K * sizeof(float)) +
          (minmax ? align256(2 * ranges * K * sizeof(int64_t)) : 0);
 }
 
 int launch_spmm_eb(int red, int mean, const int64_t* rowptr, const int64_t* row,
-                   const int64_t* col, const float* val, const float* mat, float* out, int64_t ldo,
+                   const int64_t* col, const float* val, const void* mat, void* out, int64_t ldo,
                    int64_t* arg_out, uint8_t* arg_bytes, int arg_width, int64_t M, int64_t N, int64_t K,
-                   int64_t nnz, const float* hot_rows, int64_t num_hot, void* workspace, size_t workspace_bytes,
-                   bool nt_gather, int range_len_override, int dbg, hipStream_t s) {
+                   int64_t nnz, const void* hot_rows, int64_t num_hot, void* workspace, size_t workspace_bytes,
+                   bool nt_gather, int range_len_override, int dbg, hipStream_t s, int half) {
   PSA_REQUIRE(num_hot >= 0 && N + num_hot < (1ll << 31), "column ids (with the hot copy) must fit 31 bits");
-  PSA_REQUIRE(eb_supported(M, K, nnz), "shape not served by the edge-balanced kernels");
+  PSA_REQUIRE(half >= 0 && half <= 2, "half: 0 fp32, 1 fp16, 2 bf16");
+  PSA_REQUIRE(eb_supported(M, K, nnz, half), "shape not served by the edge-balanced kernels");
+  const int E = half ? 8 : 4;
   const bool minmax = red != R_SUM;
-  if (workspace == nullptr || workspace_bytes < eb_workspace_bytes(minmax, K, nnz)) {
+  if (workspace == nullptr || workspace_bytes < eb_workspace_bytes(minmax, K, nnz, half)) {
     set_error("psa_spmm: workspace too small");
     return PSA_ERR_WORKSPACE;
   }
   PSA_REQUIRE(aligned(workspace, 16), "workspace must be 16-byte aligned");
-  const EbPlan plan = eb_plan(K, range_len_override);
-  PSA_REQUIRE(plan.range_len >= scratch_range_len(K), "range too short for the scratch layout");
+  const EbPlan plan = eb_plan(K, range_len_override, E);
+  PSA_REQUIRE(plan.range_len >= scratch_range_len(K, E), "range too short for the scratch layout");
   char* p = static_cast<char*>(workspace);
   if (row == nullptr && nnz > 0) {
     int64_t* built = reinterpret_cast<int64_t*>(p);
@@ -571,6 +657,7 @@ int launch_spmm_eb(int red, int mean, const int64_t* rowptr, const int64_t* row,
   a.hot = num_hot > 0 ? hot_rows : nullptr;
   a.ncols = num_hot > 0 ? N : INT64_MAX;
   a.out = out;
+  a.half = half;
   a.ldo = ldo;
   a.arg_out = minmax ? arg_out : nullptr;
   a.arg_bytes = minmax ? arg_bytes : nullptr;
@@ -580,7 +667,7 @@ int launch_spmm_eb(int red, int mean, const int64_t* rowptr, const int64_t* row,
   a.nnz = nnz;
   a.range_len = plan.range_len;
   a.num_ranges = ceil_div(nnz, plan.range_len);
-  const size_t slots = 2 * static_cast<size_t>(ceil_div(nnz > 0 ? nnz : 1, scratch_range_len(K)));
+  const size_t slots = 2 * static_cast<size_t>(ceil_div(nnz > 0 ? nnz : 1, scratch_range_len(K, E)));
   a.part_val = reinterpret_cast<float*>(p);
   p += align256(slots * K * sizeof(float));
   a.part_arg = minmax ? reinterpret_cast<int64_t*>(p) : nullptr;
@@ -599,25 +686,25 @@ int launch_spmm_eb(int red, int mean, const int64_t* rowptr, const int64_t* row,
   if (cblocks > 4096) cblocks = 4096;
   const dim3 cgrid(static_cast<unsigned>(cblocks > 0 ? cblocks : 1));
 
-#define PSA_EB_NT(LPR, U, D, NT)                                                                           \
+#define PSA_EB_NT(LPR, U, D, NT, E)                                                                        \
   do {                                                                                            \
     if (red == R_SUM) {                                                                           \
-      hipLaunchKernelGGL((spmm_eb_kernel<LPR, R_SUM, U, D, false, NT>), grid, block, 0, s, a);           \
+      hipLaunchKernelGGL((spmm_eb_kernel<LPR, R_SUM, U, D, false, NT, E>), grid, block, 0, s, a);        \
       if (a.num_ranges > 1) hipLaunchKernelGGL((spmm_eb_combine_kernel<R_SUM, false>), cgrid, block, 0, s, a); \
     } else if (red == R_MIN) {                                                                    \
       if (track) {                                                                                \
-        hipLaunchKernelGGL((spmm_eb_kernel<LPR, R_MIN, U, D, true, NT>), grid, block, 0, s, a);          \
+        hipLaunchKernelGGL((spmm_eb_kernel<LPR, R_MIN, U, D, true, NT, E>), grid, block, 0, s, a);       \
         if (a.num_ranges > 1) hipLaunchKernelGGL((spmm_eb_combine_kernel<R_MIN, true>), cgrid, block, 0, s, a); \
       } else {                                                                                    \
-        hipLaunchKernelGGL((spmm_eb_kernel<LPR, R_MIN, U, D, false, NT>), grid, block, 0, s, a);         \
+        hipLaunchKernelGGL((spmm_eb_kernel<LPR, R_MIN, U, D, false, NT, E>), grid, block, 0, s, a);      \
         if (a.num_ranges > 1) hipLaunchKernelGGL((spmm_eb_combine_kernel<R_MIN, false>), cgrid, block, 0, s, a); \
       }                                                                                           \
     } else {                                                                                      \
       if (track) {                                                                                \
-        hipLaunchKernelGGL((spmm_eb_kernel<LPR, R_MAX, U, D, true, NT>), grid, block, 0, s, a);          \
+        hipLaunchKernelGGL((spmm_eb_kernel<LPR, R_MAX, U, D, true, NT, E>), grid, block, 0, s, a);       \
         if (a.num_ranges > 1) hipLaunchKernelGGL((spmm_eb_combine_kernel<R_MAX, true>), cgrid, block, 0, s, a); \
       } else {                                                                                    \
-        hipLaunchKernelGGL((spmm_eb_kernel<LPR, R_MAX, U, D, false, NT>), grid, block, 0, s, a);         \
+        hipLaunchKernelGGL((spmm_eb_kernel<LPR, R_MAX, U, D, false, NT, E>), grid, block, 0, s, a);      \
         if (a.num_ranges > 1) hipLaunchKernelGGL((spmm_eb_combine_kernel<R_MAX, false>), cgrid, block, 0, s, a); \
       }                                                                                           \
     }                                                                                             \
@@ -625,15 +712,25 @@ int launch_spmm_eb(int red, int mean, const int64_t* rowptr, const int64_t* row,
 
 #define PSA_EB(LPR, U, D)                  \
   do {                                     \
-    if (nt_gather) PSA_EB_NT(LPR, U, D, true); \
-    else PSA_EB_NT(LPR, U, D, false);      \
+    if (nt_gather) PSA_EB_NT(LPR, U, D, true, 4); \
+    else PSA_EB_NT(LPR, U, D, false, 4);      \
   } while (0)
-  switch (plan.lpr) {
-    case 4: PSA_EB_NT(4, 2, 2, false); break;
-    case 8: PSA_EB_NT(8, 2, 4, false); break;
-    case 16: PSA_EB_NT(16, 2, 4, false); break;
-    case 32: PSA_EB(32, 2, 4); break;
-    default: PSA_EB(64, 2, 4); break;
+  if (half) {  // two-byte operands: 8 elements per lane, ordinary (cached) gathers
+    switch (plan.lpr) {
+      case 4: PSA_EB_NT(4, 2, 2, false, 8); break;
+      case 8: PSA_EB_NT(8, 2, 4, false, 8); break;
+      case 16: PSA_EB_NT(16, 2, 4, false, 8); break;
+      case 32: PSA_EB_NT(32, 2, 4, false, 8); break;
+      default: PSA_EB_NT(64, 2, 4, false, 8); break;
+    }
+  } else {
+    switch (plan.lpr) {
+      case 4: PSA_EB_NT(4, 2, 2, false, 4); break;
+      case 8: PSA_EB_NT(8, 2, 4, false, 4); break;
+      case 16: PSA_EB_NT(16, 2, 4, false, 4); break;
+      case 32: PSA_EB(32, 2, 4); break;
+      default: PSA_EB(64, 2, 4); break;
+    }
   }
 #undef PSA_EB
 #undef PSA_EB_NT

@@ -19,6 +19,7 @@
 #include <hip/hip_fp16.h>
 
 #include "common.h"
+#include "spmm_eb.h"
 
 namespace {
 
@@ -421,4 +422,38 @@ extern "C" int psa_spmm_half(int reduce, int dtype, const int64_t* rowptr, const
   if (dtype == PSA_BF16)
     return dispatch_half<BF16>(red, track, val32, rowptr, col, value, m, o, arg_out, M, K, nnz, reduce == PSA_MEAN, s);
   return dispatch_half<F16>(red, track, val32, rowptr, col, value, m, o, arg_out, M, K, nnz, reduce == PSA_MEAN, s);
+}
+
+extern "C" size_t psa_spmm_half_workspace_bytes(int reduce, int64_t K, int64_t nnz) {
+  if (K <= 0 || nnz <= 0 || K % 8 != 0) return 0;
+  return psa::eb_workspace_bytes(reduce == PSA_MIN || reduce == PSA_MAX, K, nnz, 1);
+}
+
+extern "C" int psa_spmm_half_coo(int reduce, int dtype, const int64_t* rowptr, const int64_t* row, const int64_t* col,
+                                 const float* value, const void* mat, const void* hot_rows, int64_t num_hot, int64_t M,
+                                 int64_t N, int64_t K, int64_t nnz, void* out, int64_t* arg_out, int algo,
+                                 void* workspace, size_t workspace_bytes, psa_stream_t stream) {
+  PSA_REQUIRE(reduce >= PSA_SUM && reduce <= PSA_MAX, "bad reduce");
+  PSA_REQUIRE(algo >= PSA_SPMM_AUTO && algo <= PSA_SPMM_EDGE_RANGES, "bad algo");
+  PSA_REQUIRE(num_hot >= 0 && (num_hot == 0 || hot_rows != nullptr), "hot_rows is NULL");
+  if (dtype != PSA_F16 && dtype != PSA_BF16) {
+    psa::set_error("psa_spmm_half_coo: dtype must be PSA_F16 or PSA_BF16");
+    return PSA_ERR_UNSUPPORTED;
+  }
+  const int half = dtype == PSA_BF16 ? 2 : 1;
+  const bool eb = algo == PSA_SPMM_EDGE_RANGES && workspace != nullptr && nnz > 0 && N < (1ll << 31) &&
+                  psa::aligned(mat, 16) && psa::aligned(out, 16) && psa::eb_supported(M, K, nnz, half) &&
+                  (num_hot == 0 || psa::aligned(hot_rows, 16));
+  if (!eb) {
+    if (num_hot > 0) {
+      psa::set_error("psa_spmm_half_coo: hot_rows is served by the edge-range kernels only (algo = PSA_SPMM_EDGE_RANGES, "
+                     "K % 8 == 0, 16-byte aligned operands, a workspace)");
+      return PSA_ERR_UNSUPPORTED;
+    }
+    return psa_spmm_half(reduce, dtype, rowptr, col, value, PSA_F32, mat, M, N, K, nnz, out, arg_out, stream);
+  }
+  PSA_REQUIRE(rowptr != nullptr && col != nullptr && mat != nullptr && out != nullptr, "NULL pointer");
+  const int red = reduce == PSA_MIN ? R_MIN : (reduce == PSA_MAX ? R_MAX : R_SUM);
+  return psa::launch_spmm_eb(red, reduce == PSA_MEAN, rowptr, row, col, value, mat, out, K, arg_out, nullptr, 1, M, N, K,
+                             nnz, hot_rows, num_hot, workspace, workspace_bytes, false, 0, 0, psa::as_stream(stream), half);
 }

@@ -62,7 +62,15 @@ class _SpMM(torch.autograd.Function):
             # half-width dense operand: 2-byte gathers and stores, fp32 sums (psa_spmm_half).  The
             # backward runs the fp32 kernels on widened operands and narrows the gradients.
             need = track and (ctx.needs_input_grad[1] or (value is not None and ctx.needs_input_grad[0]))
-            out, arg = ops._spmm(reduce, rowptr, col, value, mat, want_arg=need and reduce in ("min", "max"))
+            algo, row, hot_rows = "auto", None, None
+            if mat.shape[1] % 8 == 0 and (value is None or value.dtype == torch.float32) and storage._spmm_algo() == "edge_ranges":
+                # power-law matrix: the edge-range kernels and the hub-row copy, as for fp32
+                algo, row = "edge_ranges", storage.row()
+                plan = storage._hot_columns()
+                if plan is not None:
+                    hot_rows, col = ops._gather_rows_raw(mat.detach(), plan[0]), plan[1]
+            out, arg = ops._spmm(reduce, rowptr, col, value, mat, want_arg=need and reduce in ("min", "max"), row=row,
+                                 algo=algo, hot_rows=hot_rows)
             ctx.storage, ctx.reduce, ctx.half = storage, reduce, mat.dtype
             ctx.save_for_backward(value, mat, arg, None)
             return out

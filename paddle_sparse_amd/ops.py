@@ -121,7 +121,7 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
     if mat.dtype in (torch.float16, torch.bfloat16):
         if out is not None or want_arg_bytes:
             raise ValueError("the half-width SpMM takes neither `out` nor arg_bytes")
-        res = _spmm_half(reduce, rowptr, col, value, mat, want_arg)
+        res = _spmm_half(reduce, rowptr, col, value, mat, want_arg, row=row, algo=algo, hot_rows=hot_rows)
         return res
     if mat.dtype != torch.float32:
         raise TypeError(f"spmm takes float32, float16 or bfloat16 dense operands (mat is {mat.dtype})")
@@ -179,10 +179,12 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
     return out, arg
 
 
-def _spmm_half(reduce: str, rowptr, col, value, mat, want_arg: bool = True):
+def _spmm_half(reduce: str, rowptr, col, value, mat, want_arg: bool = True, row=None, algo: str = "auto",
+               hot_rows=None):
     """fp16 / bf16 `mat` -> (out in mat's dtype, arg_out | None): fp32 products and sums,
-    one rounding on store (psa_spmm_half).  value: None, float32[nnz] or mat's dtype[nnz].
-    K % 8 != 0 widens to fp32 and rounds the fp32 kernel's result instead."""
+    one rounding on store (psa_spmm_half / psa_spmm_half_coo).  value: None, float32[nnz] or
+    mat's dtype[nnz].  algo="edge_ranges" (with `row`, `hot_rows` as for fp32; fp32 or no values):
+    the edge-balanced kernels.  K % 8 != 0 widens to fp32 and rounds the fp32 kernel's result."""
     if mat.dim() != 2:
         raise ValueError("mat must be 2-D [N, K]")
     mat = mat.contiguous()
@@ -199,6 +201,22 @@ def _spmm_half(reduce: str, rowptr, col, value, mat, want_arg: bool = True):
         return res[0].to(mat.dtype), res[1]
     out = torch.empty((M, K), dtype=mat.dtype, device=mat.device)
     arg = torch.empty((M, K), dtype=torch.int64, device=mat.device) if minmax and want_arg else None
+    if algo == "edge_ranges" and nnz > 0 and (value is None or value.dtype == torch.float32):
+        num_hot = 0
+        if hot_rows is not None:
+            _gpu(hot_rows, "hot_rows")
+            if hot_rows.dtype != mat.dtype or hot_rows.dim() != 2 or hot_rows.shape[1] != K or not hot_rows.is_contiguous():
+                raise ValueError("hot_rows must be a contiguous [h, K] tensor of mat's dtype")
+            num_hot = hot_rows.shape[0]
+        lib = _lib.load()
+        ws = _workspace(lib.psa_spmm_half_workspace_bytes(rid, K, nnz), mat.device)
+        with _on(mat.device):
+            check(lib.psa_spmm_half_coo(rid, _DTYPE_ID[mat.dtype], _ptr(rowptr), _ptr(row), _ptr(col), _ptr(value), _ptr(mat),
+                                        _ptr(hot_rows) if num_hot else None, num_hot, M, N, K, nnz, _ptr(out), _ptr(arg),
+                                        _lib.SPMM_ALGO_ID[algo], _ptr(ws), ws.numel(), _stream()))
+        return out, arg
+    if hot_rows is not None:
+        raise ValueError("hot_rows needs algo='edge_ranges' and fp32 (or no) values")
     with _on(mat.device):
         check(_lib.load().psa_spmm_half(rid, _DTYPE_ID[mat.dtype], _ptr(rowptr), _ptr(col), _ptr(value),
                                         _DTYPE_ID[value.dtype] if value is not None else 0, _ptr(mat), M, N, K, nnz,

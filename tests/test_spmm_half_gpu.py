@@ -126,3 +126,90 @@ def test_half_full_size_properties():
     o32 = ops.spmm_sum(rowptr, col, val, B.float())  # the fp32 kernel on the same (widened) operand
     S = ops.spmm_sum(rowptr, col, val.abs(), B.float().abs())
     assert bool(((o1 - o32).abs() <= 2e-5 * S + 2.0 ** -8 * o32.abs() + 1e-30).all())
+
+
+# ---- the edge-range kernels with 2-byte operands (psa_spmm_half_coo) ------------------------------
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max"])
+@pytest.mark.parametrize("K", [8, 16, 32, 64, 128, 256, 264, 520])
+@pytest.mark.parametrize("give_row", [True, False])
+def test_half_edge_ranges_vs_oracle(dtype, reduce, K, give_row):
+    """algo="edge_ranges" with fp16 / bf16 operands: rows of 0, a few, 200 and 900 entries (rows
+    crossing many ranges, ranges holding many rows, empty rows between them), fp32 or no values,
+    against the oracle on the rounded inputs; min / max exact with identical arg_out; two
+    launches give the same bits; the hub-row copy gives the same bits."""
+    from paddle_sparse_amd import ops
+
+    M, N = 700, 500
+    d = lambda x: None if x is None else torch.from_numpy(np.ascontiguousarray(x)).cuda()  # noqa: E731
+    for seed, long_rows, long_deg in ((K, (0, 350, 699), 900), (K + 1, (3,), 200)):
+        row, rowptr, col, val = skewed_csr(M, N, seed=seed, long_rows=long_rows, long_deg=long_deg)
+        B = np.random.default_rng(K).standard_normal((N, K)).astype(np.float32)
+        Bd, Bf = rounded(B, dtype)
+        for v in (val, None):
+            out, arg = ops._spmm(reduce, d(rowptr), d(col), d(v), Bd, row=d(row) if give_row else None, algo="edge_ranges")
+            assert out.dtype == dtype
+            ref, ref_arg = oracle.spmm(reduce, rowptr, col, v, Bf)
+            S = oracle.spmm_abs_sum(rowptr, col, v, Bf)
+            got = out.float().cpu().numpy()
+            assert np.all(np.abs(got - ref) <= 1e-5 * S + EPS[dtype] * np.abs(ref) + TINY[dtype] + 1e-30), (reduce, v is None)
+            if reduce in ("min", "max"):
+                assert np.array_equal(got, torch.from_numpy(ref).to(dtype).float().numpy())
+                assert np.array_equal(arg.cpu().numpy(), ref_arg)
+                plain = ops._spmm(reduce, d(rowptr), d(col), d(v), Bd)  # one wave per row: same results exactly
+                assert torch.equal(plain[0], out) and torch.equal(plain[1], arg)
+            again = ops._spmm(reduce, d(rowptr), d(col), d(v), Bd, row=d(row) if give_row else None, algo="edge_ranges")
+            assert torch.equal(again[0], out)
+            # hub-row copy: references to the hot columns go to a compact copy — same edges, same order
+            hot = torch.tensor([7, 0, 499, 123, 77], device="cuda")
+            slot = torch.full((N,), -1, dtype=torch.int64, device="cuda")
+            slot[hot] = torch.arange(hot.numel(), device="cuda")
+            c = d(col)
+            col_eff = torch.where(slot[c] >= 0, N + slot[c], c)
+            copy = ops._spmm(reduce, d(rowptr), col_eff, d(v), Bd, row=d(row), algo="edge_ranges", hot_rows=Bd[hot].contiguous())
+            assert torch.equal(copy[0], out)
+            if reduce in ("min", "max"):
+                assert torch.equal(copy[1], arg)
+
+
+def test_half_surface_takes_edge_ranges_on_a_power_law_matrix():
+    """SparseTensor.matmul with a bf16 operand on a hub-dominated matrix: edge ranges + hub-row
+    copy chosen per matrix (as for fp32), result within the stated bound of the oracle."""
+    import paddle_sparse_amd.storage as st_mod
+    from paddle_sparse_amd import SparseTensor, ops
+
+    rng = np.random.default_rng(46)
+    M, N, K = 6000, 5000, 64
+    deg = rng.integers(0, 3, M)
+    deg[rng.integers(0, M, 20)] = 800
+    row = np.repeat(np.arange(M), deg)
+    col = rng.integers(0, N, row.size)
+    hubs = rng.integers(0, N, 40)
+    pick = rng.random(row.size) < 0.6
+    col[pick] = hubs[rng.integers(0, 40, int(pick.sum()))]
+    key = np.unique(row * N + col)
+    row, col = key // N, key % N
+    val = rng.standard_normal(key.size).astype(np.float32)
+    rowptr = oracle.ind2ptr(row, M)
+    Bd, Bf = rounded(rng.standard_normal((N, K)).astype(np.float32), torch.bfloat16)
+    d = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()  # noqa: E731
+    a = SparseTensor(row=d(row), col=d(col), value=d(val), sparse_sizes=(M, N), is_sorted=True)
+    seen = []
+    real = ops._spmm_half
+
+    def spy(*args, **kw):
+        seen.append((kw.get("algo"), kw.get("hot_rows") is not None))
+        return real(*args, **kw)
+
+    old = st_mod.HOT_COLUMNS
+    st_mod.HOT_COLUMNS, ops._spmm_half = 64, spy
+    try:
+        with torch.no_grad():
+            out = a.matmul(Bd, "sum")
+    finally:
+        st_mod.HOT_COLUMNS, ops._spmm_half = old, real
+    assert seen == [("edge_ranges", True)] and out.dtype == torch.bfloat16
+    ref, _ = oracle.spmm("sum", rowptr, col, val, Bf)
+    S = oracle.spmm_abs_sum(rowptr, col, val, Bf)
+    assert np.all(np.abs(out.float().cpu().numpy() - ref) <= 1e-5 * S + 2.0 ** -8 * np.abs(ref) + 1e-30)
