@@ -260,3 +260,15 @@ tags = A.storage._csc_edge_tags()
 ms = gpu_ms(lambda: ops.spmm_minmax_bw_csc(rowptr_d, colptr_d, row_csc, csr2csc, tags, val_c, B_d, g_d, arg), reps=10)
 report("a13", "spmm_max backward, one CSC pass (both grads)", ms,
        M * F * 9 + E * (4 * F + F + 21) + N * F * 8 + E * 4)
+# what autograd runs: the forward leaves the row-local arg_out (1 byte per element here), no int64 arg_out, no compress pass
+_, _, local = ops._spmm("max", rowptr_d, col_s, val_c, B_d, want_arg_bytes=True, want_arg=False)
+inv = A.storage.csc2csr()
+ms = gpu_ms(lambda: ops.spmm_minmax_bw_csc(rowptr_d, colptr_d, row_csc, csr2csc, tags, val_c, B_d, g_d, None, csc2csr=inv,
+                                           arg_bytes=local), reps=10)
+report("a13", "spmm_max backward, one CSC pass fed by the forward's row-local arg (both grads)", ms,
+       E * (8 + 8 + 4 + 4 * F + F + 1 + 4 + 16) + N * (8 + 8 * F))
+ms = gpu_ms(lambda: ops.spmm_minmax_bw_csc(rowptr_d, colptr_d, row_csc, csr2csc, tags, val_c, B_d, g_d, None, want_value=False,
+                                           arg_bytes=local), reps=10)
+report("a13", "  same, grad of mat only (fixed adjacency)", ms, E * (8 + 8 + 4 + 4 * F + F + 1) + N * (8 + 4 * F))
+ms = gpu_ms(lambda: ops.spmm_sum_bw_csc(colptr_d, row_csc, csr2csc, val_c, B_d, g_d, True, csc2csr=inv), reps=10)
+report("a13", "spmm_sum backward, one CSC pass (both grads)", ms, E * (8 + 8 + 4 + 4 * F + 4 + 16) + N * (8 + 8 * F))
