@@ -548,6 +548,16 @@ size_t psa_unique_workspace_bytes(int64_t n);
 int psa_unique_count(const int64_t* sorted_keys, int64_t n, void* workspace,
                      size_t workspace_bytes, int64_t* count_out,
                      psa_stream_t stream);
+/* psa_unique_count on the output of psa_index_sort / psa_sort_pairs_u32, folding in
+ * the sort's look-back diagnostic: count_out int64[2] (device) = {count, fault},
+ * fault != 0 when a bounded inter-workgroup wait of a radix pass gave up (never
+ * expected; the order is then invalid).  sort_workspace / sort_max_value: what the
+ * sort was called with (its workspace must still be alive); n is the same n.
+ * The caller reads both words in its one host read of the count. */
+int psa_unique_count_after_sort(const int64_t* sorted_keys, int64_t n,
+                                void* workspace, size_t workspace_bytes,
+                                const void* sort_workspace, int64_t sort_max_value,
+                                int64_t* count_out, psa_stream_t stream);
 
 /* Phase 2 (after the caller has read the count and sized the outputs):
  * ptr_out int64[count+1] = start of every run of equal keys, ptr_out[count]

@@ -98,6 +98,7 @@ SIGNATURES = {
     "psa_count2ptr_workspace_bytes": (c_size_t, [c_int64]),
     "psa_count2ptr": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "psa_unique_workspace_bytes": (c_size_t, [c_int64]),
+    "psa_unique_count_after_sort": (c_int, [c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_int64, c_void_p, c_void_p]),
     "psa_unique_count": (c_int, [c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_void_p]),
     "psa_unique_write": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -37,7 +37,7 @@ def _coalesce_sorted_stream(row, col, value, m: int, n: int, op: str):
     flags = int(status[1].item())
     if flags & 1:
         raise ops.IndexRangeError(f"coalesce: an index lies outside the {m} x {n} matrix")
-    perm = None
+    perm = scratch = None
     was_sorted = not (flags & 2)
     if not was_sorted:
         if value is not None and value.dim() == 1 and value.element_size() == 4 and not ops.needs_grad(value):
@@ -45,10 +45,11 @@ def _coalesce_sorted_stream(row, col, value, m: int, n: int, op: str):
             # reduce below then reads them as a stream, not as value[perm[i]]
             # (values that autograd tracks go through the permutation instead:
             # ops.segment_csr / ops.gather_rows are differentiable)
-            keys, value = ops.sort_pairs(keys, value, m * n)
+            keys, value, scratch = ops.sort_pairs(keys, value, m * n, keep_scratch=True)
         else:
-            keys, perm = ops.index_sort(keys, m * n, with_sorted_inputs=True)
-    count, ptr, new_row, new_col = ops.unique_sorted(keys, n)
+            keys, perm, scratch = ops.index_sort(keys, m * n, with_sorted_inputs=True, keep_scratch=True)
+    # the count read below also brings back the sort's look-back diagnostic
+    count, ptr, new_row, new_col = ops.unique_sorted(keys, n, after=scratch)
     if count == nnz and was_sorted:
         return row, col, value  # sorted and duplicate-free already
     if value is not None:

@@ -117,7 +117,9 @@ scan_blocks_kernel(uint32_t* __restrict__ block_counts, int64_t nb,
     *count = static_cast<int64_t>(base) + incl;
     // the coalesce chain's status words {count, flags, range seen, inversion seen} (chain.hip):
     // flag bits folded here, with the sort's fault word, instead of in launches of their own
-    if (chain_status) count[1] = (count[2] ? 1 : 0) | (count[3] ? 2 : 0) | ((fault != nullptr && *fault != 0) ? 4 : 0);
+    if (chain_status == 1) count[1] = (count[2] ? 1 : 0) | (count[3] ? 2 : 0) | ((fault != nullptr && *fault != 0) ? 4 : 0);
+    // psa_unique_count_after_sort: count[1] = did a look-back of the sort that produced these keys give up
+    if (chain_status == 2) count[1] = (fault != nullptr && *fault != 0) ? 1 : 0;
   }
 }
 
@@ -337,6 +339,31 @@ int segment_reduce_dev(int reduce, int dtype, const void* src, const int64_t* pe
 extern "C" {
 
 size_t psa_unique_workspace_bytes(int64_t n) { return unique_ws_bytes(n); }
+
+int psa_unique_count_after_sort(const int64_t* sorted_keys, int64_t n, void* workspace, size_t workspace_bytes,
+                                const void* sort_workspace, int64_t sort_max_value, int64_t* count_out,
+                                psa_stream_t stream) {
+  PSA_REQUIRE(n >= 0, "negative size");
+  PSA_REQUIRE(count_out != nullptr, "count_out is NULL");
+  hipStream_t s = psa::as_stream(stream);
+  if (n == 0) {
+    PSA_ZERO(count_out, 2 * sizeof(int64_t), s);
+    return PSA_OK;
+  }
+  PSA_REQUIRE(sorted_keys != nullptr, "sorted_keys is NULL");
+  if (workspace == nullptr || workspace_bytes < unique_ws_bytes(n)) {
+    psa::set_error("psa_unique_count_after_sort: workspace too small");
+    return PSA_ERR_WORKSPACE;
+  }
+  const int64_t nb = psa::ceil_div(n, kTile);
+  PSA_REQUIRE(nb <= 0x7fffffff, "n too large for one launch");
+  uint32_t* bc = static_cast<uint32_t*>(workspace);
+  hipLaunchKernelGGL(unique_count_kernel, dim3(static_cast<unsigned>(nb)), dim3(kThreads), 0, s, sorted_keys, n, bc);
+  hipLaunchKernelGGL(scan_blocks_kernel, dim3(1), dim3(1024), 0, s, bc, nb, count_out, 2,
+                     psa::sort_fault_word(sort_workspace, n, sort_max_value));
+  PSA_LAUNCH_CHECK();
+  return PSA_OK;
+}
 
 int psa_unique_count(const int64_t* sorted_keys, int64_t n, void* workspace,
                      size_t workspace_bytes, int64_t* count_out,

@@ -279,14 +279,22 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
 
 
+class SortScratch:
+    """Workspace of a finished sort, kept alive so that the next host read can fold in the
+    sort's look-back diagnostic (unique_sorted(after=...))."""
+
+    def __init__(self, ws: torch.Tensor, n: int, max_value: int):
+        self.ws, self.n, self.max_value = ws, n, max_value
+
+
 def index_sort(keys: torch.Tensor, max_value: Optional[int] = None,
-               with_sorted_inputs: bool = False
-               ) -> Tuple[Optional[torch.Tensor], torch.Tensor]:
+               with_sorted_inputs: bool = False, keep_scratch: bool = False):
     """paddle_sparse/utils.py:14-23 — returns (sorted | None, perm).
 
     Stable LSD radix sort in HIP; `max_value` (exclusive bound on the keys, the
     reference passes M*N) selects the number of 8-bit passes.  perm is the
     stable sorting permutation, bit-identical to numpy argsort(kind="stable").
+    keep_scratch: also return a SortScratch for unique_sorted(after=...).
     """
     keys = _index(keys, "keys")
     n = keys.numel()
@@ -301,6 +309,8 @@ def index_sort(keys: torch.Tensor, max_value: Optional[int] = None,
     with _on(keys.device):
         check(lib.psa_index_sort(_ptr(keys), n, max_value, _ptr(out), _ptr(perm),
                                  _ptr(ws), ws.numel(), _stream()))
+    if keep_scratch:
+        return out, perm, SortScratch(ws, n, max_value)
     return out, perm
 
 
@@ -322,10 +332,10 @@ def index_sort_checked(keys: torch.Tensor, max_value: int):
     return out, perm, status
 
 
-def sort_pairs(keys: torch.Tensor, payload: torch.Tensor, max_value: Optional[int] = None
-               ) -> Tuple[torch.Tensor, torch.Tensor]:
+def sort_pairs(keys: torch.Tensor, payload: torch.Tensor, max_value: Optional[int] = None, keep_scratch: bool = False):
     """Stable sort of (key, 4-byte payload) pairs: returns (sorted_keys,
-    payload[perm]) without ever forming perm.  payload: 1-D, 4-byte dtype."""
+    payload[perm]) without ever forming perm.  payload: 1-D, 4-byte dtype.
+    keep_scratch: also return a SortScratch for unique_sorted(after=...)."""
     keys = _index(keys, "keys")
     _gpu(payload, "payload")
     if payload.dim() != 1 or payload.element_size() != 4 or payload.numel() != keys.numel():
@@ -342,6 +352,8 @@ def sort_pairs(keys: torch.Tensor, payload: torch.Tensor, max_value: Optional[in
     with _on(keys.device):
         check(lib.psa_sort_pairs_u32(_ptr(keys), _ptr(payload), n, max_value, _ptr(out_keys),
                                      _ptr(out_pay), _ptr(ws), ws.numel(), _stream()))
+    if keep_scratch:
+        return out_keys, out_pay, SortScratch(ws, n, max_value)
     return out_keys, out_pay
 
 
@@ -678,20 +690,29 @@ def _segment_csr_raw(src: torch.Tensor, indptr: torch.Tensor, reduce: str = "sum
 
 
 def unique_sorted(sorted_keys: torch.Tensor, N: int, want_ptr: bool = True,
-                  want_rowcol: bool = True):
+                  want_rowcol: bool = True, after: Optional[SortScratch] = None):
     """Run-length structure of SORTED keys (storage.py:455-470 without the
     bool-mask selects).  Returns (count, ptr | None, row | None, col | None)
     with row = key // N, col = key % N of each distinct key.  One host sync
-    (reading the count to size the outputs) — the reference has three."""
+    (reading the count to size the outputs) — the reference has three.
+    after: the SortScratch of the sort that produced the keys; its look-back
+    diagnostic comes back with the count (HipCoreError if a wait gave up)."""
     sorted_keys = _index(sorted_keys, "sorted_keys")
     n = sorted_keys.numel()
     dev = sorted_keys.device
     lib = _lib.load()
     ws = _workspace(lib.psa_unique_workspace_bytes(n), dev)
-    count_d = torch.empty(1, dtype=torch.int64, device=dev)
+    count_d = torch.empty(2, dtype=torch.int64, device=dev)
     with _on(dev):
-        check(lib.psa_unique_count(_ptr(sorted_keys), n, _ptr(ws), ws.numel(), _ptr(count_d), _stream()))
-        count = int(count_d.item())
+        if after is not None and after.n == n:
+            check(lib.psa_unique_count_after_sort(_ptr(sorted_keys), n, _ptr(ws), ws.numel(), _ptr(after.ws),
+                                                  after.max_value, _ptr(count_d), _stream()))
+            count, fault = count_d.tolist()
+            if fault:
+                raise HipCoreError("index_sort: an inter-workgroup wait of a radix pass gave up; the order is invalid")
+        else:
+            check(lib.psa_unique_count(_ptr(sorted_keys), n, _ptr(ws), ws.numel(), _ptr(count_d), _stream()))
+            count = int(count_d[0].item())
         ptr = torch.empty(count + 1, dtype=torch.int64, device=dev) if want_ptr else None
         # row and col are the two rows of ONE [2, count] buffer, so the
         # functional API's `stack([row, col])` (coalesce.py:29) is `row._base`

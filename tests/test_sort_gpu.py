@@ -250,3 +250,27 @@ def test_segment_csr_long_segments_wave_kernel(reduce):
     got = ops.segment_csr(dev(src), dev(indptr), reduce).cpu().numpy()
     ref = so.segment_csr_fast(src, indptr, reduce)
     np.testing.assert_allclose(got, ref, rtol=1e-6, atol=0)
+
+
+def test_count_read_brings_back_the_sorts_lookback_diagnostic():
+    """ops.unique_sorted(after=scratch): the one host read of the run count also carries the
+    fault word of the sort that produced the keys (psa_unique_count_after_sort) — 0 on every
+    real run; a poisoned workspace stands in for a look-back that gave up."""
+    from paddle_sparse_amd import ops
+    from paddle_sparse_amd._lib import HipCoreError
+
+    g = torch.Generator(device="cuda").manual_seed(5)
+    n, bound = 1_500_000, 3000 * 3000
+    keys = torch.randint(0, bound, (n,), generator=g, device="cuda")
+    out, perm, scratch = ops.index_sort(keys, bound, with_sorted_inputs=True, keep_scratch=True)
+    plain = ops.unique_sorted(out, 3000)
+    checked = ops.unique_sorted(out, 3000, after=scratch)
+    assert plain[0] == checked[0] == int(torch.unique(keys).numel())
+    assert all(torch.equal(a, b) for a, b in zip(plain[1:], checked[1:]))
+    pay = torch.arange(n, dtype=torch.int32, device="cuda")
+    out2, pay2, scratch2 = ops.sort_pairs(keys, pay, bound, keep_scratch=True)
+    assert torch.equal(out2, out) and torch.equal(pay2.long(), perm)
+    assert ops.unique_sorted(out2, 3000, after=scratch2)[0] == plain[0]
+    scratch.ws.fill_(255)
+    with pytest.raises(HipCoreError, match="gave up"):
+        ops.unique_sorted(out, 3000, after=scratch)
