@@ -45,11 +45,14 @@ def _spmm_sum_planned(st: SparseStorage, weights: Optional[torch.Tensor], mat: t
     storage's per-matrix choices: kernel family, COO row ids, compact copy of the hub rows."""
     algo = st._spmm_algo()
     col, row, hot_rows = st.col(), None, None
-    if algo == "edge_ranges":
+    lanes = 8 if mat.dtype in (torch.float16, torch.bfloat16) else 4  # elements per 16-byte lane of the edge-range kernels
+    if algo == "edge_ranges" and mat.shape[1] % lanes == 0:
         row = st.row()
-        plan = st._hot_columns() if mat.shape[1] % 4 == 0 else None
+        plan = st._hot_columns()
         if plan is not None:
-            hot_rows, col = ops.gather_rows(mat, plan[0]), plan[1]
+            hot_rows, col = ops._gather_rows_raw(mat, plan[0]), plan[1]
+    else:
+        algo = "auto"
     return ops._spmm("sum", st.rowptr(), col, weights, mat, row=row, algo=algo, hot_rows=hot_rows)[0]
 
 
@@ -118,6 +121,16 @@ class _SpMM(torch.autograd.Function):
         need_value = value is not None and ctx.needs_input_grad[0]
         need_mat = ctx.needs_input_grad[1]
         grad_out = grad_out.contiguous()
+        if (ctx.half is not None and reduce in ("sum", "mean") and need_mat and not need_value
+                and grad_out.dtype == ctx.half and grad_out.shape[1] % 8 == 0):
+            # fixed adjacency, half-width operands: A^T grad_out is the half-width forward over the
+            # CSC view (fp32 weights, fp32 sums, one rounding) — no widening of grad_out, no fp32 pass
+            csr2csc = st.csr2csc()
+            mean = reduce == "mean"
+            w = None
+            if value is not None or mean:
+                w = _csc_weights(st, None if value is None else value.detach().float(), csr2csc, st._row_in_csc_order(), mean)
+            return None, _spmm_sum_planned(st._csc_view(), w, grad_out), None, None, None
         if ctx.half is not None:
             gv, gm = _SpMM._backward_fp32(st, reduce, None if value is None else value.float(), mat.float(),
                                           grad_out.float(), arg, None, need_value, need_mat)

@@ -213,3 +213,62 @@ def test_half_surface_takes_edge_ranges_on_a_power_law_matrix():
     ref, _ = oracle.spmm("sum", rowptr, col, val, Bf)
     S = oracle.spmm_abs_sum(rowptr, col, val, Bf)
     assert np.all(np.abs(out.float().cpu().numpy() - ref) <= 1e-5 * S + 2.0 ** -8 * np.abs(ref) + 1e-30)
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean"])
+@pytest.mark.parametrize("graph", ["uniform", "hubs"])
+@pytest.mark.parametrize("with_value", [True, False])
+def test_half_backward_of_a_fixed_adjacency_stays_half_width(reduce, graph, with_value):
+    """Gradient wrt a bf16 dense operand with fixed edge weights: the half-width forward over
+    the CSC view (fp32 weights and sums, one rounding), no fp32 copies of the operands; against
+    the oracle on the rounded grad_out with the stated bound."""
+    import paddle_sparse_amd.storage as st_mod
+    from paddle_sparse_amd import SparseTensor, ops
+
+    rng = np.random.default_rng(48)
+    K = 64
+    if graph == "uniform":
+        M, N = 3000, 2500
+        row, rowptr, col, val = random_csr(M, N, 30_000, seed=7, sort_cols=True)
+    else:
+        M, N = 6000, 5000
+        deg = rng.integers(0, 3, M)
+        deg[rng.integers(0, M, 20)] = 800
+        row = np.repeat(np.arange(M), deg)
+        col = rng.integers(0, N, row.size)
+        hubs = rng.integers(0, N, 40)
+        pick = rng.random(row.size) < 0.6
+        col[pick] = hubs[rng.integers(0, 40, int(pick.sum()))]
+        key = np.unique(row * N + col)
+        row, col = key // N, key % N
+        val = rng.standard_normal(key.size).astype(np.float32)
+        rowptr = oracle.ind2ptr(row, M)
+    keep = np.concatenate([[True], (row[1:] != row[:-1]) | (col[1:] != col[:-1])])
+    row, col, val = row[keep], col[keep], val[keep]
+    rowptr = oracle.ind2ptr(row, M)
+    if not with_value:
+        val = None
+    d = lambda x: None if x is None else torch.from_numpy(np.ascontiguousarray(x)).cuda()  # noqa: E731
+    Bd, _ = rounded(rng.standard_normal((N, K)).astype(np.float32), torch.bfloat16)
+    Gd, Gf = rounded(rng.standard_normal((M, K)).astype(np.float32), torch.bfloat16)
+    a = SparseTensor(row=d(row), col=d(col), value=d(val), sparse_sizes=(M, N), is_sorted=True)
+    Bt = Bd.clone().requires_grad_()
+    widened = []
+    real = ops._spmm
+
+    def spy(reduce_, rowptr_, col_, value_, mat_, **kw):
+        widened.append(mat_.dtype)
+        return real(reduce_, rowptr_, col_, value_, mat_, **kw)
+
+    old = st_mod.HOT_COLUMNS
+    st_mod.HOT_COLUMNS, ops._spmm = 64, spy
+    try:
+        a.matmul(Bt, reduce).backward(Gd)
+    finally:
+        st_mod.HOT_COLUMNS, ops._spmm = old, real
+    assert widened == [torch.bfloat16, torch.bfloat16]  # forward and backward, both half-width
+    assert Bt.grad.dtype == torch.bfloat16
+    ones = np.ones(col.size, np.float32)
+    want = oracle.spmm_mat_bw(reduce, row, rowptr, col, ones if val is None else val, Gf, N)
+    scale = oracle.spmm_mat_bw(reduce, row, rowptr, col, ones if val is None else np.abs(val), np.abs(Gf), N)
+    assert np.all(np.abs(Bt.grad.float().cpu().numpy() - want) <= 1e-5 * scale + 2.0 ** -8 * np.abs(want) + 1e-30)
