@@ -191,6 +191,22 @@ def breadth(rowptr, col, val, B, reps: int):
     for reduce, nb, sv in (("sum", fwd + bwd, fwd + survey_bwd), ("max", fwd + M * F + bwd_minmax, fwd_arg + survey_bwd)):
         fwd_bwd(reduce)
         put(f"spmm_{reduce}_fwd_bwd", event_ms(lambda: fwd_bwd(reduce), max(3, reps // 4)), nb, sv)
+    # fixed adjacency (gradient wrt the dense operand only): the backward is a forward over the CSC view
+    del a, v, Bt
+    fixed = SparseTensor(row=row, rowptr=rowptr, col=col, value=val, sparse_sizes=(M, N), is_sorted=True, trust_data=True)
+    fixed.storage.csr2csc()
+    for dtype, name, nb in ((torch.float32, "spmm_sum_fwd_bwd_fixed_adjacency", fwd + algorithmic_bytes(nnz, N, F, True, False)),
+                            (torch.bfloat16, "spmm_sum_bf16_fwd_bwd_fixed_adjacency", 2 * half_bytes)):
+        Bd = B.detach().to(dtype, copy=True).requires_grad_()  # a leaf of its own (B itself stays as it is)
+        Gd = G.to(dtype)
+
+        def step():
+            Bd.grad = None
+            fixed.matmul(Bd, "sum").backward(Gd)
+
+        step()
+        put(name, event_ms(step, max(3, reps // 4)), nb)
+        del Bd, Gd
     return out
 
 
