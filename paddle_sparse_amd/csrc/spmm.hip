@@ -137,7 +137,10 @@ struct MaskArgs {
 // Reduce edges [s, e) of one row into acc/arg: LPR lanes x VEC floats cover the
 // K tile at k0, the G = 64/LPR lane groups take different edges of a step, U
 // steps are issued before any is consumed; the groups are folded at the end.
-template <int VEC, int LPR, int RED, int U, int MODE = M_PLAIN>
+// AW (M_MASK): form of bytes / tag — 1: one byte per entry, candidates of long rows verified against
+// arg_out (second phase); 0: one byte, no arg_out at hand (candidates of long rows count as no hit);
+// 2: two bytes per entry, exact.  HOT: ids >= m.hot_first go to the compact copies
+template <int VEC, int LPR, int RED, int U, int MODE = M_PLAIN, int AW = 1, bool HOT = false>
 __device__ __forceinline__ void reduce_edge_range(
     const int64_t* __restrict__ col, const float* __restrict__ val,
     const float* __restrict__ matk, int64_t K, bool kact, int64_t s, int64_t e,
@@ -183,7 +186,7 @@ __device__ __forceinline__ void reduce_edge_range(
           v_l *= s_l;
         }
         if (MASK) {  // the tag rides in the top bits of the edge id (ids stay below 2^48)
-          if (m.arg_width == 2) id_l |= static_cast<int64_t>(reinterpret_cast<const uint16_t*>(m.tag)[base + lane]) << 48;
+          if (AW == 2) id_l |= static_cast<int64_t>(reinterpret_cast<const uint16_t*>(m.tag)[base + lane]) << 48;
           else id_l |= static_cast<int64_t>(m.tag[base + lane]) << 56;
         }
       } else {
@@ -203,9 +206,10 @@ __device__ __forceinline__ void reduce_edge_range(
         ok[u] = (idx < n) && kact;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) b[u][i] = 0.f;
-        const bool is_hot = INDIRECT && c >= m.hot_first;
+        const bool is_hot = HOT && c >= m.hot_first;
+        const int64_t off = (is_hot ? c - m.hot_first : c) * K;
         if (ok[u]) {
-          const float* src = is_hot ? m.hot + (c - m.hot_first) * K : matk + c * K;
+          const float* src = (is_hot ? m.hot : matk) + off;
           if (m.nt_gather) load_vec_nt<VEC>(src, b[u]);
           else load_vec<VEC>(src, b[u]);
         }
@@ -213,8 +217,8 @@ __device__ __forceinline__ void reduce_edge_range(
           mb[u] = 0;
           mb2[u] = 0;
           if (ok[u]) {
-            const uint8_t* bsrc = is_hot ? m.hot_bytes + (c - m.hot_first) * K * m.arg_width : m.bytes + c * K * m.arg_width;
-            if (m.arg_width == 2) {
+            const uint8_t* bsrc = (is_hot ? m.hot_bytes : m.bytes) + off * (AW == 2 ? 2 : 1);
+            if (AW == 2) {
               const uint2 w2 = *reinterpret_cast<const uint2*>(bsrc);
               mb[u] = w2.x;
               mb2[u] = w2.y;
@@ -237,7 +241,7 @@ __device__ __forceinline__ void reduce_edge_range(
           const uint64_t idw = static_cast<uint64_t>(shfl_i64(id_l, idx));
           hits[u] = 0;
           uint32_t tag;
-          if (m.arg_width == 2) {  // exact: equal entries are the hits
+          if (AW == 2) {  // exact: equal entries are the hits
             tag = static_cast<uint32_t>(idw >> 48);
 #pragma unroll
             for (int i = 0; i < VEC; ++i)
@@ -256,7 +260,11 @@ __device__ __forceinline__ void reduce_edge_range(
         // inside the gather loop, they made this pass 1.5x slower than float atomics
         // on an R-MAT graph.  The low words decide: arg_out[r, k] is an edge of row r,
         // and two edges of one row differ in their low 32 bits.
-        if (__any(any_need)) {
+        if (AW == 0) {
+#pragma unroll
+          for (int u = 0; u < U; ++u) hits[u] &= ~need[u];
+        }
+        if (AW == 1 && __any(any_need)) {
           int32_t seen[U][VEC];
 #pragma unroll
           for (int u = 0; u < U; ++u) {
@@ -689,7 +697,7 @@ find_long_rows_kernel(const int64_t* __restrict__ rowptr, int64_t M,
   }
 }
 
-template <int VEC, int LPR, int RED, int U, int MODE = M_PLAIN>
+template <int VEC, int LPR, int RED, int U, int MODE = M_PLAIN, int AW = 1, bool HOT = false>
 __global__ void __launch_bounds__(kThreads)
 spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col,
                   const float* __restrict__ val, const float* __restrict__ mat,
@@ -707,9 +715,9 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
   float acc[VEC];
   int64_t arg[VEC];
   if (MODE == M_MASK) {
-    mask.bytes += k0 * mask.arg_width;
+    mask.bytes += k0 * (AW == 2 ? 2 : 1);
     mask.arg += k0;
-    if (mask.hot_bytes) mask.hot_bytes += k0 * mask.arg_width;
+    if (mask.hot_bytes) mask.hot_bytes += k0 * (AW == 2 ? 2 : 1);
   }
   if ((MODE == M_MASK || MODE == M_CSC) && mask.hot) mask.hot += k0;
   const unsigned kFusedChunkBlocks = static_cast<unsigned>(mask.chunk_blocks);
@@ -723,7 +731,7 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
       const int64_t s = rs + static_cast<int64_t>(c - ent.first_chunk) * kLongChunk;
       const int64_t e = s + kLongChunk < re ? s + kLongChunk : re;
       if ((MODE == M_MASK || MODE == M_CSC) && mask.mat) mask.mrow = mask.mat + ent.row * K + k0;
-      reduce_edge_range<VEC, LPR, RED, U, MODE>(col, val, mat + k0, K, kact, s, e, nnz, lane, acc, arg, mask);
+      reduce_edge_range<VEC, LPR, RED, U, MODE, AW, HOT>(col, val, mat + k0, K, kact, s, e, nnz, lane, acc, arg, mask);
       if (g == 0 && kact) {
         store_vec<VEC>(part_val + static_cast<int64_t>(c) * K + k0, acc);
         if (RED != R_SUM && MODE != M_NOARG) {
@@ -752,7 +760,7 @@ spmm_fused_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict_
   const int64_t e = rowptr[row + 1];
   if (e - s > kLongRow) return;  // on the list: chunk role + combine write it
   if ((MODE == M_MASK || MODE == M_CSC) && mask.mat) mask.mrow = mask.mat + row * K + k0;
-  reduce_edge_range<VEC, LPR, RED, U, MODE>(col, val, mat + k0, K, kact, s, e, nnz, lane, acc, arg, mask);
+  reduce_edge_range<VEC, LPR, RED, U, MODE, AW, HOT>(col, val, mat + k0, K, kact, s, e, nnz, lane, acc, arg, mask);
   if (g == 0 && kact) {
     const int64_t deg = e - s;
     if (RED == R_SUM) {
@@ -1071,9 +1079,27 @@ int launch_fused_masked(const int64_t* colptr, const int64_t* row_csc, const flo
   mask.mix_xcds = g_variant != 27;
   hipLaunchKernelGGL(find_long_rows_kernel, dim3(static_cast<unsigned>(psa::ceil_div(N, kThreads * kFindIters))),
                      block, 0, s, colptr, N, w.ctr, w.list);
-  hipLaunchKernelGGL((spmm_fused_kernel<4, LPR, R_SUM, U, MODE>), grid, block, 0, s, colptr, row_csc,
-                     value, grad, out, static_cast<int64_t*>(nullptr), N, K, nnz, 0, w.ctr, w.list,
-                     w.part_val, w.part_arg, mask);
+  // instantiations by what the pass needs: the one-byte form keeps its second phase (exact test
+  // against arg_out), the two-byte form and the hub-row copies have none of it — 76 VGPRs instead
+  // of 96 where they are not needed, one more wave per SIMD
+  const bool hot = mask.hot != nullptr;
+#define PSA_MASKED(AW, HOT)                                                                                           \
+  hipLaunchKernelGGL((spmm_fused_kernel<4, LPR, R_SUM, U, MODE, AW, HOT>), grid, block, 0, s, colptr, row_csc, value, \
+                     grad, out, static_cast<int64_t*>(nullptr), N, K, nnz, 0, w.ctr, w.list, w.part_val, w.part_arg, mask)
+  if constexpr (MODE == M_MASK) {
+    if (mask.arg_width == 2) {
+      if (hot) PSA_MASKED(2, true);
+      else PSA_MASKED(2, false);
+    } else {
+      PSA_REQUIRE(!hot, "hub-row copies go with the two-byte row-local form");
+      if (mask.arg != nullptr) PSA_MASKED(1, false);
+      else PSA_MASKED(0, false);
+    }
+  } else {
+    if (hot) PSA_MASKED(1, true);
+    else PSA_MASKED(1, false);
+  }
+#undef PSA_MASKED
   hipLaunchKernelGGL((spmm_long_combine_kernel<R_SUM>), dim3(kLongBlocks), dim3(psa::kLongThreads), 0, s,
                      colptr, K, 0, w.ctr, w.list, w.part_val, w.part_arg, out,
                      static_cast<int64_t*>(nullptr), static_cast<uint8_t*>(nullptr), 1);
