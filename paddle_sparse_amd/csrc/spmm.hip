@@ -92,6 +92,10 @@ using psa::push_long_row;
 enum { M_PLAIN = 0, M_MASK = 1, M_CSC = 2, M_NOARG = 3 };
 
 constexpr int kFusedChunkBlocksDefault = 768;
+// ... and of the CSC-view backward kernels (more registers, fewer resident workgroups): R-MAT 21, both
+// gradients, 256 / 384 / 512 / 768 / 1024 workgroups: sum 2.63 / 2.21 / 2.31 / 2.46 / 2.51 ms, max 3.14 / 2.94 /
+// 3.13 / 3.25 / 3.27 ms; no effect on a uniform graph (profiles/r02_rmat_backward.txt)
+constexpr int kMaskedChunkBlocks = 384;
 using psa::arg_local;
 using psa::kByteExact;
 using psa::kWordExact;
@@ -1071,12 +1075,13 @@ template <int LPR, int U, int MODE>
 int launch_fused_masked(const int64_t* colptr, const int64_t* row_csc, const float* value,
                         const float* grad, OutView out, int64_t N, int64_t K, int64_t nnz,
                         const MaskArgs& mask_in, const LongScratch& w, hipStream_t s) {
-  const int kFusedChunkBlocks = kFusedChunkBlocksDefault;
+  const int kFusedChunkBlocks = g_variant == 20 ? 512 : g_variant == 21 ? 1024 : g_variant == 22 ? 1536 : g_variant == 23 ? 2048 : g_variant == 24 ? 256 : g_variant == 29 ? 768 : kMaskedChunkBlocks;
   const int64_t gx = psa::ceil_div(psa::ceil_div(N, kWaves), 8) * 8 + kFusedChunkBlocks;  // whole groups of 8 row blocks
   PSA_REQUIRE(gx <= 0x7fffffff, "N too large for one launch");
   const dim3 block(kThreads), grid(static_cast<unsigned>(gx));
   MaskArgs mask = mask_in;
   mask.mix_xcds = g_variant != 27;
+  mask.chunk_blocks = kFusedChunkBlocks;
   hipLaunchKernelGGL(find_long_rows_kernel, dim3(static_cast<unsigned>(psa::ceil_div(N, kThreads * kFindIters))),
                      block, 0, s, colptr, N, w.ctr, w.list);
   // instantiations by what the pass needs: the one-byte form keeps its second phase (exact test
