@@ -299,8 +299,9 @@ int psa_spmm_minmax_bw(const int64_t* col, const float* value, const float* mat,
  * arg_bytes.  Ids in [M, M + num_hot) in row_csc then name row id - M of the
  * copies (the hub rows of a power-law graph, as hot_rows of psa_spmm_coo;
  * R-MAT scale 21 as generated: the pass runs 1.9 ms faster with the hubs'
- * rows relabelled away from their crowded addresses).  Needs an exact
- * arg_bytes (arg_out NULL). */
+ * rows relabelled away from their crowded addresses).  Needs the two-byte
+ * arg_bytes (arg_width 2, arg_out NULL): a matrix whose rows all fit the
+ * one-byte form has no hub rows to speak of. */
 int psa_csc_edge_tags(const int64_t* rowptr, const int64_t* row_csc,
                       const int64_t* csr2csc, int64_t nnz, void* tag,
                       int width, psa_stream_t stream);

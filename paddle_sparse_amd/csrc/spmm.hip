@@ -1275,9 +1275,9 @@ int psa_spmm_minmax_bw_csc(const int64_t* rowptr, const int64_t* colptr,
   PSA_REQUIRE(arg_width == 1 || arg_width == 2, "arg_width must be 1 or 2");
   PSA_REQUIRE(arg_bytes == nullptr || psa::aligned(arg_bytes, 4 * arg_width), "arg_bytes alignment");
   PSA_REQUIRE(num_hot >= 0 && (num_hot == 0 || (hot_grad != nullptr && hot_bytes != nullptr)), "hot rows are NULL");
-  PSA_REQUIRE(num_hot == 0 || (arg_bytes != nullptr && arg_out == nullptr && psa::aligned(hot_grad, 16) &&
-                               psa::aligned(hot_bytes, 4 * arg_width)),
-              "hot rows go with an exact arg_bytes (no arg_out) and 16-byte aligned copies");
+  PSA_REQUIRE(num_hot == 0 || (arg_bytes != nullptr && arg_out == nullptr && arg_width == 2 && psa::aligned(hot_grad, 16) &&
+                               psa::aligned(hot_bytes, 8)),
+              "hot rows go with the two-byte arg_bytes (no arg_out) and 16-byte aligned copies");
   PSA_REQUIRE(grad_value == nullptr || mat != nullptr || nnz == 0, "grad_value needs mat");
   PSA_REQUIRE(max_long_chunks(nnz) < (1ll << 32), "too many chunks");
   if (workspace == nullptr || workspace_bytes < psa_spmm_minmax_bw_csc_workspace_bytes(M, K, nnz)) {

@@ -152,7 +152,8 @@ class _SpMM(torch.autograd.Function):
                 width = arg_bytes.element_size() if arg_bytes is not None else 1
                 # hub rows of a power-law matrix: the pass reads their rows of grad_out and of
                 # arg_bytes from compact copies (the CSC view's own hot "columns")
-                plan = st._csc_view()._hot_columns() if (arg is None and arg_bytes is not None) else None
+                # (with the two-byte form only: a matrix whose rows all fit the one-byte form has no hub rows to speak of)
+                plan = st._csc_view()._hot_columns() if (arg is None and arg_bytes is not None and width == 2) else None
                 grad_value, grad_mat = ops.spmm_minmax_bw_csc(
                     st.rowptr(), st.colptr(), st._row_in_csc_order() if plan is None else plan[1], csr2csc,
                     st._csc_edge_tags(width), value, mat, grad_out, arg, want_value=need_value,

@@ -848,8 +848,8 @@ def spmm_minmax_bw_csc(rowptr, colptr, row_csc, csr2csc, tag, value, mat, grad, 
     hot_grad = hot_bytes = None
     num_hot = 0
     if hot_ids is not None and hot_ids.numel():
-        if arg_bytes is None or arg_out is not None:
-            raise ValueError("hot_ids need an exact arg_bytes and no arg_out")
+        if arg_bytes is None or arg_out is not None or width != 2:
+            raise ValueError("hot_ids need an exact arg_bytes in the two-byte form and no arg_out")
         hot_ids = _index(hot_ids, "hot_ids")
         num_hot = hot_ids.numel()
         hot_grad, hot_bytes = _gather_rows_raw(grad, hot_ids), _gather_rows_raw(arg_bytes, hot_ids)
