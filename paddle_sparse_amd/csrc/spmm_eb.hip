@@ -499,18 +499,21 @@ __global__ void __launch_bounds__(kThreads) spmm_eb_combine_kernel(EbArgs a) {
         arg[t] = (RED == R_SUM || !TRACK || !on) ? 0 : a.part_arg[p_tail + 64 * t];
       }
       const int64_t p_head = 2 * (rg + 1) * a.K + kb;  // + 2 K per further range
-      for (int64_t c = 0; c < pieces; c += 8) {
-        float x[2][8];
+      // kFold partials per K position requested per step and folded in range order: a hub row of a
+      // power-law matrix spans thousands of ranges (760 k entries: 2 970), and this loop is its critical path
+      constexpr int kFold = 32;
+      for (int64_t c = 0; c < pieces; c += kFold) {
+        float x[2][kFold];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i)
+          for (int i = 0; i < kFold; ++i)
             x[t][i] = (c + i < pieces && (t == 0 || two)) ? a.part_val[p_head + 64 * t + (c + i) * 2 * a.K] : 0.f;
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
+          for (int i = 0; i < kFold; ++i) {
             if (c + i >= pieces || (t == 1 && !two)) break;
             if (RED == R_SUM) {
               acc[t] += x[t][i];
