@@ -147,6 +147,89 @@ int main() {
     if (!(status[1] & 1)) return 14;
   }
 
+  // the one-launch form (scalar fp32 values): first column of the values above
+  {
+    std::vector<float> sval = {1, 2, 3, 4, 5, 6};
+    float* d_sval = to_device(sval);
+    int64_t *d_index, *d_status;
+    float* d_sv;
+    HIP_OK(hipMalloc(&d_index, 8 * 2 * cn));
+    HIP_OK(hipMalloc(&d_sv, 4 * cn));
+    HIP_OK(hipMalloc(&d_status, 16));
+    if (cn > psa_coalesce_small_max_fused()) return 15;
+    PSA_OK_(psa_coalesce_small_fused(d_crow, d_ccol, d_sval, PSA_F32, cn, cm, cN, PSA_SUM, d_index, d_sv, d_status, stream));
+    int64_t status[2];
+    std::vector<int64_t> index(8);
+    std::vector<float> sv(4);
+    HIP_OK(hipMemcpyAsync(status, d_status, 16, hipMemcpyDeviceToHost, stream));
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipMemcpy(index.data(), d_index, 8 * 8, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(sv.data(), d_sv, 4 * 4, hipMemcpyDeviceToHost));
+    const float want_s[] = {6, 7, 3, 5};  // (0,1): 2 + 4, (1,0): 1 + 6, (1,1): 3, (2,0): 5
+    if (status[0] != 4 || status[1] != 2) return 16;
+    for (int i = 0; i < 4; ++i)
+      if (index[i] != want_r[i] || index[4 + i] != want_c[i] || sv[i] != want_s[i]) return std::printf("fused entry %d wrong\n", i), 17;
+  }
+
+  // spmm_max forward leaving the two-byte row-local arg_out, then both gradients in one pass over
+  // the CSC view (README.md:293-305 matrix; K = 4 so that the 16-byte kernels apply)
+  {
+    const int64_t K4 = 4;
+    std::vector<float> B4 = {1, 4, 0, 0, 2, 5, 0, 0, 3, 6, 0, 0};  // [3, 4]: the README's B padded with zeros
+    std::vector<float> G4(M * K4, 1.0f);
+    float *d_B4 = to_device(B4), *d_G4 = to_device(G4), *d_out4, *d_gv_csc, *d_gm;
+    int64_t *d_colptr, *d_perm2, *d_rowcsc, *d_keys2, *d_sorted2;
+    uint16_t *d_words, *d_tags;
+    HIP_OK(hipMalloc(&d_out4, 4 * M * K4));
+    HIP_OK(hipMalloc(&d_words, 2 * M * K4));
+    HIP_OK(hipMalloc(&d_tags, 2 * nnz));
+    HIP_OK(hipMalloc(&d_gv_csc, 4 * nnz));
+    HIP_OK(hipMalloc(&d_gm, 4 * N * K4));
+    HIP_OK(hipMalloc(&d_colptr, 8 * (N + 1)));
+    HIP_OK(hipMalloc(&d_perm2, 8 * nnz));
+    HIP_OK(hipMalloc(&d_rowcsc, 8 * nnz));
+    HIP_OK(hipMalloc(&d_keys2, 8 * nnz));
+    HIP_OK(hipMalloc(&d_sorted2, 8 * nnz));
+    const size_t fw_b = psa_spmm_workspace_bytes(PSA_MAX, K4, nnz);
+    void* fw_ws = nullptr;
+    if (fw_b) HIP_OK(hipMalloc(&fw_ws, fw_b));
+    PSA_OK_(psa_spmm_coo(PSA_MAX, d_rowptr, d_row, d_col, d_val, d_B4, nullptr, 0, M, N, K4, nnz, d_out4, 0, nullptr, d_words, 2,
+                         PSA_SPMM_AUTO, fw_ws, fw_b, stream));
+    // CSC view: stable sort of col (csr2csc), row[csr2csc], colptr
+    void* s_ws;
+    const size_t s_b = psa_index_sort_workspace_bytes(nnz, N);
+    HIP_OK(hipMalloc(&s_ws, s_b));
+    PSA_OK_(psa_index_sort(d_col, nnz, N, d_sorted2, d_perm2, s_ws, s_b, stream));
+    PSA_OK_(psa_gather_rows(d_row, d_perm2, nnz, 8, d_rowcsc, stream));
+    PSA_OK_(psa_ind2ptr(d_sorted2, nnz, N, d_colptr, stream));
+    PSA_OK_(psa_csc_edge_tags(d_rowptr, d_rowcsc, d_perm2, nnz, d_tags, 2, stream));
+    const size_t bw_b = psa_spmm_minmax_bw_csc_workspace_bytes(M, K4, nnz);
+    void* bw_ws;
+    HIP_OK(hipMalloc(&bw_ws, bw_b));
+    PSA_OK_(psa_spmm_minmax_bw_csc(d_rowptr, d_colptr, d_rowcsc, d_perm2, d_tags, d_val, d_B4, d_G4, nullptr, d_words, 2, nullptr,
+                                   nullptr, 0, M, N, K4, nnz, d_gv_csc, d_gm, bw_ws, bw_b, stream));
+    std::vector<float> out4(M * K4), gm(N * K4), gv(nnz);
+    std::vector<int64_t> perm2(nnz);
+    HIP_OK(hipStreamSynchronize(stream));
+    HIP_OK(hipMemcpy(out4.data(), d_out4, 4 * M * K4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(gm.data(), d_gm, 4 * N * K4, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(gv.data(), d_gv_csc, 4 * nnz, hipMemcpyDeviceToHost));
+    HIP_OK(hipMemcpy(perm2.data(), d_perm2, 8 * nnz, hipMemcpyDeviceToHost));
+    // A = [[1, 0, 2], [0, 4, 0], [1, 3, 0]], entries e0..e4 in CSR order: max over each row of value * B[col]
+    const float want_out4[] = {6, 12, 0, 0, 8, 20, 0, 0, 6, 15, 0, 0};
+    for (int i = 0; i < M * K4; ++i)
+      if (out4[i] != want_out4[i]) return std::printf("max out[%d] = %f\n", i, out4[i]), 18;
+    // winners: row 0 -> e1 for k 0, 1 and e0 for the zero columns (ties go to the first entry); row 1 -> e2;
+    // row 2 -> e4 for k 0, 1 and e3 for k 2, 3.  grad_mat[c, k] = sum of the values of the winners in column c
+    const float want_gm[] = {0, 0, 2, 2, 7, 7, 4, 4, 2, 2, 0, 0};
+    for (int i = 0; i < N * K4; ++i)
+      if (gm[i] != want_gm[i]) return std::printf("grad_mat[%d] = %f\n", i, gm[i]), 19;
+    // grad_value[e] = sum over the k it won of B[col[e], k] (grad = 1), read back through csr2csc
+    const float want_gv[] = {0, 9, 7, 0, 7};
+    for (int j = 0; j < nnz; ++j)
+      if (gv[j] != want_gv[perm2[j]]) return std::printf("grad_value of entry %lld = %f\n", (long long)perm2[j], gv[j]), 20;
+  }
+
   // error reporting: a bad enum comes back as a status + message, not a crash
   if (psa_spmm(17, d_rowptr, d_col, d_val, d_B, M, N, K, nnz, d_out, nullptr, nullptr, nullptr, 0, stream) != PSA_ERR_INVALID_ARG)
     return 9;
