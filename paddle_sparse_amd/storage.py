@@ -389,7 +389,8 @@ class SparseStorage(object):
             M = self._sparse_sizes[0]
             empty, tiny, _, longest = ops.csr_row_stats(self.rowptr()) if M > 0 else (0, 0, 0, 0)
             self._max_rowcount = longest
-            self._spmm_algo_memo = "edge_ranges" if 5 * (empty + tiny) > 2 * M else "row_waves"
+            fits = M < (1 << 31) and self._sparse_sizes[1] < (1 << 31) and self._col.numel() < (1 << 31)  # 31-bit ids in the edge-range kernels
+            self._spmm_algo_memo = "edge_ranges" if fits and 5 * (empty + tiny) > 2 * M else "row_waves"
         return self._spmm_algo_memo
 
     def _csc_edge_tags(self, width: int = 1) -> torch.Tensor:
