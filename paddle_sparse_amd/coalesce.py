@@ -104,7 +104,14 @@ def coalesce(index: torch.Tensor, value: Optional[torch.Tensor], m: int, n: int,
     ("add"/"sum", "mean", "min", "max").  Returns (index[2, nnz'], value)."""
     row, col = index[0].contiguous(), index[1].contiguous()
     assert row.dtype == torch.int64 and col.dtype == torch.int64
+    nnz = col.numel()
     if value is not None:
-        assert value.shape[0] == col.numel()
+        assert value.shape[0] == nnz
+    if (0 < nnz <= _CHAIN_BELOW and m > 0 and n > 0 and m * n < (1 << 62)
+            and (value is None or value.dtype in ops._DTYPE_ID) and not ops.needs_grad(value)):
+        # the chain hands back the [2, nnz'] index as one buffer: nothing to split and restack
+        # (config 1 is launch- and host-bound: every microsecond of Python shows)
+        out_index, out_value, _ = ops.coalesce_chain(row, col, value, m, n, op)
+        return out_index, out_value
     row, col, value = _coalesce_sorted_stream(row, col, value, m, n, op)
     return _stack_index(row, col), value

@@ -20,7 +20,14 @@ from . import _lib
 from ._lib import REDUCE_ID, HipCoreError, check
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    """The current HIP stream of the current device as an integer handle (2.9 us through
+    torch.cuda.current_stream(), which builds a Stream object; 0.3 us through the raw getter)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
