@@ -318,6 +318,33 @@ int psa_spmm_minmax_bw_csc(const int64_t* rowptr, const int64_t* colptr,
                            float* grad_mat, void* workspace,
                            size_t workspace_bytes, psa_stream_t stream);
 
+/* Gradient wrt the dense operand of spmm_min / spmm_max for a FIXED adjacency on a
+ * power-law matrix: the edge-range kernels of psa_spmm_coo over the CSC view, with
+ * the term of an entry counted only where the forward's row-local arg_out names it
+ *   grad_mat[c, k] = sum over entries e = (r, c) with arg_bytes[r, k] == tag[e] of
+ *                    weight_csc[e] * grad[r, k]
+ * (two gathers per entry: the row of grad and its row of arg_bytes).  No
+ * grad_value: callers that train the edge values use psa_spmm_minmax_bw_csc.
+ * col_csc: int64[nnz], the column of every CSC-ordered entry (the COO row ids of
+ * the view), or NULL (derived from colptr into the workspace).  row_csc, tag,
+ * arg_bytes / arg_width, hot_grad / hot_bytes / num_hot: as psa_spmm_minmax_bw_csc;
+ * arg_bytes must be exact (one byte: no row above 128 entries; two bytes: none above
+ * 65 536).  weight_csc: f32[nnz] = value[csr2csc] (psa_transpose_weights) or NULL
+ * (weights 1).  Sums run in entry order inside a range and range by range for
+ * columns that cross ranges: deterministic, last bits may differ from
+ * psa_spmm_minmax_bw_csc.  R-MAT scale 21, K = 128: 2.7 -> 2.0 ms.
+ * workspace: psa_spmm_minmax_bw_eb_workspace_bytes(K, nnz) bytes, 16-byte aligned.
+ * PSA_ERR_UNSUPPORTED unless K % 4 == 0 and every id fits 31 bits. */
+size_t psa_spmm_minmax_bw_eb_workspace_bytes(int64_t K, int64_t nnz);
+int psa_spmm_minmax_bw_eb(const int64_t* colptr, const int64_t* col_csc,
+                          const int64_t* row_csc, const void* tag,
+                          const float* weight_csc, const float* grad,
+                          const void* arg_bytes, int arg_width,
+                          const float* hot_grad, const void* hot_bytes,
+                          int64_t num_hot, int64_t M, int64_t N, int64_t K,
+                          int64_t nnz, float* grad_mat, void* workspace,
+                          size_t workspace_bytes, psa_stream_t stream);
+
 /* sum backward with BOTH gradients in one pass over the CSC view (trainable
  * edge values): for column c and each stored entry e = (r, c)
  *   grad_mat[c, :] += value[e] * grad[r, :]      (value NULL: weights 1)

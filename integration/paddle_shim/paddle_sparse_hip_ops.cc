@@ -366,6 +366,30 @@ PD_BUILD_OP(spmm_minmax_bw_csc)
     .Attrs({"want_value: bool"})
     .SetKernelFn(PD_KERNEL(spmm_minmax_bw_csc));
 
+// min/max backward wrt the dense operand for a fixed adjacency on a power-law matrix: edge ranges over the CSC view
+std::vector<paddle::Tensor> spmm_minmax_bw_eb(paddle::Tensor& colptr, const paddle::optional<paddle::Tensor>& col_csc,
+                                              paddle::Tensor& row_csc, paddle::Tensor& tag,
+                                              const paddle::optional<paddle::Tensor>& weight_csc, paddle::Tensor& grad,
+                                              paddle::Tensor& arg_bytes, const paddle::optional<paddle::Tensor>& hot_grad,
+                                              const paddle::optional<paddle::Tensor>& hot_bytes) {
+  CHECK_GPU(grad);
+  const int64_t M = grad.shape()[0], K = grad.shape()[1], N = colptr.numel() - 1, nnz = row_csc.numel();
+  const int width = tag.dtype() == paddle::DataType::INT16 ? 2 : 1;
+  auto gm = paddle::empty({N, K}, grad.dtype(), grad.place());
+  const size_t ws_bytes = psa_spmm_minmax_bw_eb_workspace_bytes(K, nnz);
+  auto ws = scratch(ws_bytes, grad.place());
+  PSA_CALL(psa_spmm_minmax_bw_eb(i64(colptr), i64_or_null(col_csc), i64(row_csc), tag.data(), f32_or_null(weight_csc),
+                                 f32(grad), arg_bytes.data(), width, f32_or_null(hot_grad),
+                                 hot_bytes ? hot_bytes.get().data() : nullptr, hot_grad ? hot_grad.get().shape()[0] : 0, M, N,
+                                 K, nnz, gm.data<float>(), ws.data<uint8_t>(), ws_bytes, stream_of(grad)));
+  return {gm};
+}
+PD_BUILD_OP(spmm_minmax_bw_eb)
+    .Inputs({"colptr", paddle::Optional("col_csc"), "row_csc", "tag", paddle::Optional("weight_csc"), "grad", "arg_bytes",
+             paddle::Optional("hot_grad"), paddle::Optional("hot_bytes")})
+    .Outputs({"grad_mat"})
+    .SetKernelFn(PD_KERNEL(spmm_minmax_bw_eb));
+
 // sum / mean backward, both gradients in one pass over the CSC view (trainable edge values)
 std::vector<paddle::Tensor> spmm_sum_bw_csc(paddle::Tensor& colptr, paddle::Tensor& row_csc, paddle::Tensor& csr2csc,
                                             paddle::Tensor& csc2csr, const paddle::optional<paddle::Tensor>& value,

@@ -58,6 +58,10 @@ SIGNATURES = {
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int64,
                                        c_int64, c_int64, c_int64,
                                        c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "psa_spmm_minmax_bw_eb_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "psa_spmm_minmax_bw_eb": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                      c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p,
+                                      c_size_t, c_void_p]),
     "psa_spmm_sum_bw_csc_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "psa_spmm_sum_bw_csc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int64, c_int64,

@@ -1319,6 +1319,34 @@ int psa_spmm_minmax_bw_csc(const int64_t* rowptr, const int64_t* colptr,
   return launch_fused_masked<64, 8, M_MASK>(colptr, row_csc, value, grad, OutView{grad_mat, K}, N, K, nnz, mask, w, s);
 }
 
+size_t psa_spmm_minmax_bw_eb_workspace_bytes(int64_t K, int64_t nnz) {
+  if (K <= 0 || nnz <= 0 || K % 4 != 0) return 256;
+  return psa::eb_workspace_bytes(false, K, nnz);
+}
+
+int psa_spmm_minmax_bw_eb(const int64_t* colptr, const int64_t* col_csc, const int64_t* row_csc, const void* tag,
+                          const float* weight_csc, const float* grad, const void* arg_bytes, int arg_width,
+                          const float* hot_grad, const void* hot_bytes, int64_t num_hot, int64_t M, int64_t N, int64_t K,
+                          int64_t nnz, float* grad_mat, void* workspace, size_t workspace_bytes, psa_stream_t stream) {
+  PSA_REQUIRE(M >= 0 && N >= 0 && K >= 0 && nnz >= 0, "negative size");
+  PSA_REQUIRE(arg_width == 1 || arg_width == 2, "arg_width must be 1 or 2");
+  if (N == 0 || K == 0) return PSA_OK;
+  PSA_REQUIRE(colptr != nullptr && grad_mat != nullptr, "NULL pointer");
+  if (nnz == 0) {  // no entries: grad_mat = 0
+    return psa::zero_async(grad_mat, sizeof(float) * static_cast<size_t>(N) * K, psa::as_stream(stream));
+  }
+  if (K % 4 != 0 || M >= (1ll << 31) || !psa::aligned(grad, 16) || !psa::aligned(grad_mat, 16) || !psa::eb_supported(N, K, nnz)) {
+    psa::set_error("psa_spmm_minmax_bw_eb: needs K % 4 == 0, 31-bit ids and 16-byte aligned operands (use psa_spmm_minmax_bw_csc)");
+    return PSA_ERR_UNSUPPORTED;
+  }
+  PSA_REQUIRE(row_csc && tag && grad && arg_bytes, "NULL pointer");
+  PSA_REQUIRE(num_hot >= 0 && (num_hot == 0 || (hot_grad != nullptr && hot_bytes != nullptr)), "hot rows are NULL");
+  const psa::EbMask mask{arg_bytes, hot_bytes, tag, arg_width};
+  // the CSC view as a CSR matrix: rows = columns of A (N of them), gathered operand = grad ([M, K])
+  return psa::launch_spmm_eb(R_SUM, 0, colptr, col_csc, row_csc, weight_csc, grad, grad_mat, K, nullptr, nullptr, 1, N, M, K,
+                             nnz, hot_grad, num_hot, workspace, workspace_bytes, false, 0, 0, psa::as_stream(stream), 0, &mask);
+}
+
 size_t psa_spmm_sum_bw_csc_workspace_bytes(int64_t K, int64_t nnz) {
   return long_workspace_bytes(false, K > 0 ? K : 1, nnz > 0 ? nnz : 1);
 }

@@ -78,6 +78,11 @@ struct EbArgs {
   int nt_gather;
   int minmax;
   int dbg;  // A/B hooks: 1 = drop the row stores (timing only), 2 = ordinary instead of non-temporal stores
+  // masked sum (template MW = 1 / 2: grad of the dense operand of spmm_min / max over the CSC view, psa_spmm_minmax_bw_eb):
+  // an edge's term counts for column k only where words[c, k] (c = its gathered row id) equals the edge's tag
+  const uint8_t* words;      // [rows of mat, K] entries of MW bytes: the forward's row-local arg_out
+  const uint8_t* hot_words;  // the same rows as `hot`, compact
+  const uint8_t* tags;       // [nnz] entries of MW bytes, in the order of col / row
 };
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -292,6 +297,25 @@ __device__ __forceinline__ void asm_gather16(f32x4& dst, const char* p) {
 __device__ __forceinline__ void asm_load_word(int& dst, const void* p) {
   asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
 }
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void asm_gather8(u32x2& dst, const uint8_t* p) {
+  asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void asm_gather4(u32x2& dst, const uint8_t* p) {
+  asm volatile("global_load_dword %0, %1, off" : "=v"(dst.x) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void asm_load_ushort(int& dst, const void* p) {
+  asm volatile("global_load_ushort %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void asm_load_ubyte(int& dst, const void* p) {
+  asm volatile("global_load_ubyte %0, %1, off" : "=v"(dst) : "v"(p) : "memory");
+}
+// the same wait with the mask words of the round named as well (rounds of 2 edges)
+template <int N>
+__device__ __forceinline__ void asm_wait_round_masked(f32x4 (&b)[2], u32x2 (&m)[2]) {
+  asm volatile("s_waitcnt vmcnt(%c4)" : "+v"(b[0]), "+v"(b[1]), "+v"(m[0]), "+v"(m[1]) : "i"(N) : "memory");
+}
+
 template <int N, int U>
 __device__ __forceinline__ void asm_wait_round(f32x4 (&b)[U]) {
   static_assert(U == 1 || U == 2 || U == 4, "rounds of 1, 2 or 4 edges");
@@ -300,8 +324,10 @@ __device__ __forceinline__ void asm_wait_round(f32x4 (&b)[U]) {
   else asm volatile("s_waitcnt vmcnt(%c4)" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "i"(N) : "memory");
 }
 
-template <int LPR, int RED, int U, int D, bool TRACK, bool NT, int E>
+template <int LPR, int RED, int U, int D, bool TRACK, bool NT, int E, int MW = 0>
 __global__ void __launch_bounds__(kThreads) spmm_eb_kernel(EbArgs a) {
+  static_assert(MW == 0 || (RED == R_SUM && !TRACK && E == 4 && U == 2), "masked form: fp32 sum, rounds of 2 edges");
+  constexpr int LPE = MW ? 2 : 1;  // gather instructions per edge
   if (blockIdx.x < a.fill_blocks) {  // ---- fill role ----
     if (blockIdx.y == 0) eb_fill_role<E>(a);
     return;
@@ -311,7 +337,7 @@ __global__ void __launch_bounds__(kThreads) spmm_eb_kernel(EbArgs a) {
   constexpr int G = 64 / LPR;
   constexpr int RPS = LPR / U;  // rounds per staged batch of LPR edges
   static_assert(LPR % U == 0 && RPS % D == 0 && D >= 2, "ring positions must repeat every staged batch");
-  static_assert((D - 1) * U < 64, "vmcnt is a 6-bit field");
+  static_assert((D - 1) * U * LPE < 64, "vmcnt is a 6-bit field");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int g = lane / LPR;
@@ -322,6 +348,9 @@ __global__ void __launch_bounds__(kThreads) spmm_eb_kernel(EbArgs a) {
   const char* matk = static_cast<const char*>(a.mat) + (kact ? k0 : 0) * ESZ;  // idle K lanes gather (and drop) column 0
   const char* hotk = static_cast<const char*>(a.hot) + (kact ? k0 : 0) * ESZ;
   const int64_t row_bytes = a.K * ESZ;
+  const uint8_t* wordsk = a.words + (kact ? k0 : 0) * MW;
+  const uint8_t* hot_wordsk = a.hot_words + (kact ? k0 : 0) * MW;
+  const int64_t words_row_bytes = a.K * MW;
   const int64_t rg = ((static_cast<int64_t>(blockIdx.x) - a.fill_blocks) * kWaves + wave) * G + g;
   const int64_t start = rg * a.range_len;
   const bool active = start < a.nnz;
@@ -354,6 +383,7 @@ __global__ void __launch_bounds__(kThreads) spmm_eb_kernel(EbArgs a) {
   // eb_supported; the low words of the int64 entries are read)
   struct Staged {
     int c, r, v;
+    int t = 0;  // the edge's tag (masked form only)
   };
   const bool has_val = a.val != nullptr;
   const void* vsrc = has_val ? static_cast<const void*>(a.val) : static_cast<const void*>(a.col);  // no values: any readable word
@@ -363,9 +393,13 @@ __global__ void __launch_bounds__(kThreads) spmm_eb_kernel(EbArgs a) {
     asm_load_word(s.c, a.col + e);
     asm_load_word(s.r, a.row + e);
     asm_load_word(s.v, static_cast<const char*>(vsrc) + 4 * e);
+    if constexpr (MW == 2) asm_load_ushort(s.t, a.tags + 2 * e);
+    if constexpr (MW == 1) asm_load_ubyte(s.t, a.tags + e);
   };
 
   f32x4 b[D][U];
+  u32x2 mk[D][U];  // masked form: words[c, k0 .. k0 + 3] of the edge's gathered row
+  int tg[D][U];
   float w[D][U];
   int rr[D][U];
   auto issue = [&](auto buf, const Staged& s, int idx0) {  // U loads
@@ -380,11 +414,18 @@ __global__ void __launch_bounds__(kThreads) spmm_eb_kernel(EbArgs a) {
       // ids at or above ncols name a row of the compact hot copy (psa_spmm_coo, hot_rows)
       const bool is_hot = c >= a.ncols;
       asm_gather16<NT>(b[B][u], (is_hot ? hotk : matk) + (is_hot ? c - a.ncols : c) * row_bytes);
+      if constexpr (MW != 0) {
+        tg[B][u] = __builtin_amdgcn_ds_bpermute(sel, s.t);
+        const uint8_t* wp = (is_hot ? hot_wordsk : wordsk) + (is_hot ? c - a.ncols : c) * words_row_bytes;
+        if constexpr (MW == 2) asm_gather8(mk[B][u], wp);
+        else asm_gather4(mk[B][u], wp);
+      }
     }
   };
   auto consume = [&](auto buf, int local0) {
     constexpr int B = decltype(buf)::value;
-    asm_wait_round<(D - 1) * U, U>(b[B]);
+    if constexpr (MW != 0) asm_wait_round_masked<(D - 1) * U * LPE>(b[B], mk[B]);
+    else asm_wait_round<(D - 1) * U, U>(b[B]);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int local = local0 + u;
@@ -402,6 +443,15 @@ __global__ void __launch_bounds__(kThreads) spmm_eb_kernel(EbArgs a) {
         }
         float bf[E];
         eb_unpack<E>(b[B][u], a.half, bf);
+        if constexpr (MW != 0) {  // only where the forward named this edge the winner
+          const uint32_t tag = static_cast<uint32_t>(tg[B][u]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const uint32_t f = MW == 2 ? (((i < 2 ? mk[B][u].x : mk[B][u].y) >> (16 * (i & 1))) & 0xffffu)
+                                       : ((mk[B][u].x >> (8 * i)) & 0xffu);
+            if (f != tag) bf[i] = 0.f;
+          }
+        }
         if (RED == R_SUM) {
 #pragma unroll
           for (int i = 0; i < E; ++i) acc[i] += w[B][u] * bf[i];
@@ -424,6 +474,7 @@ __global__ void __launch_bounds__(kThreads) spmm_eb_kernel(EbArgs a) {
   stage(cur, start);
   stage(nxt, start + LPR);
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(cur.c), "+v"(cur.r), "+v"(cur.v), "+v"(nxt.c), "+v"(nxt.r), "+v"(nxt.v) : : "memory");
+  if constexpr (MW != 0) asm volatile("" : "+v"(cur.t), "+v"(nxt.t));
   static_for<D - 1>([&](auto q) { issue(q, cur, decltype(q)::value * U); });
   for (int64_t sb = start; sb < end; sb += LPR) {
     stage(pre, sb + 2 * LPR);
@@ -438,6 +489,7 @@ __global__ void __launch_bounds__(kThreads) spmm_eb_kernel(EbArgs a) {
         src.c = from_next ? nxt.c : cur.c;
         src.r = from_next ? nxt.r : cur.r;
         src.v = from_next ? nxt.v : cur.v;
+        src.t = from_next ? nxt.t : cur.t;
         issue(std::integral_constant<int, (DD + D - 1) % D>{}, src, (from_next ? qi - RPS : qi) * U);
         consume(d, local0 + (q0 + DD) * U);
       });
@@ -445,6 +497,7 @@ __global__ void __launch_bounds__(kThreads) spmm_eb_kernel(EbArgs a) {
     // `pre` was requested before every gather of this batch, the last counted wait
     // covered it; naming it here keeps the copies below behind that wait
     asm volatile("" : "+v"(pre.c), "+v"(pre.r), "+v"(pre.v));
+    if constexpr (MW != 0) asm volatile("" : "+v"(pre.t));
     cur = nxt;
     nxt = pre;
   }
@@ -499,9 +552,10 @@ __global__ void __launch_bounds__(kThreads) spmm_eb_combine_kernel(EbArgs a) {
         arg[t] = (RED == R_SUM || !TRACK || !on) ? 0 : a.part_arg[p_tail + 64 * t];
       }
       const int64_t p_head = 2 * (rg + 1) * a.K + kb;  // + 2 K per further range
-      // kFold partials per K position requested per step and folded in range order: a hub row of a
-      // power-law matrix spans thousands of ranges (760 k entries: 2 970), and this loop is its critical path
-      constexpr int kFold = 32;
+      // kFold partials per K position requested per step and folded in range order.  (32 per step helps
+      // the one row that spans thousands of ranges — 760 k entries: 2 970 pieces, 2.37 -> 2.29 ms — and costs
+      // every ordinary boundary row 64 predicated loads: R-MAT 21 spmm_max + 0.25 ms.  8 it stays.)
+      constexpr int kFold = 8;
       for (int64_t c = 0; c < pieces; c += kFold) {
         float x[2][kFold];
 #pragma unroll
@@ -630,7 +684,7 @@ int launch_spmm_eb(int red, int mean, const int64_t* rowptr, const int64_t* row,
                    const int64_t* col, const float* val, const void* mat, void* out, int64_t ldo,
                    int64_t* arg_out, uint8_t* arg_bytes, int arg_width, int64_t M, int64_t N, int64_t K,
                    int64_t nnz, const void* hot_rows, int64_t num_hot, void* workspace, size_t workspace_bytes,
-                   bool nt_gather, int range_len_override, int dbg, hipStream_t s, int half) {
+                   bool nt_gather, int range_len_override, int dbg, hipStream_t s, int half, const EbMask* mask) {
   PSA_REQUIRE(num_hot >= 0 && N + num_hot < (1ll << 31), "column ids (with the hot copy) must fit 31 bits");
   PSA_REQUIRE(half >= 0 && half <= 2, "half: 0 fp32, 1 fp16, 2 bf16");
   PSA_REQUIRE(eb_supported(M, K, nnz, half), "shape not served by the edge-balanced kernels");
@@ -679,6 +733,16 @@ int launch_spmm_eb(int red, int mean, const int64_t* rowptr, const int64_t* row,
   a.nt_gather = nt_gather ? 1 : 0;
   a.minmax = minmax ? 1 : 0;
   a.dbg = dbg;
+  a.words = a.hot_words = a.tags = nullptr;
+  const int mw = mask != nullptr ? mask->width : 0;
+  if (mw != 0) {
+    PSA_REQUIRE(!half && red == R_SUM && (mw == 1 || mw == 2), "masked form: fp32 sum, entries of 1 or 2 bytes");
+    PSA_REQUIRE(mask->words != nullptr && mask->tags != nullptr && (num_hot == 0 || mask->hot_words != nullptr), "NULL mask");
+    PSA_REQUIRE(aligned(mask->words, 4 * mw) && (num_hot == 0 || aligned(mask->hot_words, 4 * mw)), "mask alignment");
+    a.words = static_cast<const uint8_t*>(mask->words);
+    a.hot_words = static_cast<const uint8_t*>(num_hot > 0 ? mask->hot_words : mask->words);
+    a.tags = static_cast<const uint8_t*>(mask->tags);
+  }
   const int G = 64 / plan.lpr;
   const int64_t range_blocks = ceil_div(a.num_ranges, static_cast<int64_t>(G) * kWaves);
   const int64_t gx = static_cast<int64_t>(a.fill_blocks) + range_blocks;
@@ -718,7 +782,25 @@ int launch_spmm_eb(int red, int mean, const int64_t* rowptr, const int64_t* row,
     if (nt_gather) PSA_EB_NT(LPR, U, D, true, 4); \
     else PSA_EB_NT(LPR, U, D, false, 4);      \
   } while (0)
-  if (half) {  // two-byte operands: 8 elements per lane, ordinary (cached) gathers
+#define PSA_EB_MASKED(LPR, D, MW)                                                                              \
+  do {                                                                                                        \
+    hipLaunchKernelGGL((spmm_eb_kernel<LPR, R_SUM, 2, D, false, false, 4, MW>), grid, block, 0, s, a);          \
+    if (a.num_ranges > 1) hipLaunchKernelGGL((spmm_eb_combine_kernel<R_SUM, false>), cgrid, block, 0, s, a); \
+  } while (0)
+  if (mw != 0) {  // masked sum: two gathers per edge (the row of mat and its row of words)
+    switch (plan.lpr * 4 + mw) {
+      case 4 * 4 + 1: PSA_EB_MASKED(4, 2, 1); break;
+      case 4 * 4 + 2: PSA_EB_MASKED(4, 2, 2); break;
+      case 8 * 4 + 1: PSA_EB_MASKED(8, 4, 1); break;
+      case 8 * 4 + 2: PSA_EB_MASKED(8, 4, 2); break;
+      case 16 * 4 + 1: PSA_EB_MASKED(16, 4, 1); break;
+      case 16 * 4 + 2: PSA_EB_MASKED(16, 4, 2); break;
+      case 32 * 4 + 1: PSA_EB_MASKED(32, 4, 1); break;
+      case 32 * 4 + 2: PSA_EB_MASKED(32, 4, 2); break;
+      case 64 * 4 + 1: PSA_EB_MASKED(64, 4, 1); break;
+      default: PSA_EB_MASKED(64, 4, 2); break;
+    }
+  } else if (half) {  // two-byte operands: 8 elements per lane, ordinary (cached) gathers
     switch (plan.lpr) {
       case 4: PSA_EB_NT(4, 2, 2, false, 8); break;
       case 8: PSA_EB_NT(8, 2, 4, false, 8); break;
@@ -737,6 +819,7 @@ int launch_spmm_eb(int red, int mean, const int64_t* rowptr, const int64_t* row,
   }
 #undef PSA_EB
 #undef PSA_EB_NT
+#undef PSA_EB_MASKED
   PSA_LAUNCH_CHECK();
   return PSA_OK;
 }

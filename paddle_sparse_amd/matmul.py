@@ -150,6 +150,16 @@ class _SpMM(torch.autograd.Function):
             if need_mat and ops.minmax_bw_csc_supported(grad_out.shape[1]):
                 csr2csc = st.csr2csc()  # first: it leaves colptr and row[csr2csc] behind
                 width = arg_bytes.element_size() if arg_bytes is not None else 1
+                view = st._csc_view()
+                if not need_value and arg is None and arg_bytes is not None and view._spmm_algo() == "edge_ranges":
+                    # fixed adjacency on a power-law matrix: the edge-range kernels over the CSC view, masked by
+                    # the row-local arg_out (two gathers per entry), hub rows from compact copies
+                    plan = view._hot_columns()
+                    w = None if value is None else _csc_weights(st, value, csr2csc, st._row_in_csc_order(), False)
+                    grad_mat = ops.spmm_minmax_bw_eb(st.colptr(), view.row(), st._row_in_csc_order() if plan is None else plan[1],
+                                                     st._csc_edge_tags(width), w, grad_out, arg_bytes,
+                                                     hot_ids=None if plan is None else plan[0])
+                    return None, grad_mat
                 # hub rows of a power-law matrix: the pass reads their rows of grad_out and of
                 # arg_bytes from compact copies (the CSC view's own hot "columns")
                 # (with the two-byte form only: a matrix whose rows all fit the one-byte form has no hub rows to speak of)

@@ -880,6 +880,39 @@ def spmm_minmax_bw_csc(rowptr, colptr, row_csc, csr2csc, tag, value, mat, grad, 
     return gv, gm
 
 
+def spmm_minmax_bw_eb(colptr, col_csc, row_csc, tag, weight_csc, grad, arg_bytes, hot_ids=None) -> torch.Tensor:
+    """grad_mat f32[N, K] of spmm_min / spmm_max for a fixed adjacency, by the edge-range kernels over
+    the CSC view (psa_spmm_minmax_bw_eb): power-law matrices.  col_csc: column of every CSC-ordered
+    entry or None; tag / arg_bytes: uint8 or int16 (exact form); weight_csc: value[csr2csc] or None;
+    hot_ids: rows of grad / arg_bytes that row_csc names as M + position (copies gathered here)."""
+    colptr, row_csc = _index(colptr, "colptr"), _index(row_csc, "row_csc")
+    if col_csc is not None:
+        col_csc = _index(col_csc, "col_csc")
+    grad = _f32(grad, "grad")
+    _gpu(tag, "tag")
+    _gpu(arg_bytes, "arg_bytes")
+    if tag.dtype not in (torch.uint8, torch.int16) or arg_bytes.dtype != tag.dtype or arg_bytes.shape != grad.shape:
+        raise ValueError("tag / arg_bytes must be uint8 or int16, arg_bytes [M, K] like grad")
+    arg_bytes, tag = arg_bytes.contiguous(), tag.contiguous()
+    if weight_csc is not None:
+        weight_csc = _f32(weight_csc, "weight_csc")
+    (M, K), N, nnz = grad.shape, colptr.numel() - 1, row_csc.numel()
+    hot_grad = hot_bytes = None
+    num_hot = 0
+    if hot_ids is not None and hot_ids.numel():
+        hot_ids = _index(hot_ids, "hot_ids")
+        num_hot = hot_ids.numel()
+        hot_grad, hot_bytes = _gather_rows_raw(grad, hot_ids), _gather_rows_raw(arg_bytes, hot_ids)
+    gm = torch.empty((N, K), dtype=torch.float32, device=grad.device)
+    lib = _lib.load()
+    ws = _workspace(lib.psa_spmm_minmax_bw_eb_workspace_bytes(K, nnz), grad.device)
+    with _on(grad.device):
+        check(lib.psa_spmm_minmax_bw_eb(_ptr(colptr), _ptr(col_csc), _ptr(row_csc), _ptr(tag), _ptr(weight_csc), _ptr(grad),
+                                        _ptr(arg_bytes), tag.element_size(), _ptr(hot_grad), _ptr(hot_bytes), num_hot,
+                                        M, N, K, nnz, _ptr(gm), _ptr(ws), ws.numel(), _stream()))
+    return gm
+
+
 def spmm_sum_bw_csc(colptr, row_csc, csr2csc, value, mat, grad, want_value: bool = True,
                     csc2csr: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
                     hot_ids: Optional[torch.Tensor] = None):

@@ -519,6 +519,52 @@ def test_grad_mat_over_a_power_law_csc_view(reduce):
     assert np.all(np.abs(Bt.grad.cpu().numpy() - want) <= 1e-5 * scale + 1e-30)
 
 
+@pytest.mark.parametrize("reduce", ["min", "max"])
+def test_minmax_fixed_adjacency_on_a_power_law_matrix(reduce):
+    """Fixed edge weights, gradient wrt the dense operand only: the surface takes the masked edge-range
+    pass over the CSC view (ops.spmm_minmax_bw_eb) with the hub-row copies; gradient against the oracle."""
+    import paddle_sparse_amd.storage as st_mod
+    from paddle_sparse_amd import SparseTensor, ops
+
+    rng = np.random.default_rng(47)
+    M, N, K = 5000, 4000, 64
+    deg = rng.integers(0, 3, M)
+    deg[rng.integers(0, M, 25)] = 600
+    row = np.repeat(np.arange(M), deg)
+    col = rng.integers(0, N, row.size)
+    hubs = rng.integers(0, N, 30)
+    pick = rng.random(row.size) < 0.6
+    col[pick] = hubs[rng.integers(0, 30, int(pick.sum()))]
+    key = np.unique(row * N + col)
+    row, col = key // N, key % N
+    val = rng.standard_normal(key.size).astype(np.float32)
+    rowptr = oracle.ind2ptr(row, M)
+    B = rng.standard_normal((N, K)).astype(np.float32)
+    G = rng.standard_normal((M, K)).astype(np.float32)
+    a = SparseTensor(row=idx(row), col=idx(col), value=torch.from_numpy(val).cuda(), sparse_sizes=(M, N), is_sorted=True)
+    Bt = torch.from_numpy(B).cuda().requires_grad_(True)
+    taken = []
+    real = ops.spmm_minmax_bw_eb
+
+    def spy(*args, **kw):
+        taken.append(kw.get("hot_ids") is not None)
+        return real(*args, **kw)
+
+    old = st_mod.HOT_COLUMNS
+    st_mod.HOT_COLUMNS, ops.spmm_minmax_bw_eb = 64, spy
+    try:
+        out = a.matmul(Bt, reduce)
+        out.backward(torch.from_numpy(G).cuda())
+    finally:
+        st_mod.HOT_COLUMNS, ops.spmm_minmax_bw_eb = old, real
+    assert taken == [True]
+    ref_out, arg = oracle.spmm(reduce, rowptr, col, val, B)
+    assert np.array_equal(out.detach().cpu().numpy(), ref_out)
+    _, want = oracle.spmm_minmax_bw(col, val, B, G, arg, want_value=False)
+    _, scale = oracle.spmm_minmax_bw(col, np.abs(val), np.abs(B), np.abs(G), arg, want_value=False)
+    assert np.all(np.abs(Bt.grad.cpu().numpy() - want) <= 1e-5 * scale + 1e-30)
+
+
 @pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max"])
 def test_trained_values_on_a_power_law_matrix(reduce):
     """Hub rows and hub columns, gradients wrt the values AND the dense operand: the one-pass

@@ -485,3 +485,48 @@ def test_value_in_csc_order_is_kept_until_either_side_changes():
     t = a.t()
     t.storage.value().add_(1.0)  # the transposed tensor owns what was the memo: written in place
     np.testing.assert_allclose(a.sum(0).cpu().numpy(), colsum(3 * val), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("reduce", ["min", "max"])
+@pytest.mark.parametrize("K", [4, 16, 32, 64, 128, 256])  # the K tiles whose forward leaves the row-local arg_out
+@pytest.mark.parametrize("width", [1, 2])
+@pytest.mark.parametrize("has_value", [True, False])
+def test_minmax_grad_mat_by_edge_ranges_over_the_csc_view(reduce, K, width, has_value):
+    """psa_spmm_minmax_bw_eb: grad wrt the dense operand for a fixed adjacency — the edge-range kernels
+    over the CSC view, masked by the forward's row-local arg_out — against the oracle and the row-wave
+    pass; with and without the view's COO ids, with hub-row copies; two launches give the same bits."""
+    from paddle_sparse_amd import SparseStorage, ops
+
+    M, N = 900, 300
+    long_deg = 100 if width == 1 else 2500  # width 1 is exact up to 128 entries per row
+    row, rowptr, col, val = skewed_csr(M, N, seed=K + width, long_rows=(0, 450, 899), long_deg=long_deg)
+    if not has_value:
+        val = None
+    st = SparseStorage(rowptr=dev(rowptr), col=dev(col), value=dev(val), sparse_sizes=(M, N), is_sorted=True)
+    csr2csc, row_csc = st.csr2csc(), st._row_in_csc_order()
+    B = torch.randn(N, K, device="cuda")
+    G = torch.randn(M, K, device="cuda")
+    _, _, words = ops._spmm(reduce, st.rowptr(), st.col(), st.value(), B, want_arg_bytes=width, want_arg=False)
+    tags = st._csc_edge_tags(width)
+    w = None if val is None else ops.transpose_weights(st.value(), csr2csc, None, None, False)
+    view_row = st._csc_view().row()
+    got = ops.spmm_minmax_bw_eb(st.colptr(), view_row, row_csc, tags, w, G, words)
+    _, ref_arg = oracle.spmm(reduce, rowptr, col, val, B.cpu().numpy())
+    _, ref_m = oracle.spmm_minmax_bw(col, val, B.cpu().numpy(), G.cpu().numpy(), ref_arg, want_value=False)
+    live = ref_arg < col.size
+    rr, kk = np.nonzero(live)
+    ee = ref_arg[rr, kk]
+    scale = np.zeros((N, K), np.float32)
+    wabs = np.ones(col.size, np.float32) if val is None else np.abs(val)
+    np.add.at(scale, (col[ee], kk), wabs[ee] * np.abs(G.cpu().numpy()[rr, kk]))
+    assert np.all(np.abs(got.cpu().numpy() - ref_m) <= 1e-5 * scale + 1e-30)
+    none, waves = ops.spmm_minmax_bw_csc(st.rowptr(), st.colptr(), row_csc, csr2csc, tags, st.value(), B, G, None,
+                                         want_value=False, arg_bytes=words)
+    assert none is None and np.all(np.abs(got.cpu().numpy() - waves.cpu().numpy()) <= 2e-5 * scale + 1e-30)
+    assert torch.equal(got, ops.spmm_minmax_bw_eb(st.colptr(), view_row, row_csc, tags, w, G, words))
+    assert torch.equal(got, ops.spmm_minmax_bw_eb(st.colptr(), None, row_csc, tags, w, G, words))  # ids derived from colptr
+    hot = torch.tensor([899, 0, 17, 450, 3, 444], device="cuda")
+    slot = torch.full((M,), -1, dtype=torch.int64, device="cuda")
+    slot[hot] = torch.arange(hot.numel(), device="cuda")
+    redirected = torch.where(slot[row_csc] >= 0, M + slot[row_csc], row_csc)
+    assert torch.equal(got, ops.spmm_minmax_bw_eb(st.colptr(), view_row, redirected, tags, w, G, words, hot_ids=hot))
