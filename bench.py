@@ -249,7 +249,18 @@ def power_law(device, F: int, reps: int):
             for reduce in ("sum", "max"):
                 step(reduce)
                 entry[f"spmm_{reduce}_fwd_bwd_trained_values_ms"] = round(event_ms(lambda: step(reduce), max(3, reps // 4)), 4)
-            del t, v, Bt, G
+            del t, v
+            # ... and with a fixed adjacency (gradient wrt the dense operand only)
+            fixed = SparseTensor(row=row, rowptr=rowptr, col=col, value=val, sparse_sizes=(N, N), is_sorted=True, trust_data=True)
+
+            def fixed_step(reduce):
+                Bt.grad = None
+                fixed.matmul(Bt, reduce).backward(G)
+
+            for reduce in ("sum", "max"):
+                fixed_step(reduce)
+                entry[f"spmm_{reduce}_fwd_bwd_fixed_adjacency_ms"] = round(event_ms(lambda: fixed_step(reduce), max(3, reps // 4)), 4)
+            del fixed, Bt, G
         entry["algo_chosen_by_row_stats"] = a.storage._spmm_algo()
         entry["hot_column_copy_rows"] = 0 if a.storage._hot_columns() is None else int(a.storage._hot_columns()[0].numel())
         res["rmat21_relabelled_columns" if relabel else "rmat21_as_generated"] = entry
