@@ -72,6 +72,54 @@ def test_spmm_forward_backward_random_shapes(seed):
         np.testing.assert_allclose(v.grad.cpu().numpy(), gV, rtol=2e-4, atol=2e-4, err_msg=str((M, N, K, reduce)))
 
 
+@pytest.mark.parametrize("seed", range(24 * SCALE))
+def test_spmm_fixed_adjacency_random_shapes(seed):
+    """Fixed edge weights (gradient wrt the dense operand only), fp32 and bf16 operands, with the
+    hub-row plans switched on for small matrices: the per-matrix choices of matmul.py — edge ranges,
+    hub-row copies, the masked edge-range backward, the half-width backward — on whatever shape comes."""
+    import paddle_sparse_amd.storage as st_mod
+    from paddle_sparse_amd import SparseTensor
+
+    rng = np.random.default_rng(3000 + seed)
+    M, N, row, col = random_graph(rng)
+    K = int(rng.choice([4, 8, 16, 32, 64, 72, 128, 136, 256, 264]))
+    reduce = ["sum", "mean", "min", "max"][seed % 4]
+    half = seed % 3 == 0 and reduce in ("sum", "mean")
+    has_value = bool(rng.integers(0, 2))
+    nnz = row.size
+    val = rng.standard_normal(nnz).astype(np.float32) if has_value else None
+    B = rng.standard_normal((N, K)).astype(np.float32)
+    G = rng.standard_normal((M, K)).astype(np.float32)
+    if half:  # the oracle sees what the kernels see: bf16-rounded operands
+        B = torch.from_numpy(B).to(torch.bfloat16).float().numpy()
+        G = torch.from_numpy(G).to(torch.bfloat16).float().numpy()
+    rowptr = oracle.ind2ptr(row, M)
+    dt = torch.bfloat16 if half else torch.float32
+    Bt = torch.from_numpy(B).cuda().to(dt).requires_grad_()
+    a = SparseTensor(row=idx(row), col=idx(col), value=None if val is None else torch.from_numpy(val).cuda(),
+                     sparse_sizes=(M, N), is_sorted=True)
+    old = st_mod.HOT_COLUMNS
+    st_mod.HOT_COLUMNS = 64
+    try:
+        out = a.matmul(Bt, reduce)
+        out.backward(torch.from_numpy(G).cuda().to(dt))
+    finally:
+        st_mod.HOT_COLUMNS = old
+    ref, arg = oracle.spmm(reduce, rowptr, col, val, B)
+    S = oracle.spmm_abs_sum(rowptr, col, val, B)
+    eps = 2.0 ** -8 if half else 0.0
+    assert np.all(np.abs(out.detach().float().cpu().numpy() - ref) <= 1e-5 * S + eps * np.abs(ref) + 1e-30), (M, N, K, reduce)
+    ones = np.ones(nnz, np.float32)
+    if reduce in ("sum", "mean"):
+        gB = oracle.spmm_mat_bw(reduce, row, rowptr, col, ones if val is None else val, G, N)
+        scale = oracle.spmm_mat_bw(reduce, row, rowptr, col, ones if val is None else np.abs(val), np.abs(G), N)
+    else:
+        _, gB = oracle.spmm_minmax_bw(col, val, B, G, arg, want_value=False)
+        _, scale = oracle.spmm_minmax_bw(col, None if val is None else np.abs(val), np.abs(B), np.abs(G), arg, want_value=False)
+    got = Bt.grad.float().cpu().numpy()
+    assert np.all(np.abs(got - gB) <= 1e-5 * scale + eps * np.abs(gB) + 1e-30), (M, N, K, reduce, half)
+
+
 @pytest.mark.parametrize("seed", range(16 * SCALE))
 def test_coalesce_transpose_reduce_random_shapes(seed):
     import paddle_sparse_amd as ps
