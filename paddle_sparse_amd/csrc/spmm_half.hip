@@ -83,16 +83,16 @@ __global__ void __launch_bounds__(kThreads)
 spmm_half_row_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col,
                      const void* __restrict__ val, const uint16_t* __restrict__ mat,
                      uint16_t* __restrict__ out, int64_t* __restrict__ arg_out, int64_t M, int64_t K,
-                     int64_t nnz, int mean) {
+                     int64_t nnz, int mean, int mix_xcds) {
   constexpr int G = 64 / LPR;
   static_assert(64 % (G * U) == 0, "edge batch must divide the wave");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // inside every group of 8 consecutive row blocks the blocks go to the XCDs (round-robin by
+  // (variant 3, A/B) inside every group of 8 consecutive row blocks the blocks go to the XCDs (round-robin by
   // blockIdx) in an order hashed from the group number: on graphs whose row lengths follow the
   // bits of the row id, XCD 0 would otherwise own all the heavy rows (spmm.hip, MaskArgs.mix_xcds)
   int64_t rb = blockIdx.x;
-  rb ^= static_cast<int64_t>((static_cast<uint32_t>(rb >> 3) * 0x9E3779B1u) >> 29);  // the grid holds whole groups of 8
+  if (mix_xcds) rb ^= static_cast<int64_t>((static_cast<uint32_t>(rb >> 3) * 0x9E3779B1u) >> 29);  // the grid holds whole groups of 8
   const int64_t row = rb * kWaves + wave;
   if (row >= M) return;
   const int g = lane / LPR;
@@ -340,7 +340,7 @@ int launch_half(int red, bool track, bool val32, const int64_t* rowptr, const in
   const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(gy)), block(kThreads);
 #define PSA_H(R, TR, V32)                                                                              \
   hipLaunchKernelGGL((spmm_half_row_kernel<T, LPR, R, U, TR, V32>), grid, block, 0, s, rowptr, col, val, mat, out, \
-                     arg_out, M, K, nnz, mean)
+                     arg_out, M, K, nnz, mean, g_half_variant == 3 ? 1 : 0)
 #define PSA_HV(R, TR)        \
   do {                       \
     if (val32) PSA_H(R, TR, true); \
