@@ -213,8 +213,8 @@ int psa_spmm_half_coo(int reduce, int dtype, const int64_t* rowptr,
                       size_t workspace_bytes, psa_stream_t stream);
 
 /* Test/bench hook: 0 = default (one row per wave), 1 = several rows per wave for
- * K <= 128, 2 = one row per wave with 8 gather steps in flight.  Returns the
- * previous value. */
+ * K <= 128, 2 = one row per wave with 8 gather steps in flight, 3 = default
+ * without the XCD mixing of the row blocks.  Returns the previous value. */
 int psa_spmm_half_set_variant(int variant);
 
 /* Row-length statistics of a CSR pointer, for choosing psa_spmm_algo once per

@@ -88,7 +88,7 @@ spmm_half_row_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restri
   static_assert(64 % (G * U) == 0, "edge batch must divide the wave");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // (variant 3, A/B) inside every group of 8 consecutive row blocks the blocks go to the XCDs (round-robin by
+  // (variant 3 switches it off for A/B: no difference on the uniform config-3 graph) inside every group of 8 consecutive row blocks the blocks go to the XCDs (round-robin by
   // blockIdx) in an order hashed from the group number: on graphs whose row lengths follow the
   // bits of the row id, XCD 0 would otherwise own all the heavy rows (spmm.hip, MaskArgs.mix_xcds)
   int64_t rb = blockIdx.x;
@@ -340,7 +340,7 @@ int launch_half(int red, bool track, bool val32, const int64_t* rowptr, const in
   const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(gy)), block(kThreads);
 #define PSA_H(R, TR, V32)                                                                              \
   hipLaunchKernelGGL((spmm_half_row_kernel<T, LPR, R, U, TR, V32>), grid, block, 0, s, rowptr, col, val, mat, out, \
-                     arg_out, M, K, nnz, mean, g_half_variant == 3 ? 1 : 0)
+                     arg_out, M, K, nnz, mean, g_half_variant == 3 ? 0 : 1)
 #define PSA_HV(R, TR)        \
   do {                       \
     if (val32) PSA_H(R, TR, true); \

@@ -16,7 +16,7 @@ B = torch.randn(M, F, device=dev)
 lib = _lib.load()
 for dt in (torch.bfloat16, torch.float16):
     Bh = B.to(dt)
-    for variant in (0, 3, 0, 3, 2, 1):  # 3 = the row kernel with XCD mixing of its row blocks
+    for variant in (0, 3, 0, 3, 2, 1):  # 3 = the row kernel without XCD mixing of its row blocks
         lib.psa_spmm_half_set_variant(variant)
         for red in ("sum", "max"):
             ops._spmm(red, rowptr, col, val, Bh)
