@@ -19,11 +19,12 @@ for nnz in (1_000, 10_000, 16_384, 16_385, 50_000, 100_000, 262_144, 262_145, 1_
     index = torch.stack([torch.randint(0, m, (nnz,), generator=g, device="cuda"),
                          torch.randint(0, n, (nnz,), generator=g, device="cuda")])
     value = torch.randn(nnz, generator=g, device="cuda")
-    for _ in range(3):
+    small = nnz < 10_000_000
+    for _ in range(100 if small else 3):  # steady state (the call reads its count back: it is synchronous)
         out = ps.coalesce(index, value, m, n)
     torch.cuda.synchronize()
     ts = []
-    for _ in range(7 if nnz < 10_000_000 else 3):
+    for _ in range(300 if small else 5):
         t0 = time.perf_counter()
         out = ps.coalesce(index, value, m, n)
         torch.cuda.synchronize()
