@@ -12,6 +12,7 @@ CPU tensors are rejected: this build has no CPU kernels and never falls back.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -164,7 +165,7 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
     minmax = rid in (_lib.MIN, _lib.MAX)
     lib = _lib.load()
     ws_bytes = lib.psa_spmm_workspace_bytes(rid, K, nnz)  # long-row scratch (0 if no row can be long)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=mat.device) if ws_bytes else None
+    ws = _workspace(ws_bytes, mat.device) if ws_bytes else None
     # the kernels that write the byte form themselves: K <= 64 (multirow) and the
     # fused-roles kernel (64 < K <= 256, taken when there is a workspace); behind
     # the others the bytes are derived from arg_out, which must then exist
@@ -281,9 +282,15 @@ _DTYPE_ID = {
 }
 
 
+_POISON_WORKSPACE = os.environ.get("PSA_POISON_WORKSPACE") == "1"  # test hook: scratch starts as 0xff, not as whatever it held
+
+
 def _workspace(nbytes: int, device) -> torch.Tensor:
     # torch's caching allocator hands back >= 512-byte aligned blocks
-    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+    ws = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+    if _POISON_WORKSPACE:
+        ws.fill_(255)
+    return ws
 
 
 class SortScratch:
@@ -759,7 +766,7 @@ def spmm_value_bw(row, rowptr, col, mat, grad, reduce: str = "sum") -> torch.Ten
     out = torch.empty(nnz, dtype=torch.float32, device=mat.device)
     lib = _lib.load()
     ws_bytes = lib.psa_spmm_value_bw_workspace_bytes(nnz)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=mat.device) if ws_bytes else None
+    ws = _workspace(ws_bytes, mat.device) if ws_bytes else None
     with _on(mat.device):
         check(lib.psa_spmm_value_bw(REDUCE_ID[reduce], _ptr(rowptr), _ptr(col), _ptr(mat),
                                     _ptr(grad), M, K, nnz, _ptr(out), _ptr(ws), ws_bytes, _stream()))
