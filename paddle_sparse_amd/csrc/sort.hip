@@ -710,6 +710,7 @@ os_pass_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict_
 // either way and finishes sooner with less work per workgroup.
 constexpr int64_t kOsSmallBelow = int64_t{1} << 20;  // the A/B shapes (variants 8-11) apply below this
 constexpr int64_t kOsMidBelow = int64_t{1} << 19;    // production: 1024 x 4 below, 512 x 16 from here
+constexpr int64_t kOsHugeFrom = int64_t{1} << 25;    // ... and 1024 x 16 from here
 constexpr int kOsSmallTile = 2048;  // smallest tile any configuration uses (sizes the status words)
 
 size_t os_status_bytes(int64_t n);
@@ -1074,12 +1075,16 @@ static int sort_impl(const char* who, const int64_t* keys, const uint32_t* pay_i
   // (0: 512 threads x 16 keys, two blocks per CU; 5: 1024 x 8, one block);
   // 1-4, 7: the three-launch-per-pass family, kept for A/B.
   PSA_REQUIRE(!prepared || variant == 0, "prepared histograms need the single-sweep passes");
-  if (variant == 0 || variant == 5 || (variant >= 8 && variant <= 11)) {
+  if (variant == 0 || variant == 5 || variant == 6 || (variant >= 8 && variant <= 11)) {
     char* os = ws + 2 * p.keys_bytes + 2 * p.idx_bytes + p.counts_bytes;
     // tile shape: 0 production rule, 5 / 8-11 forced for A/B (tools/sort_tiles.py)
     int os_threads = 512, os_items = 16;
     if (variant == 5) os_threads = 1024, os_items = 8;
+    if (variant == 6) os_threads = 1024, os_items = 16;  // A/B: 16 384-key tiles, one workgroup per CU
     if (variant == 0 && n < kOsMidBelow) os_threads = 1024, os_items = 4;  // profiles/r02_sort_tiles.txt
+    // very large inputs: 16 384-key tiles (one workgroup per CU) — 64-key store runs per digit; 100 M 48-bit keys
+    // 3.75 -> 3.44 ms, no gain at 20 M (profiles/r02_sort_tiles.txt)
+    if (variant == 0 && n >= kOsHugeFrom) os_threads = 1024, os_items = 16;
     if (n < kOsSmallBelow) {
       if (variant == 8) os_threads = 512, os_items = 4;
       if (variant == 9) os_threads = 512, os_items = 8;
@@ -1115,6 +1120,7 @@ static int sort_impl(const char* who, const int64_t* keys, const uint32_t* pay_i
   do {                                                                  \
     if (os_threads == 512 && os_items == 16) PSA_OS1(P0, L, 512, 16);   \
     else if (os_threads == 1024 && os_items == 8) PSA_OS1(P0, L, 1024, 8); \
+    else if (os_threads == 1024 && os_items == 16) PSA_OS1(P0, L, 1024, 16); \
     else if (os_threads == 512 && os_items == 4) PSA_OS1(P0, L, 512, 4);  \
     else if (os_threads == 512 && os_items == 8) PSA_OS1(P0, L, 512, 8);  \
     else if (os_threads == 256 && os_items == 8) PSA_OS1(P0, L, 256, 8);  \
