@@ -274,3 +274,21 @@ def test_count_read_brings_back_the_sorts_lookback_diagnostic():
     scratch.ws.fill_(255)
     with pytest.raises(HipCoreError, match="gave up"):
         ops.unique_sorted(out, 3000, after=scratch)
+
+
+@pytest.mark.parametrize("n,bits", [((1 << 25) + 5, 44), (40_000_003, 17)])
+def test_huge_inputs_take_the_16384_key_tiles(n, bits):
+    """From 2^25 keys the single-sweep passes run with 1024 x 16 tiles (one workgroup per CU): the
+    stable permutation against torch's stable sort, keys and 4-byte payloads; a ragged last tile."""
+    from paddle_sparse_amd import ops
+
+    g = torch.Generator(device="cuda").manual_seed(n % 1000)
+    keys = torch.randint(0, 1 << bits, (n,), generator=g, device="cuda")
+    out, perm, scratch = ops.index_sort(keys, 1 << bits, with_sorted_inputs=True, keep_scratch=True)
+    ref = torch.sort(keys, stable=True)
+    assert torch.equal(out, ref.values) and torch.equal(perm, ref.indices)
+    assert ops.unique_sorted(out, 1 << 20, want_ptr=False, want_rowcol=False, after=scratch)[0] == int(torch.unique(keys).numel())
+    del ref
+    pay = torch.arange(n, dtype=torch.int32, device="cuda")
+    out2, pay2 = ops.sort_pairs(keys, pay, 1 << bits)
+    assert torch.equal(out2, out) and torch.equal(pay2.long(), perm)
