@@ -396,7 +396,11 @@ int psa_index_sort(const int64_t* keys, int64_t n, int64_t max_value,
 /* Diagnostic (synchronises the stream): 0 if the last psa_index_sort /
  * psa_sort_pairs_u32 that used `workspace` (same n, max_value) finished every
  * inter-workgroup wait normally, 1 if a bounded spin of the look-back gave up
- * (never expected; results are then invalid), -1 if the flag could not be read. */
+ * (never expected; results are then invalid), -1 if the flag could not be read.
+ * A sort never hands back a wrong order unmarked (the reference's argsort cannot,
+ * storage.py:164-169): once a wait gave up, the last pass stores -1 over its share
+ * of perm_out / sorted_out instead of positions.  Callers with no host read behind
+ * the sort (the SparseStorage constructor, csr2csc) call this and raise. */
 int psa_index_sort_status(const void* workspace, int64_t n, int64_t max_value,
                           psa_stream_t stream);
 
@@ -518,6 +522,12 @@ int psa_make_keys_checked(const int64_t* row, const int64_t* col, int64_t n,
  * per pass with 2048-key LDS tile, direct per-lane stores, 4096- / 8192-key
  * tiles).  Returns the previous value.  All variants produce the same bits. */
 int psa_sort_set_variant(int variant);
+
+/* Test hook: polls a look-back wait of the single-sweep passes may spend on a word that is
+ * not ready before it gives up and raises the fault word (production: 2^22; 0 makes every
+ * wait that does not succeed at once give up; negative restores the default).  Returns the
+ * previous value. */
+int64_t psa_sort_set_spin_limit(int64_t limit);
 
 /* keys[i] = a[i] * mul + b[i]  (storage.py:159-162 key = row*N + col,
  * storage.py:430 key = M*col + row).  If unsorted_flag != NULL, *unsorted_flag

@@ -19,6 +19,12 @@
     if ((expr) != PSA_OK) PD_THROW(psa_last_error());   \
   } while (0)
 
+// A sort never hands back a wrong order (the reference's argsort cannot, storage.py:164-169):
+// the look-back diagnostic of the radix passes, one 4-byte host read behind the sort.
+#define PSA_SORT_OK(ws_ptr, n, max_value, stream)                                                  \
+  PD_CHECK(psa_index_sort_status((ws_ptr), (n), (max_value), (stream)) == 0,                       \
+           "index_sort: an inter-workgroup wait of a radix pass gave up; the order is invalid")
+
 #define CHECK_GPU(x) PD_CHECK((x).is_gpu(), #x " must be a GPU tensor (HIP build has no CPU path)")
 #define CHECK_I64(x) PD_CHECK((x).dtype() == paddle::DataType::INT64, #x " must be int64")
 
@@ -117,6 +123,7 @@ std::vector<paddle::Tensor> index_sort(paddle::Tensor& keys, int64_t max_value) 
   auto ws = paddle::empty({ws_bytes > 0 ? ws_bytes : 1}, paddle::DataType::UINT8, keys.place());
   PSA_CALL(psa_index_sort(i64(keys), n, max_value, sorted.data<int64_t>(), perm.data<int64_t>(),
                           ws.data<uint8_t>(), static_cast<size_t>(ws_bytes), stream_of(keys)));
+  if (n > 0) PSA_SORT_OK(ws.data<uint8_t>(), n, max_value, stream_of(keys));
   return {sorted, perm};
 }
 std::vector<paddle::DataType> index_sort_infer_dtype(const paddle::DataType d) { return {d, d}; }
@@ -502,6 +509,7 @@ std::vector<paddle::Tensor> sort_pairs(paddle::Tensor& keys, paddle::Tensor& pay
   auto ws = scratch(ws_bytes, keys.place());
   PSA_CALL(psa_sort_pairs_u32(i64(keys), payload.data(), n, max_value, sorted.data<int64_t>(), out.data(),
                               ws.data<uint8_t>(), ws_bytes, stream_of(keys)));
+  if (n > 0) PSA_SORT_OK(ws.data<uint8_t>(), n, max_value, stream_of(keys));
   return {sorted, out};
 }
 PD_BUILD_OP(sort_pairs)
@@ -679,6 +687,7 @@ std::vector<paddle::Tensor> sample_adj(paddle::Tensor& rowptr, paddle::Tensor& c
   auto ws = paddle::empty({wsb > 0 ? wsb : 1}, paddle::DataType::UINT8, place);
   PSA_CALL(psa_index_sort(i64(keys), E, max_key, sorted.data<int64_t>(), perm.data<int64_t>(), ws.data<uint8_t>(),
                           static_cast<size_t>(wsb), s));
+  if (E > 0) PSA_SORT_OK(ws.data<uint8_t>(), E, max_key, s);
   if (E > 0) PSA_CALL(psa_split_keys(i64(sorted), E, n_out, nullptr, out_col.data<int64_t>(), s));
   PSA_CALL(psa_gather_rows(e_raw.data<int64_t>(), i64(perm), E, 8, e_id.data<int64_t>(), s));
   return {out_rowptr, out_col, n_id, e_id};
@@ -707,7 +716,12 @@ std::vector<paddle::Tensor> coalesce(paddle::Tensor& index, const paddle::option
   const int64_t nnz = index.shape()[1];
   void* s = stream_of(index);
   const auto place = index.place();
-  const int64_t* row = i64(index);  // index is contiguous [2, nnz]: row, then col
+  // row, then col: the op reads `index` as one dense [2, nnz] block.  coalesce.py hands over
+  // what `paddle.stack([row, col])` / a user's fresh tensor gives; a strided view (e.g. a
+  // transposed [nnz, 2] array) must be made dense by the Python seam first
+  // (`index = index.contiguous()` in coalesce.py:25 — INTEGRATION.md §2), since the
+  // custom-op Tensor API the reference uses has no stride query.
+  const int64_t* row = i64(index);
   const int64_t* col = i64(index) + nnz;
   if (nnz == 0) return {index, value ? value.get() : paddle::empty({0}, paddle::DataType::FLOAT32, place)};
   const int dtype = value ? dtype_id_of(value.get()) : 0;
@@ -721,6 +735,7 @@ std::vector<paddle::Tensor> coalesce(paddle::Tensor& index, const paddle::option
   const int64_t distinct = reinterpret_cast<const int64_t*>(status_words.data<uint8_t>())[0];
   const int64_t flags = reinterpret_cast<const int64_t*>(status_words.data<uint8_t>())[1];
   PD_CHECK(!(flags & 1), "coalesce: an index lies outside the m x n matrix");  // storage.py:78-91 asserts it
+  PD_CHECK(!(flags & 4), "coalesce: an inter-workgroup wait of the radix sort gave up; the result is invalid");
   auto out_index = paddle::empty({2, distinct}, paddle::DataType::INT64, place);
   auto shape = value ? value.get().shape() : std::vector<int64_t>{0};
   shape[0] = value ? distinct : 0;

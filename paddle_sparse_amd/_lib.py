@@ -78,6 +78,7 @@ SIGNATURES = {
     "psa_merge_sorted": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p]),
     "psa_sort_set_variant": (c_int, [c_int]),
+    "psa_sort_set_spin_limit": (c_int64, [c_int64]),
     "psa_coalesce_small_max": (c_int64, []),
     "psa_coalesce_small_workspace_bytes": (c_size_t, [c_int64]),
     "psa_coalesce_small": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p,

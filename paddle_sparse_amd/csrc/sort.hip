@@ -521,6 +521,7 @@ constexpr int kOsItems = 8;
 constexpr int kOsTile = kOsThreads * kOsItems;  // 8192 keys
 constexpr int kOsMaxPasses = 8;
 constexpr uint32_t kOsSpinLimit = 1u << 22;
+uint32_t g_os_spin_limit = kOsSpinLimit;  // test hook: psa_sort_set_spin_limit
 
 __device__ __forceinline__ uint64_t os_pack(uint32_t flag, uint32_t value) {
   return (static_cast<uint64_t>(flag) << 32) | value;
@@ -552,7 +553,7 @@ os_pass_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict_
                int64_t* __restrict__ perm_out, int64_t n, int shift, int pass,
                const uint32_t* __restrict__ ghist /*this pass: [256] digit counts of the whole input*/,
                uint64_t* __restrict__ status /*[num_tiles][256]*/,
-               uint32_t* __restrict__ ticket, uint32_t* __restrict__ err) {
+               uint32_t* __restrict__ ticket, uint32_t* __restrict__ err, uint32_t spin_limit) {
   constexpr int WAVES = THREADS / 64;
   constexpr int TILE = THREADS * ITEMS;
   __shared__ uint64_t skey[TILE];
@@ -561,6 +562,7 @@ os_pass_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict_
   __shared__ uint32_t wave_tot[4];
   __shared__ uint32_t hist_tot[4];
   __shared__ uint32_t s_tile;
+  __shared__ uint32_t s_fault;
   uint32_t* sidx = reinterpret_cast<uint32_t*>(skey);
 
   const int tid = threadIdx.x;
@@ -569,7 +571,10 @@ os_pass_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict_
   const uint32_t flag_agg = 2u * pass + 1u;   // pass-tagged: words of earlier
   const uint32_t flag_incl = 2u * pass + 2u;  // passes read as "not ready"
 
-  if (tid == 0) s_tile = atomicAdd(ticket, 1u);
+  if (tid == 0) {
+    s_tile = atomicAdd(ticket, 1u);
+    s_fault = 0u;
+  }
   for (int i = tid; i < WAVES * kRadix; i += THREADS) (&wcnt[0][0])[i] = 0;
   __syncthreads();
   const uint32_t tile = s_tile;
@@ -668,8 +673,11 @@ os_pass_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict_
           --t;
           continue;
         }
-        if (++spins > kOsSpinLimit) {  // never expected; keeps a bug from hanging the GPU
-          atomicExch(err, 1u);
+        if (++spins > spin_limit) {  // never expected; keeps a bug from hanging the GPU
+          // the returned value keeps the flag_incl store below behind this atomic: a tile that
+          // takes this tile's (wrong) prefix finds the fault word set
+          excl += atomicExch(err, 1u) & 0u;
+          s_fault = 1u;
           break;
         }
         __builtin_amdgcn_s_sleep(2);
@@ -678,8 +686,19 @@ os_pass_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict_
                          __HIP_MEMORY_SCOPE_AGENT);
     }
     gofs[tid] = static_cast<int32_t>(dbase + excl) - static_cast<int32_t>(dstart);
+    // A sort never returns garbage (storage.py:164-169): once any tile of any pass gave up,
+    // the LAST pass stores -1 over its share of the outputs instead of a wrong order, so a
+    // caller without a host read behind the sort cannot mistake the result for one either.
+    if (LAST && tid == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) s_fault = 1u;
   }
   __syncthreads();
+  if (LAST && s_fault != 0u) {  // block-uniform
+    for (int p = tid; p < tile_n; p += THREADS) {
+      if (perm_out) perm_out[tile_begin + p] = -1;
+      if (keys_out) keys_out[tile_begin + p] = ~0ull;
+    }
+    return;
+  }
   uint32_t dst[ITEMS];
 #pragma unroll
   for (int j = 0; j < ITEMS; ++j) {
@@ -722,6 +741,10 @@ struct SortPlan {
   int num_blocks;
   size_t keys_bytes, idx_bytes, counts_bytes, os_bytes, total_bytes;
 };
+
+bool single_sweep_variant(int variant) {
+  return variant == 0 || variant == 5 || variant == 6 || (variant >= 8 && variant <= 11);
+}
 
 int bits_for(int64_t max_value) {
   // keys lie in [0, max_value); max_value <= 1 -> every key is 0
@@ -1022,6 +1045,12 @@ int psa_sort_set_variant(int variant) {
   return prev;
 }
 
+int64_t psa_sort_set_spin_limit(int64_t limit) {
+  const int64_t prev = g_os_spin_limit;
+  g_os_spin_limit = limit < 0 ? kOsSpinLimit : static_cast<uint32_t>(limit > 0xffffffffll ? 0xffffffffll : limit);
+  return prev;
+}
+
 size_t psa_index_sort_workspace_bytes(int64_t n, int64_t max_value) {
   if (n <= 0) return 0;
   return make_plan(n, max_value).total_bytes;
@@ -1075,7 +1104,7 @@ static int sort_impl(const char* who, const int64_t* keys, const uint32_t* pay_i
   // (0: 512 threads x 16 keys, two blocks per CU; 5: 1024 x 8, one block);
   // 1-4, 7: the three-launch-per-pass family, kept for A/B.
   PSA_REQUIRE(!prepared || variant == 0, "prepared histograms need the single-sweep passes");
-  if (variant == 0 || variant == 5 || variant == 6 || (variant >= 8 && variant <= 11)) {
+  if (single_sweep_variant(variant)) {
     char* os = ws + 2 * p.keys_bytes + 2 * p.idx_bytes + p.counts_bytes;
     // tile shape: 0 production rule, 5 / 8-11 forced for A/B (tools/sort_tiles.py)
     int os_threads = 512, os_items = 16;
@@ -1115,7 +1144,7 @@ static int sort_impl(const char* who, const int64_t* keys, const uint32_t* pay_i
 #define PSA_OS1(P0, L, T, I)                                                                  \
   hipLaunchKernelGGL((os_pass_kernel<P0, L, T, I>), os_grid, os_block, 0, s, kin, iin, kout, \
                      iout, perm_out, n, shift, pass, ghist + pass * kRadix, status,          \
-                     tickets + pass, err)
+                     tickets + pass, err, g_os_spin_limit)
 #define PSA_OS(P0, L)                                                   \
   do {                                                                  \
     if (os_threads == 512 && os_items == 16) PSA_OS1(P0, L, 512, 16);   \
@@ -1216,6 +1245,9 @@ const uint32_t* sort_fault_word(const void* workspace, int64_t n, int64_t max_va
   if (n <= 0 || workspace == nullptr) return nullptr;
   const SortPlan p = make_plan(n, max_value);
   if (p.passes == 0) return nullptr;
+  // only the single-sweep passes zero and use the word; behind an A/B variant (1-4, 7) it is
+  // untouched scratch (0xff under PSA_POISON_WORKSPACE) and those passes cannot fault
+  if (!single_sweep_variant(g_sort_variant & 15)) return nullptr;
   const char* os = static_cast<const char*>(workspace) + 2 * p.keys_bytes + 2 * p.idx_bytes +
                    p.counts_bytes;
   return reinterpret_cast<const uint32_t*>(os + os_status_bytes(n)) + 2 * kOsMaxPasses * kRadix + kOsMaxPasses;

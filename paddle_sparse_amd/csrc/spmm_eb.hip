@@ -205,7 +205,8 @@ __device__ __forceinline__ float red_init() {
 }
 
 // One finished row of a range: out (and arg_out / arg_bytes) straight from the
-// registers of the lane group that reduced it.
+// registers of the lane group that reduced it.  arg < 0: no product of the row beat the
+// init (all NaN, or all -inf under max): the `nnz` sentinel, as the row-wave kernels leave it.
 template <int RED, bool TRACK, int E>
 __device__ __forceinline__ void eb_store_row(const EbArgs& a, int64_t row, int64_t k0, int64_t start,
                                              int seg_first, int cnt, float (&acc)[E], const int (&arg)[E]) {
@@ -221,13 +222,14 @@ __device__ __forceinline__ void eb_store_row(const EbArgs& a, int64_t row, int64
       if (a.arg_out) {
         int64_t g[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) g[i] = start + arg[h + i];
+        for (int i = 0; i < 4; ++i) g[i] = arg[h + i] < 0 ? a.nnz : start + arg[h + i];
         store_arg_nt<4>(a.arg_out + row * a.K + k0 + h, g);
       }
       if (a.arg_bytes) {
         uint32_t f[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) f[i] = arg_local(arg[h + i] - seg_first, cnt, a.arg_width);
+        for (int i = 0; i < 4; ++i)
+          f[i] = arg_local((arg[h + i] < 0 ? a.nnz - start : arg[h + i]) - seg_first, cnt, a.arg_width);
         store_arg_local4(a.arg_bytes, row * a.K + k0 + h, f, a.arg_width);
       }
     }
@@ -252,7 +254,7 @@ __device__ __forceinline__ void eb_store_partial(const EbArgs& a, int64_t slot, 
   }
   if (RED != R_SUM && TRACK) {
 #pragma unroll
-    for (int i = 0; i < E; ++i) a.part_arg[slot * a.K + k0 + i] = start + arg[i];
+    for (int i = 0; i < E; ++i) a.part_arg[slot * a.K + k0 + i] = arg[i] < 0 ? a.nnz : start + arg[i];
   }
 }
 
@@ -376,7 +378,7 @@ __global__ void __launch_bounds__(kThreads) spmm_eb_kernel(EbArgs a) {
 #pragma unroll
   for (int i = 0; i < E; ++i) {
     acc[i] = red_init<RED>();
-    arg[i] = 0;
+    arg[i] = -1;  // nothing has won yet (see eb_store_row)
   }
 
   // staged edges: one per lane of the group (col and row ids fit 31 bits:
@@ -439,7 +441,10 @@ __global__ void __launch_bounds__(kThreads) spmm_eb_kernel(EbArgs a) {
           cur_row = rr[B][u];
           seg_first = local;
 #pragma unroll
-          for (int i = 0; i < E; ++i) acc[i] = red_init<RED>();
+          for (int i = 0; i < E; ++i) {
+            acc[i] = red_init<RED>();
+            if (RED != R_SUM && TRACK) arg[i] = -1;  // not the previous row's winner when nothing beats the init
+          }
         }
         float bf[E];
         eb_unpack<E>(b[B][u], a.half, bf);

@@ -20,6 +20,8 @@ import torch
 from . import _lib
 from ._lib import REDUCE_ID, HipCoreError, check
 
+_check = check  # for functions with a parameter named `check`
+
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
@@ -166,10 +168,13 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
     lib = _lib.load()
     ws_bytes = lib.psa_spmm_workspace_bytes(rid, K, nnz)  # long-row scratch (0 if no row can be long)
     ws = _workspace(ws_bytes, mat.device) if ws_bytes else None
-    # the kernels that write the byte form themselves: K <= 64 (multirow) and the
-    # fused-roles kernel (64 < K <= 256, taken when there is a workspace); behind
-    # the others the bytes are derived from arg_out, which must then exist
-    bytes_in_kernel = K % 4 == 0 and (K <= 64 or (K <= 256 and ws_bytes > 0))
+    # the kernels that write the byte form themselves: K <= 64 (multirow) and, for
+    # 64 < K <= 256, the fused-roles kernel — which spmm_dispatch takes only when a row
+    # CAN be long (nnz > kLongRow = 128; the edge-range kernels write the bytes too, but
+    # fall back to the row path on shapes they do not take).  Behind the others the
+    # bytes are derived from arg_out, which must then exist.  (ws_bytes > 0 is not the
+    # test: it also covers the edge-range scratch, which every nnz > 0 has.)
+    bytes_in_kernel = K % 4 == 0 and (K <= 64 or (K <= 256 and nnz > LONG_ROW))
     if minmax and want_arg_bytes and K % 4 == 0 and K <= 256 and not bytes_in_kernel:
         want_arg = True
     if minmax and want_arg:
@@ -232,6 +237,8 @@ def _spmm_half(reduce: str, rowptr, col, value, mat, want_arg: bool = True, row=
     return out, arg
 
 
+# rows above this many entries leave their wave for the chunk role (psa::kLongRow, csrc/long_rows.h)
+LONG_ROW = 128
 # rows up to this many entries: the one-byte form of arg_out (arg_bytes) needs no arg_out beside it
 ARG_BYTES_EXACT_ROW = 128
 # ... and the two-byte form (want_arg_bytes=2)
@@ -301,14 +308,28 @@ class SortScratch:
         self.ws, self.n, self.max_value = ws, n, max_value
 
 
+def _raise_on_sort_fault(lib, ws: torch.Tensor, n: int, max_value: int, who: str) -> None:
+    """One 4-byte host read behind a sort that no other host read follows: the look-back
+    diagnostic of the single-sweep passes (psa_index_sort_status).  A wait that gave up has
+    made the last pass store -1 instead of an order; here it becomes an exception, as the
+    reference's argsort could never hand back a wrong permutation (storage.py:164-169)."""
+    status = lib.psa_index_sort_status(_ptr(ws), n, max_value, _stream())
+    if status != 0:
+        raise HipCoreError(f"{who}: an inter-workgroup wait of a radix pass gave up "
+                           f"(status {status}); the order is invalid")
+
+
 def index_sort(keys: torch.Tensor, max_value: Optional[int] = None,
-               with_sorted_inputs: bool = False, keep_scratch: bool = False):
+               with_sorted_inputs: bool = False, keep_scratch: bool = False, check: bool = False):
     """paddle_sparse/utils.py:14-23 — returns (sorted | None, perm).
 
     Stable LSD radix sort in HIP; `max_value` (exclusive bound on the keys, the
     reference passes M*N) selects the number of 8-bit passes.  perm is the
     stable sorting permutation, bit-identical to numpy argsort(kind="stable").
     keep_scratch: also return a SortScratch for unique_sorted(after=...).
+    check: read the sort's fault word afterwards (one host read, synchronises) and
+    raise HipCoreError if a look-back wait gave up — for callers whose result no other
+    host read follows (SparseStorage's constructor sort, csr2csc).
     """
     keys = _index(keys, "keys")
     n = keys.numel()
@@ -321,8 +342,10 @@ def index_sort(keys: torch.Tensor, max_value: Optional[int] = None,
     nbytes = lib.psa_index_sort_workspace_bytes(n, max_value)
     ws = _workspace(nbytes, keys.device)
     with _on(keys.device):
-        check(lib.psa_index_sort(_ptr(keys), n, max_value, _ptr(out), _ptr(perm),
-                                 _ptr(ws), ws.numel(), _stream()))
+        _check(lib.psa_index_sort(_ptr(keys), n, max_value, _ptr(out), _ptr(perm),
+                                  _ptr(ws), ws.numel(), _stream()))
+        if check and n > 0:
+            _raise_on_sort_fault(lib, ws, n, max_value, "index_sort")
     if keep_scratch:
         return out, perm, SortScratch(ws, n, max_value)
     return out, perm
@@ -346,10 +369,12 @@ def index_sort_checked(keys: torch.Tensor, max_value: int):
     return out, perm, status
 
 
-def sort_pairs(keys: torch.Tensor, payload: torch.Tensor, max_value: Optional[int] = None, keep_scratch: bool = False):
+def sort_pairs(keys: torch.Tensor, payload: torch.Tensor, max_value: Optional[int] = None, keep_scratch: bool = False,
+               check: bool = False):
     """Stable sort of (key, 4-byte payload) pairs: returns (sorted_keys,
     payload[perm]) without ever forming perm.  payload: 1-D, 4-byte dtype.
-    keep_scratch: also return a SortScratch for unique_sorted(after=...)."""
+    keep_scratch: also return a SortScratch for unique_sorted(after=...).
+    check: as for index_sort."""
     keys = _index(keys, "keys")
     _gpu(payload, "payload")
     if payload.dim() != 1 or payload.element_size() != 4 or payload.numel() != keys.numel():
@@ -364,17 +389,20 @@ def sort_pairs(keys: torch.Tensor, payload: torch.Tensor, max_value: Optional[in
     lib = _lib.load()
     ws = _workspace(lib.psa_index_sort_workspace_bytes(n, max_value), keys.device)
     with _on(keys.device):
-        check(lib.psa_sort_pairs_u32(_ptr(keys), _ptr(payload), n, max_value, _ptr(out_keys),
-                                     _ptr(out_pay), _ptr(ws), ws.numel(), _stream()))
+        _check(lib.psa_sort_pairs_u32(_ptr(keys), _ptr(payload), n, max_value, _ptr(out_keys),
+                                      _ptr(out_pay), _ptr(ws), ws.numel(), _stream()))
+        if check and n > 0:
+            _raise_on_sort_fault(lib, ws, n, max_value, "sort_pairs")
     if keep_scratch:
         return out_keys, out_pay, SortScratch(ws, n, max_value)
     return out_keys, out_pay
 
 
-def sort_pairs_field(keys: torch.Tensor, payload: torch.Tensor, first_bit: int, max_value: int
-                     ) -> Tuple[torch.Tensor, torch.Tensor]:
+def sort_pairs_field(keys: torch.Tensor, payload: torch.Tensor, first_bit: int, max_value: int,
+                     keep_scratch: bool = False):
     """Stable sort of (key, 4-byte payload) pairs by the bit field
-    (key >> first_bit) < max_value only; the low bits ride inside the key."""
+    (key >> first_bit) < max_value only; the low bits ride inside the key.
+    keep_scratch: also return a SortScratch for unique_sorted(after=...)."""
     keys = _index(keys, "keys")
     _gpu(payload, "payload")
     if payload.dim() != 1 or payload.element_size() != 4 or payload.numel() != keys.numel():
@@ -387,6 +415,8 @@ def sort_pairs_field(keys: torch.Tensor, payload: torch.Tensor, first_bit: int, 
     with _on(keys.device):
         check(lib.psa_sort_pairs_u32_field(_ptr(keys), _ptr(payload), n, int(first_bit), max_value,
                                            _ptr(out_keys), _ptr(out_pay), _ptr(ws), ws.numel(), _stream()))
+    if keep_scratch:
+        return out_keys, out_pay, SortScratch(ws, n, max_value)
     return out_keys, out_pay
 
 
@@ -1083,6 +1113,6 @@ def sample_adj(rowptr: torch.Tensor, col: torch.Tensor, idx: torch.Tensor, num_n
                                      _stream()))
     if E == 0:
         return out_rowptr, keys, n_id, e_raw
-    keys, perm = index_sort(keys, max(S * n_out, 1), with_sorted_inputs=True)
+    keys, perm = index_sort(keys, max(S * n_out, 1), with_sorted_inputs=True, check=True)
     _, out_col = split_keys(keys, n_out, want_hi=False)
     return out_rowptr, out_col, n_id, gather_rows(e_raw, perm)

@@ -49,7 +49,7 @@ def index_select(src: SparseTensor, dim: int, idx: torch.Tensor) -> SparseTensor
         colcount, colptr, col, perm = _ragged_take(old_colptr, src.storage.colcount(), idx)
         row = ops.gather_rows(row, perm)
         keys, _ = ops.make_keys(row, col, idx.numel())
-        _, csc2csr = ops.index_sort(keys, src.sparse_size(0) * max(idx.numel(), 1))
+        _, csc2csr = ops.index_sort(keys, src.sparse_size(0) * max(idx.numel(), 1), check=True)
         if value is not None:
             value = ops.gather_rows(ops.gather_rows(value, perm), csc2csr)
         storage = SparseStorage(row=ops.gather_rows(row, csc2csr), col=ops.gather_rows(col, csc2csr),

@@ -54,11 +54,11 @@ def _spspmm_csr(rowA, colA, valueA, rowptrB, colB, valueB, m: int, n: int):
     # rows of A are sorted, so keys are already grouped by C row; the sort
     # orders columns inside rows and brings equal (i, j) together
     if vals is not None and vals.element_size() == 4:
-        keys, vals = ops.sort_pairs(keys, vals, m * n)
+        keys, vals, scratch = ops.sort_pairs(keys, vals, m * n, keep_scratch=True)
         perm = None
     else:
-        keys, perm = ops.index_sort(keys, m * n, with_sorted_inputs=True)
-    count, ptr, row, col = ops.unique_sorted(keys, n)
+        keys, perm, scratch = ops.index_sort(keys, m * n, with_sorted_inputs=True, keep_scratch=True)
+    count, ptr, row, col = ops.unique_sorted(keys, n, after=scratch)  # the sort's fault word rides the count
     if vals is not None:
         if count < total:
             vals = ops.segment_csr(vals, ptr, "sum", perm=perm)
@@ -92,8 +92,8 @@ def _spspmm_by_column(a, b):
     keys, vals = ops.spspmm_expand(colB_of_entry, rowB_csc, valB_csc, colptrA, rowA_csc, valA_csc, offsets,
                                    owner, total, -1, dtype)
     del owner, offsets, counts
-    keys, vals = ops.sort_pairs_field(keys, vals, 32, m)
-    count, ptr, row, col = ops.unique_sorted(keys, 1 << 32)
+    keys, vals, scratch = ops.sort_pairs_field(keys, vals, 32, m, keep_scratch=True)
+    count, ptr, row, col = ops.unique_sorted(keys, 1 << 32, after=scratch)
     if count < total:
         vals = ops.segment_csr(vals, ptr, "sum")
     return row, col, vals

@@ -133,7 +133,7 @@ class SparseStorage(object):
                 # from the sorted keys; a 4-byte scalar value rides the sort.
                 if (value is not None and value.dim() == 1 and value.element_size() == 4
                         and not ops.needs_grad(value)):  # tracked values take the differentiable gather below
-                    keys, self._value = ops.sort_pairs(keys, value, M * N)
+                    keys, self._value = ops.sort_pairs(keys, value, M * N, check=True)
                 else:
                     keys, perm = index_sort(keys, M * N, with_sorted_inputs=True)
                     if value is not None:

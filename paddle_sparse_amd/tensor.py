@@ -266,8 +266,8 @@ class SparseTensor(object):
                                 is_sorted=True, trust_data=True)
         both_r, both_c = torch.cat([row, col]), torch.cat([col, row])
         keys, _ = ops.make_keys(both_r, both_c, N)
-        sorted_keys, perm = ops.index_sort(keys, N * N, with_sorted_inputs=True)
-        _, ptr, new_row, new_col = ops.unique_sorted(sorted_keys, N)
+        sorted_keys, perm, scratch = ops.index_sort(keys, N * N, with_sorted_inputs=True, keep_scratch=True)
+        _, ptr, new_row, new_col = ops.unique_sorted(sorted_keys, N, after=scratch)
         if value is not None:
             # value of entry i (0 <= i < 2n) is value[i mod n]; fold it into perm
             src = torch.where(perm >= n, perm - n, perm)

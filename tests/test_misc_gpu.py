@@ -425,6 +425,44 @@ def test_autograd_minmax_skips_arg_out_when_the_bytes_suffice(reduce):
         ops._spmm = real
 
 
+@pytest.mark.parametrize("reduce", ["min", "max"])
+@pytest.mark.parametrize("K", [68, 128, 256])
+@pytest.mark.parametrize("algo", ["row_waves", "edge_ranges"])
+def test_tiny_matrix_minmax_backward_wrt_the_dense_operand(reduce, K, algo):
+    """at most 128 entries (no row can be long) and 64 < K <= 256 — the fused-roles
+    kernel is not taken, so the byte form of arg_out must come from arg_out itself.  The call used
+    to raise HipCoreError (bytes asked for, neither a kernel that writes them nor an arg_out)."""
+    import sys
+
+    from paddle_sparse_amd import SparseTensor, ops
+
+    mm_mod = sys.modules["paddle_sparse_amd.matmul"]
+    rng = np.random.default_rng(K)
+    M = N = 8
+    deg = np.array([5, 6, 5, 4, 5, 5, 5, 5])  # 40 entries, every row at least 3
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    col = np.concatenate([rng.choice(N, d, replace=False) for d in deg]).astype(np.int64)
+    val = rng.standard_normal(40).astype(np.float32)
+    B = rng.standard_normal((N, K)).astype(np.float32)
+    G = rng.standard_normal((M, K)).astype(np.float32)
+    # the entry point itself: bytes without arg_out
+    res = ops._spmm(reduce, dev(rowptr), dev(col), dev(val), dev(B), want_arg_bytes=1, want_arg=False, algo=algo)
+    ref, ref_arg = oracle.spmm(reduce, rowptr, col, val, B)
+    assert np.array_equal(res[0].cpu().numpy(), ref)
+    assert np.array_equal(res[2].cpu().numpy().astype(np.int64), ref_arg - rowptr[:-1, None])
+    # ... and through autograd with a fixed adjacency
+    A = SparseTensor(rowptr=dev(rowptr), col=dev(col), value=dev(val), sparse_sizes=(M, N), is_sorted=True)
+    A.storage._spmm_algo_memo = algo
+    Bg = dev(B).requires_grad_(True)
+    mm_mod.spmm_sparse(A, Bg, reduce).backward(dev(G))
+    gm = np.zeros((N, K), np.float64)
+    for i in range(M):
+        for k in range(K):
+            e = ref_arg[i, k]
+            gm[col[e], k] += float(val[e]) * float(G[i, k])
+    np.testing.assert_allclose(Bg.grad.cpu().numpy(), gm, rtol=1e-5, atol=1e-6)
+
+
 def test_minmax_bw_over_csc_rejects_unaligned_k():
     from paddle_sparse_amd import ops
     from paddle_sparse_amd._lib import HipCoreError

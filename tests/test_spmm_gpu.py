@@ -100,6 +100,40 @@ def test_random_k(reduce, K):
     check(reduce, rowptr, col, val, B)
 
 
+@pytest.mark.parametrize("reduce", ["min", "max"])
+@pytest.mark.parametrize("K", [4, 64, 128])
+def test_rows_where_nothing_beats_the_init_keep_the_sentinel(reduce, K):
+    """a row whose products are all -inf (max) / +inf (min) has no winner.  The oracle
+    (upstream: `if (x > acc)`) leaves arg_out = nnz and out = -/+FLT_MAX there; both kernel families
+    must too — the edge-range walk once kept the previous row's winner in its registers."""
+    from paddle_sparse_amd import ops
+
+    M, N = 40, 30
+    rng = np.random.default_rng(K)
+    deg = rng.integers(1, 6, M)
+    deg[7] = 0
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    nnz = int(rowptr[-1])
+    col = rng.integers(0, N - 2, nnz).astype(np.int64)
+    dead_rows = [3, 4, 11, M - 1]  # 3 and 4: consecutive, so "stale" would come from a dead row as well
+    for r in dead_rows:
+        col[rowptr[r]:rowptr[r + 1]] = N - 1 - (r & 1)  # these rows gather only the infinite rows of B
+    val = np.abs(rng.standard_normal(nnz)).astype(np.float32) + 0.5  # positive: inf keeps its sign
+    B = rng.standard_normal((N, K)).astype(np.float32)
+    B[N - 2:] = -np.inf if reduce == "max" else np.inf
+    out, arg = run_gpu(reduce, rowptr, col, val, B)
+    ref, ref_arg = oracle.spmm(reduce, rowptr, col, val, B)
+    assert np.array_equal(arg, ref_arg) and np.array_equal(out, ref)
+    assert np.all(arg[dead_rows] == nnz)
+    # the row-local byte form agrees between the families as well
+    kw = algo_kwargs(dev(rowptr), nnz)
+    if K % 4 == 0:
+        for width in (1, 2):
+            res = ops._spmm(reduce, dev(rowptr), dev(col), dev(val), dev(B), want_arg_bytes=width, **kw)
+            base = ops._spmm(reduce, dev(rowptr), dev(col), dev(val), dev(B), want_arg_bytes=width, algo="row_waves")
+            assert torch.equal(res[2], base[2]) and torch.equal(res[1], base[1])
+
+
 @pytest.mark.parametrize("reduce", ["sum", "mean", "min", "max"])
 def test_no_value(reduce):
     row, rowptr, col, _ = random_csr(500, 400, 4000, seed=3, with_value=False)
