@@ -1,17 +1,21 @@
 #!/usr/bin/env python3
 """Headline benchmark: SpMM GEdges/s + achieved-HBM fraction.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--op spmm_sum] [--config c3|c4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--op spmm_sum] [--config c3|c4] [--scaling strong|weak]
 
 N = 1 (default): BASELINE.json config 3 — random CSR, 2M x 2M, nnz = 20M,
 dense F = 128 fp32, one `spmm_sum` forward per step, inputs resident in HBM.
-N > 1 (launched by torch.distributed.run, one rank per GPU): the same per-GPU
-rows/edges on every rank (weak scaling, BASELINE config 4's structure): rank r
-owns rows [r*2M, (r+1)*2M) of A (20M edges, columns over all N*2M nodes) and
-the matching 2M-row block of B; a step = exchange of B over RCCL (all of it by
-all-gather, or only the rows the rank's columns touch by all_to_all_single) +
-local SpMM (paddle_sparse_amd.distributed.RowPartitionedSpMM).  --config c4
-runs F = 256: at 8 GPUs BASELINE config 4 (16M x 16M, 160M entries).
+N > 1 (launched by torch.distributed.run, one rank per GPU), a step = exchange
+of B over RCCL (all of it by all-gather or by direct peer copies, or only the
+rows the rank's columns touch by all_to_all_single) + the rank-local SpMM with
+the block's per-matrix plan (paddle_sparse_amd.distributed.RowPartitionedSpMM):
+  --scaling strong (default for c3 = BASELINE.json's metric "2M-node nnz=20M
+      F=128, 1/2/4/8 GPU"): the ONE config-3 matrix, rows split by nnz over the
+      ranks, the ONE B row-sharded;
+  --scaling weak (default for --config c4): the same per-GPU rows/edges on every
+      rank: rank r owns rows [r*2M, (r+1)*2M) of A (20M edges, columns over all
+      N*2M nodes) and the matching block of B; c4 runs F = 256: at 8 GPUs
+      BASELINE config 4 (16M x 16M, 160M entries).
 
 Prints ONE JSON line on rank 0 (contract in the task brief): whole-job
 GEdges/s, the roofline object of the dominant kernel (algorithmic bytes /
@@ -278,17 +282,23 @@ def main() -> None:
     ap.add_argument("--op", default="spmm_sum", choices=["spmm_sum", "spmm_mean", "spmm_max", "spmm_min"])
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--config", default="c3", choices=["c3", "c4"],
-                    help="c3 (default): 2M rows / 20M entries per GPU, F = 128 (BASELINE config 3 per GPU); "
-                         "c4: F = 256 — at 8 GPUs BASELINE config 4 (16M x 16M, 160M entries)")
+                    help="c3 (default): the 2M x 2M, nnz = 20M, F = 128 matrix of BASELINE config 3; "
+                         "c4: F = 256, 2M rows / 20M entries per GPU — at 8 GPUs BASELINE config 4 (16M x 16M, 160M entries)")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "strong", "weak"],
+                    help="N > 1.  strong: the ONE config-3 matrix split by nnz over the N ranks (BASELINE.json's metric: "
+                         "'2M-node nnz=20M F=128, 1/2/4/8 GPU'); weak: 2M rows / 20M entries PER GPU, columns over all "
+                         "N x 2M nodes (config 4's structure).  auto = strong for c3, weak for c4")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the breadth / power-law legs after the timed region")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "full", "halo"],
-                    help="N > 1: all of B by all-gather, or only the rows this rank's columns touch "
-                         "(all_to_all_single); auto times both during warmup")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "full", "full_p2p", "halo"],
+                    help="N > 1: all of B by all-gather, the same by direct peer copies, or only the rows this rank's "
+                         "columns touch (all_to_all_single); auto times all of them before the warmup")
     ap.add_argument("--feature-chunks", type=int, default=0,
                     help="N > 1: exchange B in this many column slices and run the SpMM of a slice under the "
                          "exchange of the next ones (1: one exchange, then the SpMM; default 0: time 1 and 4 "
-                         "during warmup and keep the faster)")
+                         "before the warmup and keep the faster)")
+    ap.add_argument("--no-plan", action="store_true", help="N > 1: rank-local kernel on the raw arrays (algo auto) "
+                                                           "instead of the block's per-matrix plan")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -324,13 +334,9 @@ def main() -> None:
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    M, nnz = M_PER_GPU, NNZ_PER_GPU
+    scaling = args.scaling if args.scaling != "auto" else ("strong" if args.config == "c3" else "weak")
     F = 256 if args.config == "c4" else FEAT
-    N = M * world
     reduce = args.op.split("_", 1)[1]
-    rowptr, col, val = make_workload(M, N, nnz, F, seed=2 + rank, device=device)
-    g = torch.Generator(device=device).manual_seed(100 + rank)
-    B_local = torch.randn(M, F, generator=g, device=device)
     ops.spmm_set_variant(args.variant)
 
     def sync_all():
@@ -339,28 +345,69 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize()
 
+    def wall(fn, n):
+        """Seconds per call of fn over n calls, barrier + synchronize on both sides."""
+        sync_all()
+        t_w = time.perf_counter()
+        for _ in range(n):
+            fn()
+        sync_all()
+        return (time.perf_counter() - t_w) / n
+
+    # ---- the workload ------------------------------------------------------------------------
+    if use_dist and scaling == "strong":
+        # BASELINE.json's metric at N > 1: the ONE config-3 matrix (every rank generates it from the same seed
+        # and keeps its block of rows, balanced by nnz) and the ONE dense B, row-sharded in equal blocks
+        from paddle_sparse_amd.distributed import RowPartitionedSpMM, partition_rows_by_nnz, shard_csr
+
+        M_glob = N = M_PER_GPU
+        nnz_glob = NNZ_PER_GPU
+        g_rowptr, g_col, g_val = make_workload(M_glob, N, nnz_glob, F, seed=2, device=device)
+        bounds = partition_rows_by_nnz(g_rowptr, world)
+        shard = shard_csr(g_rowptr, g_col, g_val, N, bounds, rank)
+        del g_rowptr, g_col, g_val
+        rowptr, col, val = shard.rowptr, shard.col, shard.value
+        M, nnz = shard.num_rows, shard.nnz
+        g = torch.Generator(device=device).manual_seed(100)
+        B_glob = torch.randn(N, F, generator=g, device=device)
+        nb = (N + world - 1) // world
+        B_local = torch.zeros(nb, F, device=device)
+        mine = B_glob[rank * nb:(rank + 1) * nb]
+        B_local[:mine.shape[0]] = mine
+        del B_glob, mine
+        total_nnz = nnz_glob
+    else:
+        M, nnz = M_PER_GPU, NNZ_PER_GPU
+        N = M * world
+        rowptr, col, val = make_workload(M, N, nnz, F, seed=2 + rank, device=device)
+        g = torch.Generator(device=device).manual_seed(100 + rank)
+        B_local = torch.randn(M, F, generator=g, device=device)
+        total_nnz = world * nnz
+        if use_dist:
+            from paddle_sparse_amd.distributed import RowPartitionedSpMM, RowShard
+
+            shard = RowShard(rowptr, col, val, rank * M, (rank + 1) * M, N)
+    torch.cuda.empty_cache()
+
     forms = {}  # (exchange, chunks) -> RowPartitionedSpMM
     chosen = ("full", 1)
     tune_ms = {}
+    TUNE_STEPS = 10
     if use_dist:
-        from paddle_sparse_amd.distributed import RowPartitionedSpMM, RowShard
-
-        shard = RowShard(rowptr, col, val, rank * M, (rank + 1) * M, N)
-        exchanges = ["full", "halo"] if args.exchange == "auto" else [args.exchange]
-        chunk_opts = [1, 4] if args.feature_chunks == 0 and F % 4 == 0 else [max(args.feature_chunks, 1)]
-        ops_by_exchange = {e: RowPartitionedSpMM(shard, reduce=reduce, exchange=e) for e in exchanges}
+        exchanges = ["full", "full_p2p", "halo"] if args.exchange == "auto" else [args.exchange]
+        chunk_opts = [1, 4] if args.feature_chunks == 0 and F % 16 == 0 else [max(args.feature_chunks, 1)]
+        # exchange / send buffers and the output live on the objects: a step allocates nothing (distributed.py)
+        ops_by_exchange = {e: RowPartitionedSpMM(shard, reduce=reduce, exchange=e, plan=not args.no_plan, keep_output=True)
+                           for e in exchanges}
         forms = {(e, c): ops_by_exchange[e] for e in exchanges for c in chunk_opts}
-        # Which form is faster depends on the fabric and on the graph: untimed, before the warmup,
-        # every form runs a few steps; the slowest rank's time decides and every rank keeps the same form.
+        # Which form is faster depends on the fabric and on the graph: before the warmup every form runs 3 untimed
+        # steps (buffers, plans, communicator channels) and then TUNE_STEPS timed ones in steady state — the host far
+        # ahead of the GPU, as in the timed region —; the slowest rank's time decides and every rank keeps the same form.
         spent = []
-        for (e, c), op in forms.items():
-            op(B_local, feature_chunks=c)
-            sync_all()
-            t_c = time.perf_counter()
+        for (e, c), o in forms.items():
             for _ in range(3):
-                op(B_local, feature_chunks=c)
-            sync_all()
-            spent.append((time.perf_counter() - t_c) / 3)
+                o(B_local, feature_chunks=c)
+            spent.append(wall(lambda: o(B_local, feature_chunks=c), TUNE_STEPS))
         spent_t = torch.tensor(spent, dtype=torch.float64, device=device)
         dist.all_reduce(spent_t, op=dist.ReduceOp.MAX)
         spent = [float(x) for x in spent_t]
@@ -369,14 +416,14 @@ def main() -> None:
         tune_ms = {f"{e}/chunks{c}": round(x * 1e3, 4) for (e, c), x in zip(keys, spent)}
         op = forms[chosen]
         step = lambda: op(B_local, feature_chunks=chosen[1])  # noqa: E731  exchange of B + local HIP SpMM
-        B_full = ops_by_exchange.get("full", op).gather(B_local) if "full" in ops_by_exchange else op.exchange_only(B_local)
+        B_full = op.exchange_only(B_local, chosen[1])  # the chosen form's assembled operand (the object's buffers)
     else:
         fn = getattr(ops, args.op)
         B_full = B_local
         step = lambda: fn(rowptr, col, val, B_full)  # noqa: E731
 
     def local_kernel():
-        if use_dist and "full" not in ops_by_exchange:
+        if use_dist:
             return op.spmm_only(B_full)
         return ops._spmm(reduce, rowptr, col, val, B_full)[0]
 
@@ -399,39 +446,48 @@ def main() -> None:
     # overlapped: the forms that were NOT timed above run a few steps here, so the line carries all.
     form_s = {}
     exch_ms = {}
+    kern_by_exchange = {}
     if use_dist:
-        other_steps = max(3, args.steps // 5)
+        other_steps = max(TUNE_STEPS, args.steps // 2)
         for key, o in forms.items():
             if key == chosen:
                 form_s[key] = elapsed / args.steps
                 continue
-            o(B_local, feature_chunks=key[1])
-            sync_all()
-            t1 = time.perf_counter()
-            for _ in range(other_steps):
+            for _ in range(2):
                 o(B_local, feature_chunks=key[1])
-            sync_all()
-            form_s[key] = (time.perf_counter() - t1) / other_steps
-        for e, o in ops_by_exchange.items():
-            exch_ms[e] = event_ms(lambda: o.exchange_only(B_local), max(3, args.steps // 5))
+            form_s[key] = wall(lambda: o(B_local, feature_chunks=key[1]), other_steps)
+        # the two parts of every form alone, each on the compute stream (nothing overlaps here): what a
+        # step of the form costs when exchange and kernels run back to back
+        for (e, c), o in forms.items():
+            o.exchange_only(B_local, c)
+            exch_ms[(e, c)] = event_ms(lambda: o.exchange_only(B_local, c), other_steps)
+            operand = o.exchange_only(B_local, c)
+            o.spmm_only(operand)
+            kern_by_exchange[(e, c)] = event_ms(lambda: o.spmm_only(operand), other_steps)
 
-    vec = [elapsed, kern_ms] + [form_s[k] for k in forms] + [exch_ms[e] for e in exch_ms]
+    vec = [elapsed, kern_ms] + [form_s[k] for k in forms] + [exch_ms[e] for e in exch_ms] + [kern_by_exchange[e] for e in kern_by_exchange]
     t = torch.tensor(vec, dtype=torch.float64, device=device)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     vec = [float(x) for x in t]
     elapsed, kern_ms = vec[0], vec[1]
     form_s = dict(zip(forms, vec[2:2 + len(forms)]))
-    exch_ms = dict(zip(exch_ms, vec[2 + len(forms):]))
+    exch_ms = dict(zip(exch_ms, vec[2 + len(forms):2 + len(forms) + len(exch_ms)]))
+    kern_by_exchange = dict(zip(kern_by_exchange, vec[2 + len(forms) + len(exch_ms):]))
     recv_rows = {}
+    shard_sizes = None
     if use_dist:
         rr = torch.tensor([o.rows_received_per_step() for o in ops_by_exchange.values()], dtype=torch.int64, device=device)
         dist.all_reduce(rr, op=dist.ReduceOp.MAX)
         recv_rows = dict(zip(ops_by_exchange, rr.tolist()))
+        sz = torch.zeros(world, 2, dtype=torch.int64, device=device)
+        sz[rank, 0], sz[rank, 1] = M, nnz
+        dist.all_reduce(sz)
+        shard_sizes = sz.tolist()
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        value = world * nnz / (elapsed / args.steps) / 1e9
+        value = total_nnz / (elapsed / args.steps) / 1e9
         alg = algorithmic_bytes(nnz, M, F, True, args.op in ("spmm_max", "spmm_min"))
         achieved = alg / (kern_ms * 1e-3) / 1e9
         traffic, traffic_note = None, "not collected for this configuration"
@@ -441,7 +497,16 @@ def main() -> None:
             traffic = rec.get("hbm_bytes_per_launch")
             traffic_note = (f"read from profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round "
                             f"{rec.get('round', '?')}, {rec.get('source', '?')}); not measured in this run")
-        cfg_name = "BASELINE config 3 per GPU" if args.config == "c3" else "BASELINE config 4's per-GPU share (F = 256)"
+        if use_dist and scaling == "strong":
+            what = (f"{args.op} fwd, the ONE uniform random CSR {M_PER_GPU}x{N} with nnz={total_nnz} (BASELINE config 3), "
+                    f"dense F={F} fp32, rows split by nnz over {world} GPU(s)")
+        else:
+            cfg_name = "BASELINE config 3 per GPU" if args.config == "c3" else "BASELINE config 4's per-GPU share (F = 256)"
+            what = (f"{args.op} fwd, uniform random CSR {M}x{N} per GPU, nnz={nnz} per GPU, "
+                    f"dense F={F} fp32 ({cfg_name})")
+        if use_dist:
+            what += (f"; + exchange of B ({N}x{F}, row-sharded) every step: {chosen[0]}"
+                     + (f", in {chosen[1]} column slices overlapped with the SpMM" if chosen[1] > 1 else ""))
         line = {
             "metric": f"{args.op}_gedges_per_s",
             "value": round(value, 4),
@@ -451,16 +516,12 @@ def main() -> None:
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling if use_dist else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.op} fwd, uniform random CSR {M}x{N} per GPU, nnz={nnz} per GPU, "
-                            f"dense F={F} fp32 ({cfg_name})"
-                            + (f"; + exchange of B ({N}x{F}) every step: {chosen[0]}"
-                               + (f", in {chosen[1]} column slices overlapped with the SpMM" if chosen[1] > 1 else "")
-                               if use_dist else ""),
+                "workload": what,
                 "rows_per_gpu": M, "nnz_per_gpu": nnz, "feat": F, "index_dtype": "int64",
                 "variant": args.variant,
             },
@@ -479,24 +540,36 @@ def main() -> None:
             },
         }
         if use_dist:
-            rate = lambda s_: round(world * nnz / s_ / 1e9, 4)  # noqa: E731
+            rate = lambda s_: round(total_nnz / s_ / 1e9, 4)  # noqa: E731
             serial = {e: rate(form_s[(e, 1)]) for e in ops_by_exchange if (e, 1) in form_s}
             overl = {e: rate(form_s[(e, c)]) for (e, c) in form_s if c > 1}
+            line["config"]["rows_nnz_by_rank"] = shard_sizes
+            line["roofline"]["note"] = ("rank 0's block: its kernel time over its own algorithmic bytes; kernel_ms is the "
+                                        "slowest rank's")
             line["multi_gpu"] = {
                 "form_timed_as_value": f"{chosen[0]}/chunks{chosen[1]}",
-                "form_chosen_by": "flags" if len(forms) == 1 else "warmup timing (ms per step by form)",
-                "warmup_ms_per_step_by_form": tune_ms or None,
-                "spmm_only_aggregate_gedges_per_s": round(world * nnz / (kern_ms * 1e-3) / 1e9, 4),
+                "form_chosen_by": "flags" if len(forms) == 1 else f"{TUNE_STEPS} steady-state steps per form before the warmup (ms per step by form)",
+                "tune_ms_per_step_by_form": tune_ms or None,
+                "step_ms_by_form": {f"{e}/chunks{c}": round(x * 1e3, 4) for (e, c), x in form_s.items()},
+                "local_plan": "raw arrays, algo auto" if args.no_plan else op.local_storage()._spmm_algo(),
+                "spmm_only_aggregate_gedges_per_s": rate(kern_ms * 1e-3),
                 "end_to_end_serial_gedges_per_s": serial,
                 "end_to_end_overlapped_gedges_per_s": overl,
                 "overlapped_feature_chunks": 4,
-                "exchange_ms": {e: round(x, 4) for e, x in exch_ms.items()},
-                "allgather_bytes_received_per_rank": (world - 1) * M * F * 4,
+                "exchange_ms": {e: round(x, 4) for (e, c), x in exch_ms.items() if c == 1},
+                "exchange_ms_by_form": {f"{e}/chunks{c}": round(x, 4) for (e, c), x in exch_ms.items()},
+                "kernel_ms_by_form": {f"{e}/chunks{c}": round(x, 4) for (e, c), x in kern_by_exchange.items()},
+                "kernel_plus_exchange_ms_by_form": {f"{e}/chunks{c}": round(exch_ms[(e, c)] + kern_by_exchange[(e, c)], 4)
+                                                    for (e, c) in exch_ms},
+                "step_over_parts_by_form": {f"{e}/chunks{c}": round(form_s[(e, c)] * 1e3 / (exch_ms[(e, c)] + kern_by_exchange[(e, c)]), 4)
+                                            for (e, c) in exch_ms},
+                "allgather_bytes_received_per_rank": recv_rows.get("full", 0) * F * 4,
                 "bytes_received_per_rank_by_exchange": {e: r * F * 4 for e, r in recv_rows.items()},
+                "buffer_bytes_held_by_form_objects": {e: o.buffer_bytes() for e, o in ops_by_exchange.items()},
                 "note": "value counts the exchange of B inside every step, in the form named by form_timed_as_value; "
-                        "spmm_only_* is the local-kernel rate with B already assembled",
+                        "spmm_only_* is the local-kernel rate with B already assembled (slowest rank)",
             }
-        if not args.no_cpu and args.op == "spmm_sum" and world == 1:  # CPU leg: N = 1 only
+        if not args.no_cpu and args.op == "spmm_sum" and world == 1 and isinstance(B_full, torch.Tensor) and not (use_dist and chosen[0] == "halo"):  # CPU leg: N = 1 only
             info, ref, rows = cpu_baseline(rowptr, col, val, B_full)
             got = out[:rows].cpu().numpy()
             scale = np.abs(ref).max()

@@ -162,7 +162,7 @@ int psa_spmm(int reduce, const int64_t* rowptr, const int64_t* col,
  * (paddle_sparse_amd/storage.py::_hot_columns), and per call gathers the hot
  * rows of the current mat with psa_gather_rows (13 us for 65 536 rows).
  * arg_width: bytes per entry of arg_bytes, 1 (as psa_spmm) or 2 — (index in the
- * row) & 0xffff, exact up to 65 536 entries per row; see psa_spmm_minmax_bw_csc. */
+ * row) & 0xffff, exact up to 65 535 entries per row; see psa_spmm_minmax_bw_csc. */
 typedef enum psa_spmm_algo {
   PSA_SPMM_AUTO = 0,        /* today: PSA_SPMM_ROW_WAVES */
   PSA_SPMM_ROW_WAVES = 1,   /* one wavefront per CSR row (+ the long-row chunks) */
@@ -290,7 +290,7 @@ int psa_spmm_minmax_bw(const int64_t* col, const float* value, const float* mat,
  *
  * arg_width (1 or 2): bytes per entry of arg_bytes and of tag — the width
  * psa_spmm_coo wrote and psa_csc_edge_tags was asked for.  Width 2 holds
- * (index in the row) & 0xffff: exact for rows of up to 65 536 entries, so on a
+ * (index in the row) & 0xffff: exact for rows of up to 65 535 entries (0xffff, like 0xff in the one-byte form, says "no winner": empty row, or no product beat the init), so on a
  * power-law graph (R-MAT scale 21: longest row 41 677) the forward stores
  * 2 bytes per element instead of 8 + 1 and this pass needs no arg_out.
  *
@@ -329,7 +329,7 @@ int psa_spmm_minmax_bw_csc(const int64_t* rowptr, const int64_t* colptr,
  * the view), or NULL (derived from colptr into the workspace).  row_csc, tag,
  * arg_bytes / arg_width, hot_grad / hot_bytes / num_hot: as psa_spmm_minmax_bw_csc;
  * arg_bytes must be exact (one byte: no row above 128 entries; two bytes: none above
- * 65 536).  weight_csc: f32[nnz] = value[csr2csc] (psa_transpose_weights) or NULL
+ * 65 535).  weight_csc: f32[nnz] = value[csr2csc] (psa_transpose_weights) or NULL
  * (weights 1).  Sums run in entry order inside a range and range by range for
  * columns that cross ranges: deterministic, last bits may differ from
  * psa_spmm_minmax_bw_csc.  R-MAT scale 21, K = 128: 2.7 -> 2.0 ms.

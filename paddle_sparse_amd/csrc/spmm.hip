@@ -185,10 +185,7 @@ __device__ __forceinline__ void reduce_edge_range(
       if (INDIRECT) {
         id_l = m.edge_id[base + lane];
         v_l = val ? val[id_l] : 1.f;
-        if (MODE == M_CSC && m.row_scale) {
-          s_l = m.row_scale[c_l];
-          v_l *= s_l;
-        }
+        if (MODE == M_CSC && m.row_scale) s_l = m.row_scale[c_l];  // multiplied in where the weight is consumed
         if (MASK) {  // the tag rides in the top bits of the edge id (ids stay below 2^48)
           if (AW == 2) id_l |= static_cast<int64_t>(reinterpret_cast<const uint16_t*>(m.tag)[base + lane]) << 48;
           else id_l |= static_cast<int64_t>(m.tag[base + lane]) << 56;
@@ -206,7 +203,9 @@ __device__ __forceinline__ void reduce_edge_range(
       for (int u = 0; u < U; ++u) {
         const int idx = j + u * G + g;  // < 64 by the static_assert
         const int64_t c = shfl_i64(c_l, idx);
-        w[u] = __shfl(v_l, idx);
+        // (the weight is fetched from its lane after the gathers are out: over the CSC view it comes
+        // through a dependent read, val[edge_id], which would otherwise hold the gathers back one hop)
+        if (!INDIRECT) w[u] = __shfl(v_l, idx);
         ok[u] = (idx < n) && kact;
 #pragma unroll
         for (int i = 0; i < VEC; ++i) b[u][i] = 0.f;
@@ -298,6 +297,12 @@ __device__ __forceinline__ void reduce_edge_range(
         }
       }
       if (INDIRECT) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) w[u] = __shfl(v_l, j + u * G + g);
+        if (MODE == M_CSC && m.row_scale) {  // wave-uniform
+#pragma unroll
+          for (int u = 0; u < U; ++u) w[u] *= __shfl(s_l, j + u * G + g);
+        }
         if (want_gv) {
           static_assert(!INDIRECT || ((U & (U - 1)) == 0 && U <= LPR), "U must be a power of two <= LPR");
           const int l = lane % LPR;

@@ -188,7 +188,8 @@ __device__ __forceinline__ void eb_fill_role(const EbArgs& a) {
             for (int h = 0; h < E; h += 4) {
               if (a.arg_out) store_arg_nt<4>(a.arg_out + rr * a.K + E * q + h, sentinel);
               if (a.arg_bytes) {
-                const uint32_t none[4] = {0u, 0u, 0u, 0u};
+                const uint32_t nw = arg_local(0, 0, a.arg_width);  // "no winner", as in every other kernel
+                const uint32_t none[4] = {nw, nw, nw, nw};
                 store_arg_local4(a.arg_bytes, rr * a.K + E * q + h, none, a.arg_width);
               }
             }

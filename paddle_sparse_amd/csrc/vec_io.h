@@ -90,12 +90,17 @@ __device__ __forceinline__ void store_arg_nt(int64_t* p, const int64_t (&src)[VE
 // entry of (row, k) with a per-edge tag of the same form instead of reading 8-byte edge ids):
 //   width 1  (index & 127) | 0x80 on rows of more than 128 edges, where equal bytes only name a
 //            candidate that is then tested against arg_out itself;
-//   width 2  index & 0xffff: exact for rows of up to 65 536 edges, arg_out not needed at all.
+//   width 2  index & 0xffff: exact for rows of up to 65 535 edges, arg_out not needed at all.
+// "No winner" (arg_out == nnz: an empty row, or a row none of whose products beat the init — all NaN,
+// all -inf under max) is all ones in either width: local_index >= deg tells it (nnz - row start >= deg
+// always), and no tag of an exact row equals it (tags of rows up to 128 edges are < 0x80, of rows up to
+// 65 535 edges < 0xffff), so the one-pass backward routes nothing there — as the sentinel in arg_out does.
 constexpr int kByteExact = 128;      // rows up to this many edges: width 1 is exact
-constexpr int kWordExact = 65536;    // ... width 2 is exact
+constexpr int kWordExact = 65535;    // ... width 2 is exact
 
 __device__ __forceinline__ uint32_t arg_local(int64_t local_index, int64_t deg, int width) {
   const uint32_t d = static_cast<uint32_t>(local_index);
+  if (local_index >= deg) return width == 2 ? 0xffffu : 0xffu;
   return width == 2 ? (d & 0xffffu) : ((d & 127u) | (deg > kByteExact ? 0x80u : 0u));
 }
 

@@ -7,12 +7,33 @@ this is the north-star's multi-GPU path:
     through rowptr (each rank keeps its rebased rowptr slice and its col/value
     slice, and is the only writer of out[r0:r1, :] — no output exchange);
   * the dense B is row-sharded in equal blocks (rank r owns rows
-    [r*nb, (r+1)*nb), nb = ceil(N / world)); every step either reassembles it
-    with ONE all-gather (`torch.distributed.all_gather_into_tensor`, backend
-    "nccl" = RCCL on ROCm) and runs the local HIP SpMM on the full B, or — the
-    halo form — moves only the rows the rank's columns touch with ONE
-    all_to_all_single and runs the SpMM on the compacted operand;
+    [r*nb, (r+1)*nb), nb = ceil(N / world)); every step reassembles what the
+    rank needs of it in one of three ways —
+      "full"      ONE `all_gather_into_tensor` of all of B (RCCL's all-gather),
+      "full_p2p"  the same bytes as world - 1 direct peer copies posted together
+                  (`batch_isend_irecv`: one send and one receive per peer inside one
+                  RCCL group, every block one hop over its own xGMI link — the full
+                  mesh has 7 links per GPU, a ring uses them differently),
+      "halo"      only the rows of B the rank's column ids touch, ONE
+                  `all_to_all_single` with split sizes, the local SpMM on the
+                  compacted operand —
+    and runs the local HIP SpMM with the block's own per-matrix plan
+    (`RowShard.storage()`: kernel family from the row statistics, COO row ids,
+    compact copy of the hub rows — what `SparseTensor.matmul` does on one GPU);
   * coalesce / index_sort / ind2ptr stay single-GPU (replicas only).
+
+Steady state: exchange buffers, send buffers and (optionally) the output live
+on the `RowPartitionedSpMM` object.  A buffer handed to a collective is
+recorded on the collective's stream; allocated afresh every step it cannot go
+back to the caching allocator before that stream's event completes, and a host
+that runs ahead of the GPU then falls through to hipMalloc every step (round
+2's committed rehearsal: 2.08 ms per step over 3 steps, 6.92 ms over 25).
+
+Backward (`RowPartitionedSpMM.apply`, sum / mean): grad of the local block of B
+= this rank's rows of sum_r A_r^T grad_out_r — every rank runs the SpMM over its
+block's CSC view (fixed adjacency: the planned forward of the transpose) and
+ONE `reduce_scatter_tensor` (full) or the halo's all_to_all run backwards
+followed by a segmented add (halo) brings the partial sums to their owners.
 
 xGMI arithmetic that decides what this can reach (8-GPU full mesh, 7 links x
 ~153 GB/s per GPU): every rank must receive (world-1)/world of B every step;
@@ -28,11 +49,13 @@ tests/test_distributed.py covers it at world_size 2).
 """
 from __future__ import annotations
 
-from dataclasses import dataclass
-from typing import Callable, List, Optional
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
+
+EXCHANGES = ("full", "full_p2p", "halo")
 
 
 def partition_rows_by_nnz(rowptr: torch.Tensor, world: int) -> List[int]:
@@ -74,6 +97,7 @@ class RowShard:
     row_begin: int
     row_end: int
     num_cols: int                 # N of the global matrix
+    _storages: Dict[int, object] = field(default_factory=dict, repr=False, compare=False)
 
     @property
     def num_rows(self) -> int:
@@ -82,6 +106,23 @@ class RowShard:
     @property
     def nnz(self) -> int:
         return self.col.numel()
+
+    def storage(self, col: Optional[torch.Tensor] = None, num_cols: Optional[int] = None):
+        """The block as a SparseStorage (structure only, memoised per column array): the object
+        that carries the per-matrix plan of the single-GPU product — `_spmm_algo()` from the
+        block's own row statistics, `row()`, `_hot_columns()`, the CSC view for the backward.
+        `col` / `num_cols`: the halo form's compacted column ids and operand height."""
+        from .storage import SparseStorage
+
+        col = self.col if col is None else col
+        key = col.data_ptr()
+        st = self._storages.get(key)
+        if st is None:
+            st = SparseStorage(rowptr=self.rowptr, col=col, value=None,
+                               sparse_sizes=(self.num_rows, self.num_cols if num_cols is None else num_cols),
+                               is_sorted=True, trust_data=True)
+            self._storages[key] = st
+        return st
 
 
 def shard_csr(rowptr: torch.Tensor, col: torch.Tensor, value: Optional[torch.Tensor],
@@ -112,20 +153,57 @@ def all_gather_dense(b_local: torch.Tensor, num_rows: int, group=None,
     return out[:num_rows]
 
 
-def _hip_spmm(reduce: str, rowptr, col, value, mat, out=None):
-    from . import ops  # the HIP core; loads (or fails loudly) on first use
+class _Works:
+    """Several asynchronous works waited for as one."""
 
-    return ops._spmm(reduce, rowptr, col, value, mat, want_arg=False, out=out)[0]  # `out` only: min/max skip arg_out
+    def __init__(self, works):
+        self.works = list(works)
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
 
 
-def _hip_pack(src, idx, col0, width):
+def peer_copy_dense(buf: torch.Tensor, part: torch.Tensor, group=None, async_op: bool = False):
+    """The full exchange as direct peer copies: block r of `buf` ([world * nb, w]) receives rank
+    r's `part` ([nb, w]); every rank posts one send and one receive per peer in ONE batch (an RCCL
+    group: all world - 1 transfers run concurrently, each over the link to its peer) and copies
+    its own block locally.  Same result as all_gather_into_tensor(buf, part)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    nb = part.shape[0]
+    buf[rank * nb:(rank + 1) * nb].copy_(part)
+    ops = []
+    for d in range(1, world):  # peer order rotated by rank: at every position of the batch the pairs are disjoint
+        dst, src = (rank + d) % world, (rank - d) % world
+        ops.append(dist.P2POp(dist.isend, part, dst, group))
+        ops.append(dist.P2POp(dist.irecv, buf[src * nb:(src + 1) * nb], src, group))
+    if not ops:
+        return None
+    works = _Works(dist.batch_isend_irecv(ops))
+    if async_op:
+        return works
+    works.wait()
+    return None
+
+
+def _hip_spmm_planned(reduce: str, st, value, mat, out=None):
+    from .matmul import spmm_planned  # the HIP core; loads (or fails loudly) on first use
+
+    return spmm_planned(st, value, mat, reduce, out=out)
+
+
+def _hip_pack(src, idx, col0, width, out=None):
     from . import ops
 
-    return ops.gather_rows_window(src, idx, col0, width)
+    return ops.gather_rows_window(src, idx, col0, width, out=out)
 
 
-def _torch_pack(src, idx, col0, width):
-    return src[idx, col0:col0 + width].contiguous()
+def _torch_pack(src, idx, col0, width, out=None):
+    res = src[idx, col0:col0 + width]
+    if out is None:
+        return res.contiguous()
+    out.copy_(res)
+    return out
 
 
 @dataclass
@@ -166,6 +244,7 @@ class RowPartitionedSpMM:
     """out_local = reduce-SpMM(A[r0:r1, :], B) with B row-sharded over the ranks.
 
     exchange = "full": every step reassembles all of B with one all-gather.
+    exchange = "full_p2p": the same bytes as direct peer copies (`peer_copy_dense`).
     exchange = "halo": every step moves only the rows of B that the rank's
     column ids touch (`plan_halo`, once per matrix): each rank packs the rows its
     peers asked for (one HIP gather), ONE all_to_all_single with split sizes
@@ -185,32 +264,76 @@ class RowPartitionedSpMM:
     into `out`, (world - 1) more read-modify-write passes over M x F floats —
     more HBM traffic than the SpMM itself at 8 ranks.
 
+    Buffers: the exchange and send buffers of every slice shape are kept on the
+    object (see the module docstring); `keep_output=True` keeps `out` there too —
+    the returned tensor is then overwritten by the next call (a benchmark or an
+    inference loop that consumes it at once; autograd callers leave it off or pass
+    `out=`).
+
     local_spmm is the rank-local kernel, (reduce, rowptr, col, value, mat, out) ->
-    out; it defaults to the HIP SpMM and exists as a parameter only so that the
-    CPU/gloo tests can check the partitioning and the collectives without a GPU.
+    out; it exists as a parameter only so that the CPU/gloo tests can check the
+    partitioning and the collectives without a GPU.  The default is the HIP SpMM
+    through the block's SparseStorage (`RowShard.storage()`), i.e. with the
+    per-matrix plan; plan=False calls the kernel on the raw arrays (algo auto).
     """
 
     def __init__(self, shard: RowShard, group=None, reduce: str = "sum",
-                 local_spmm: Optional[Callable] = None, exchange: str = "full"):
-        if exchange not in ("full", "halo"):
-            raise ValueError("exchange must be 'full' or 'halo'")
+                 local_spmm: Optional[Callable] = None, exchange: str = "full", plan: bool = True,
+                 keep_output: bool = False):
+        if exchange not in EXCHANGES:
+            raise ValueError(f"exchange must be one of {EXCHANGES}")
         self.shard, self.group, self.reduce, self.exchange = shard, group, reduce, exchange
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.block_rows = dense_block_rows(shard.num_cols, self.world)
-        self._local_spmm = local_spmm or _hip_spmm
+        self._custom_spmm = local_spmm
+        self.plan = plan and local_spmm is None
+        self.keep_output = keep_output
         self._pack = _hip_pack if shard.col.is_cuda else _torch_pack
-        self._gather_buf: Optional[torch.Tensor] = None
+        self._bufs: Dict[Tuple, torch.Tensor] = {}
         self.halo: Optional[HaloPlan] = plan_halo(shard, self.block_rows, group) if exchange == "halo" else None
 
     @classmethod
     def from_global(cls, rowptr, col, value, num_cols: int, group=None, reduce: str = "sum",
-                    balance: str = "nnz", local_spmm: Optional[Callable] = None, exchange: str = "full"):
+                    balance: str = "nnz", local_spmm: Optional[Callable] = None, exchange: str = "full", **kw):
         """Every rank holds the whole CSR (e.g. loaded from disk) and keeps its block."""
         world, rank = dist.get_world_size(group), dist.get_rank(group)
         M = rowptr.numel() - 1
         bounds = partition_rows_by_nnz(rowptr, world) if balance == "nnz" else partition_rows_evenly(M, world)
-        return cls(shard_csr(rowptr, col, value, num_cols, bounds, rank), group, reduce, local_spmm, exchange)
+        return cls(shard_csr(rowptr, col, value, num_cols, bounds, rank), group, reduce, local_spmm, exchange, **kw)
+
+    # ---- the rank-local kernel ----------------------------------------------------------
+    def _operand_cols(self) -> Tuple[torch.Tensor, int]:
+        """(column ids, operand height) of the local SpMM for this exchange."""
+        if self.halo is None:
+            return self.shard.col, self.shard.num_cols
+        return self.halo.col_local, self.halo.num_needed
+
+    def local_storage(self):
+        col, height = self._operand_cols()
+        return self.shard.storage(col, height)
+
+    def _local(self, operand: torch.Tensor, out: Optional[torch.Tensor]) -> torch.Tensor:
+        s = self.shard
+        col, _ = self._operand_cols()
+        if self._custom_spmm is not None:
+            return self._custom_spmm(self.reduce, s.rowptr, col, s.value, operand, out)
+        if self.plan:
+            return _hip_spmm_planned(self.reduce, self.local_storage(), s.value, operand, out)
+        from . import ops
+
+        return ops._spmm(self.reduce, s.rowptr, col, s.value, operand, want_arg=False, out=out)[0]
+
+    # ---- buffers that live as long as the object ---------------------------------------
+    def _buffer(self, kind: str, shape: Tuple[int, ...], like: torch.Tensor, slot: int = 0) -> torch.Tensor:
+        key = (kind, slot, tuple(shape), like.dtype, like.device)
+        buf = self._bufs.get(key)
+        if buf is None:
+            buf = self._bufs[key] = torch.empty(shape, dtype=like.dtype, device=like.device)
+        return buf
+
+    def buffer_bytes(self) -> int:
+        return sum(b.numel() * b.element_size() for b in self._bufs.values())
 
     # ---- bytes on the fabric ----------------------------------------------------------
     def rows_received_per_step(self) -> int:
@@ -233,55 +356,151 @@ class RowPartitionedSpMM:
         return blk.contiguous()
 
     def gather(self, b_local: torch.Tensor) -> torch.Tensor:
-        """The full exchange alone: all of B (one all-gather)."""
-        shape = (self.world * self.block_rows, b_local.shape[1])
-        buf = self._gather_buf
-        if buf is None or buf.shape != shape or buf.dtype != b_local.dtype or buf.device != b_local.device:
-            buf = self._gather_buf = torch.empty(shape, dtype=b_local.dtype, device=b_local.device)
+        """The full exchange alone: all of B (one all-gather), in the object's buffer."""
+        buf = self._buffer("recv", (self.world * self.block_rows, b_local.shape[1]), b_local)
         return all_gather_dense(b_local, self.shard.num_cols, self.group, out=buf)
 
-    def _exchange_slice(self, b_local: torch.Tensor, c0: int, width: int, async_op: bool):
-        """Start the exchange of columns [c0, c0 + width) of B; returns (work | None, operand, col)."""
+    def _exchange_slice(self, b_local: torch.Tensor, c0: int, width: int, async_op: bool, slot: int = 0):
+        """Start the exchange of columns [c0, c0 + width) of B; returns (work | None, operand)."""
         if b_local.shape[0] != self.block_rows:
             raise ValueError(f"b_local must have {self.block_rows} rows (got {b_local.shape[0]})")
         s, F = self.shard, b_local.shape[1]
         if self.halo is None:
-            part = b_local if width == F else b_local[:, c0:c0 + width].contiguous()
-            buf = torch.empty((self.world * self.block_rows, width), dtype=b_local.dtype, device=b_local.device)
-            work = dist.all_gather_into_tensor(buf, part.contiguous(), group=self.group, async_op=async_op)
-            return work, buf[:s.num_cols], s.col
+            if width == F and b_local.is_contiguous():
+                part = b_local
+            else:  # the slice as a dense block, in a buffer of its own (the collective's stream reads it)
+                part = self._buffer("part", (self.block_rows, width), b_local, slot)
+                part.copy_(b_local[:, c0:c0 + width])
+            buf = self._buffer("recv", (self.world * self.block_rows, width), b_local, slot)
+            if self.exchange == "full_p2p":
+                work = peer_copy_dense(buf, part, self.group, async_op=async_op)
+            else:
+                work = dist.all_gather_into_tensor(buf, part, group=self.group, async_op=async_op)
+            return work, buf[:s.num_cols]
         h = self.halo
-        send = self._pack(b_local.contiguous(), h.send_idx, c0, width)
-        recv = torch.empty((h.num_needed, width), dtype=b_local.dtype, device=b_local.device)
+        send = self._buffer("send", (h.send_idx.numel(), width), b_local, slot)
+        self._pack(b_local.contiguous(), h.send_idx, c0, width, send)
+        recv = self._buffer("recv", (h.num_needed, width), b_local, slot)
         work = dist.all_to_all_single(recv, send, output_split_sizes=h.need_counts, input_split_sizes=h.send_counts,
                                       group=self.group, async_op=async_op)
-        return work, recv, h.col_local
+        return work, recv
 
-    def __call__(self, b_local: torch.Tensor, feature_chunks: int = 1) -> torch.Tensor:
-        """out_local [m_local, F]; see the class docstring for the two knobs."""
+    def __call__(self, b_local: torch.Tensor, feature_chunks: int = 1, out: Optional[torch.Tensor] = None
+                 ) -> torch.Tensor:
+        """out_local [m_local, F]; see the class docstring for the knobs."""
         s, F = self.shard, b_local.shape[1]
+        if out is None and self.keep_output:
+            out = self._buffer("out", (s.num_rows, F), b_local)
         if feature_chunks <= 1:
-            _, operand, col = self._exchange_slice(b_local, 0, F, async_op=False)
-            return self._local_spmm(self.reduce, s.rowptr, col, s.value, operand, None)
+            _, operand = self._exchange_slice(b_local, 0, F, async_op=False)
+            return self._local(operand, out)
         bounds = [(F * c) // feature_chunks for c in range(feature_chunks + 1)]
-        pending = [self._exchange_slice(b_local, bounds[c], bounds[c + 1] - bounds[c], async_op=True)
+        pending = [self._exchange_slice(b_local, bounds[c], bounds[c + 1] - bounds[c], async_op=True, slot=c)
                    for c in range(feature_chunks)]
-        out = torch.empty((s.num_rows, F), dtype=b_local.dtype, device=b_local.device)
-        for c, (work, operand, col) in enumerate(pending):
-            work.wait()  # the compute stream waits for slice c only
-            self._local_spmm(self.reduce, s.rowptr, col, s.value, operand, out[:, bounds[c]:bounds[c + 1]])
+        if out is None:
+            out = torch.empty((s.num_rows, F), dtype=b_local.dtype, device=b_local.device)
+        for c, (work, operand) in enumerate(pending):
+            if work is not None:
+                work.wait()  # the compute stream waits for slice c only
+            self._local(operand, out[:, bounds[c]:bounds[c + 1]])
         return out
 
-    def spmm_only(self, b_operand: torch.Tensor) -> torch.Tensor:
-        """Local kernel on an already-assembled operand: all of B (exchange "full")
-        or the compacted rows (exchange "halo", e.g. from `exchange_only`)."""
-        s = self.shard
-        col = s.col if self.halo is None else self.halo.col_local
-        return self._local_spmm(self.reduce, s.rowptr, col, s.value, b_operand, None)
+    def spmm_only(self, b_operand, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Local kernel(s) on an already-assembled operand: all of B (full exchanges) or the
+        compacted rows (exchange "halo"), as `exchange_only` returns it — one tensor, or the
+        list of column slices of the sliced form (one kernel per slice, written in place)."""
+        slices = b_operand if isinstance(b_operand, (list, tuple)) else [b_operand]
+        F = sum(t.shape[1] for t in slices)
+        if out is None and self.keep_output:
+            out = self._buffer("out", (self.shard.num_rows, F), slices[0])
+        if len(slices) == 1:
+            return self._local(slices[0], out)
+        if out is None:
+            out = torch.empty((self.shard.num_rows, F), dtype=slices[0].dtype, device=slices[0].device)
+        c0 = 0
+        for t in slices:
+            self._local(t, out[:, c0:c0 + t.shape[1]])
+            c0 += t.shape[1]
+        return out
 
-    def exchange_only(self, b_local: torch.Tensor) -> torch.Tensor:
-        """The step's data movement alone (timing / reuse of B across SpMMs)."""
-        return self._exchange_slice(b_local, 0, b_local.shape[1], async_op=False)[1]
+    def exchange_only(self, b_local: torch.Tensor, feature_chunks: int = 1):
+        """The step's data movement alone (timing / reuse of B across SpMMs), slice after slice on
+        the caller's stream: the assembled operand, or the list of its column slices."""
+        F = b_local.shape[1]
+        if feature_chunks <= 1:
+            return self._exchange_slice(b_local, 0, F, async_op=False)[1]
+        bounds = [(F * c) // feature_chunks for c in range(feature_chunks + 1)]
+        return [self._exchange_slice(b_local, bounds[c], bounds[c + 1] - bounds[c], async_op=False, slot=c)[1]
+                for c in range(feature_chunks)]
+
+    # ---- autograd ------------------------------------------------------------------------
+    def apply(self, b_local: torch.Tensor) -> torch.Tensor:
+        """The step as a differentiable function of this rank's block of B (sum / mean, fixed
+        adjacency).  Forward = __call__; backward: every rank forms its block's contribution
+        A_r^T grad_out_r over the CSC view of its block (the planned forward of the transpose),
+        then the contributions go to the owners of the rows — ONE reduce_scatter_tensor of the
+        [world * nb, F] partial sums (full exchanges), or the halo exchange run backwards (rows go
+        back to the ranks they came from, which add them into their block by `send_idx`)."""
+        if self.reduce not in ("sum", "mean"):
+            raise NotImplementedError("RowPartitionedSpMM.apply differentiates sum / mean")
+        return _PartitionedSpMM.apply(b_local, self)
+
+    def _grad_operand(self, grad_out: torch.Tensor) -> torch.Tensor:
+        """A_r^T grad_out_r as an [operand height, F] matrix (rank-local)."""
+        s = self.shard
+        col, height = self._operand_cols()
+        if self._custom_spmm is not None or not grad_out.is_cuda:
+            # CPU / test hook: the transpose as an explicit CSR (structure from torch, values gathered), same kernel hook
+            deg = (s.rowptr[1:] - s.rowptr[:-1])
+            row = torch.repeat_interleave(torch.arange(s.num_rows, dtype=torch.int64, device=col.device), deg)
+            w = s.value if s.value is not None else torch.ones(col.numel(), dtype=grad_out.dtype, device=col.device)
+            if self.reduce == "mean":
+                w = w / deg.clamp(min=1).to(w.dtype)[row]
+            order = torch.sort(col, stable=True)[1]
+            colptr = torch.zeros(height + 1, dtype=torch.int64, device=col.device)
+            colptr[1:] = torch.cumsum(torch.bincount(col, minlength=height), 0)
+            fn = self._custom_spmm
+            if fn is None:
+                raise RuntimeError("RowPartitionedSpMM on CPU tensors needs the local_spmm hook")
+            return fn("sum", colptr, row[order].contiguous(), w[order].contiguous(), grad_out.contiguous(), None)
+        from .matmul import spmm_transposed_planned
+
+        return spmm_transposed_planned(self.local_storage(), s.value, grad_out.contiguous(), self.reduce == "mean")
+
+    def _backward(self, grad_out: torch.Tensor) -> torch.Tensor:
+        F, nb = grad_out.shape[1], self.block_rows
+        part = self._grad_operand(grad_out)  # [N, F] (full) or [num_needed, F] (halo)
+        if self.halo is None:
+            if part.shape[0] != self.world * nb:  # pad to whole blocks
+                padded = torch.zeros((self.world * nb, F), dtype=part.dtype, device=part.device)
+                padded[:part.shape[0]] = part
+                part = padded
+            grad_local = torch.empty((nb, F), dtype=part.dtype, device=part.device)
+            dist.reduce_scatter_tensor(grad_local, part.contiguous(), group=self.group)
+            return grad_local
+        h = self.halo
+        back = torch.empty((h.send_idx.numel(), F), dtype=part.dtype, device=part.device)
+        dist.all_to_all_single(back, part.contiguous(), output_split_sizes=h.send_counts, input_split_sizes=h.need_counts,
+                               group=self.group)
+        grad_local = torch.zeros((nb, F), dtype=part.dtype, device=part.device)
+        grad_local.index_add_(0, h.send_idx, back)  # a row may be asked for by several ranks
+        return grad_local
+
+
+class _PartitionedSpMM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, b_local, op: RowPartitionedSpMM):
+        ctx.op = op
+        keep = op.keep_output
+        op.keep_output = False  # autograd owns what it returns
+        try:
+            return op(b_local)
+        finally:
+            op.keep_output = keep
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        return ctx.op._backward(grad_out), None
 
 
 def gather_rows_to_root(out_local: torch.Tensor, bounds: List[int], group=None, dst: int = 0

@@ -40,9 +40,13 @@ def _csc_weights(st: SparseStorage, value: Optional[torch.Tensor], csr2csc, row_
     return w
 
 
-def _spmm_sum_planned(st: SparseStorage, weights: Optional[torch.Tensor], mat: torch.Tensor) -> torch.Tensor:
-    """spmm_sum of the matrix `st` describes (values `weights`, given separately) with the
-    storage's per-matrix choices: kernel family, COO row ids, compact copy of the hub rows."""
+def spmm_planned(st: SparseStorage, weights: Optional[torch.Tensor], mat: torch.Tensor, reduce: str = "sum",
+                 out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """reduce-SpMM of the matrix `st` describes (values `weights`, given separately; `out` only, no
+    arg_out) with the storage's per-matrix choices: kernel family, COO row ids, compact copy of
+    the hub rows.  Forward only (no autograd): the backward passes over the CSC view and the
+    rank-local step of the multi-GPU product (distributed.py) are built on it.  `out`: fp32
+    [M, K] to write into, possibly a column slice of a wider matrix."""
     algo = st._spmm_algo()
     col, row, hot_rows = st.col(), None, None
     lanes = 8 if mat.dtype in (torch.float16, torch.bfloat16) else 4  # elements per 16-byte lane of the edge-range kernels
@@ -53,7 +57,24 @@ def _spmm_sum_planned(st: SparseStorage, weights: Optional[torch.Tensor], mat: t
             hot_rows, col = ops._gather_rows_raw(mat, plan[0]), plan[1]
     else:
         algo = "auto"
-    return ops._spmm("sum", st.rowptr(), col, weights, mat, row=row, algo=algo, hot_rows=hot_rows)[0]
+    return ops._spmm(reduce, st.rowptr(), col, weights, mat, want_arg=False, row=row, algo=algo, hot_rows=hot_rows,
+                     out=out)[0]
+
+
+def _spmm_sum_planned(st: SparseStorage, weights: Optional[torch.Tensor], mat: torch.Tensor) -> torch.Tensor:
+    return spmm_planned(st, weights, mat, "sum")
+
+
+def spmm_transposed_planned(st: SparseStorage, value: Optional[torch.Tensor], grad_out: torch.Tensor,
+                            mean: bool = False) -> torch.Tensor:
+    """A^T grad_out for the matrix `st` describes (values given separately; mean: weights over the
+    row degree) — the gradient of spmm_sum / spmm_mean wrt the dense operand with a fixed adjacency:
+    a planned forward over the CSC view with the weights brought to CSC order (memoised on `st`)."""
+    csr2csc = st.csr2csc()  # leaves colptr and row[csr2csc] behind
+    w = None
+    if value is not None or mean:
+        w = _csc_weights(st, value, csr2csc, st._row_in_csc_order(), mean)
+    return spmm_planned(st._csc_view(), w, grad_out, "sum")
 
 
 class _SpMM(torch.autograd.Function):
@@ -191,14 +212,9 @@ class _SpMM(torch.autograd.Function):
                 grad_value = ops.spmm_value_bw(None, st.rowptr(), st.col(), mat, grad_out,
                                                "mean" if mean else "sum")
             if need_mat:
-                csr2csc = st.csr2csc()  # first: it leaves colptr and row[csr2csc] behind
-                row_csc = st._row_in_csc_order()
-                w = None
-                if value is not None or mean:
-                    w = _csc_weights(st, value, csr2csc, row_csc, mean)
                 # A^T grad_out = a forward SpMM over the CSC view, with that view's own choices
                 # (edge ranges and the hub-row copy when the transpose is a power-law matrix too)
-                grad_mat = _spmm_sum_planned(st._csc_view(), w, grad_out)
+                grad_mat = spmm_transposed_planned(st, value, grad_out, mean)
         return grad_value, grad_mat
 
 

@@ -242,7 +242,7 @@ LONG_ROW = 128
 # rows up to this many entries: the one-byte form of arg_out (arg_bytes) needs no arg_out beside it
 ARG_BYTES_EXACT_ROW = 128
 # ... and the two-byte form (want_arg_bytes=2)
-ARG_WORDS_EXACT_ROW = 65_536
+ARG_WORDS_EXACT_ROW = 65_535  # 0xffff is "no winner" (vec_io.h)
 
 
 def spmm_sum(rowptr, col, value, mat, row=None, algo="auto") -> torch.Tensor:

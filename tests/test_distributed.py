@@ -97,6 +97,43 @@ def _worker(rank, world, port, M, N, nnz, F, reduce, balance, result_path):
         dist.all_gather(counts, torch.tensor(h.need_counts))
         assert h.send_counts == [int(counts[q][rank]) for q in range(world)]
         assert np.array_equal(mine[h.col_local.numpy()], col[e0:e1])
+        # direct peer copies (full_p2p): the same bytes as the all-gather, the same bits out
+        p2p = pd.RowPartitionedSpMM(s, reduce=reduce, local_spmm=_oracle_local_spmm, exchange="full_p2p")
+        assert np.array_equal(p2p.exchange_only(b_local).numpy(), B)
+        assert np.array_equal(p2p(b_local).numpy(), out_local.numpy())
+        assert np.array_equal(p2p(b_local, feature_chunks=4).numpy(), out_local.numpy())
+        assert p2p.rows_received_per_step() == op.rows_received_per_step()
+
+        # steady state: every buffer a collective touches lives on the object — after the first
+        # step of a form no step allocates one again, and the second step's result is the first's
+        for o, chunks in ((op, 1), (op, 5), (p2p, 4), (halo, 1), (halo, 3)):
+            o(b_local, feature_chunks=chunks)
+            held, ptrs = o.buffer_bytes(), sorted(t.data_ptr() for t in o._bufs.values())
+            again = o(b_local, feature_chunks=chunks)
+            assert o.buffer_bytes() == held and sorted(t.data_ptr() for t in o._bufs.values()) == ptrs
+            assert np.array_equal(again.numpy(), out_local.numpy())
+        # keep_output: the result lives on the object too and is overwritten by the next call
+        kept = pd.RowPartitionedSpMM(s, reduce=reduce, local_spmm=_oracle_local_spmm, exchange="full", keep_output=True)
+        first = kept(b_local)
+        second = kept(b_local * 2)
+        assert first.data_ptr() == second.data_ptr() and np.array_equal(second.numpy(), kept(b_local * 2).numpy())
+        mine_out = torch.empty_like(out_local)
+        assert kept(b_local, out=mine_out).data_ptr() == mine_out.data_ptr()
+        assert np.array_equal(mine_out.numpy(), out_local.numpy())
+
+        # backward through the step (sum / mean): grad of this rank's block of B = its rows of A^T G
+        if reduce in ("sum", "mean"):
+            G = np.random.default_rng(9).standard_normal((M, F)).astype(np.float32)
+            w = val / np.maximum(np.diff(rowptr), 1)[row] if reduce == "mean" else val
+            want = np.zeros((world * nb, F), np.float64)
+            np.add.at(want, col, w[:, None].astype(np.float64) * G[row].astype(np.float64))
+            for o in (op, p2p, halo):
+                bl = b_local.clone().requires_grad_(True)
+                o.apply(bl).backward(torch.from_numpy(G[s.row_begin:s.row_end]))
+                np.testing.assert_allclose(bl.grad.numpy(), want[rank * nb:(rank + 1) * nb], rtol=1e-4, atol=1e-4)
+        else:
+            with pytest.raises(NotImplementedError):
+                op.apply(b_local)
         full = pd.gather_rows_to_root(out_local, bounds)
         if rank == 0:
             assert np.array_equal(full.numpy(), ref)
@@ -184,12 +221,17 @@ def test_row_partitioned_spmm_world1_on_the_device():
         row, rowptr, col, val = skewed_csr(M, N, seed=3, long_rows=(7, 2500), long_deg=4000)
         B = torch.from_numpy(np.random.default_rng(2).standard_normal((N, F)).astype(np.float32)).cuda()
         t_rowptr, t_col, t_val = (torch.from_numpy(x).cuda() for x in (rowptr, col, val))
+        from paddle_sparse_amd import SparseTensor
+
+        whole = SparseTensor(rowptr=t_rowptr, col=t_col, value=t_val, sparse_sizes=(M, N), is_sorted=True, trust_data=True)
         for reduce in ("sum", "mean", "max"):
-            want = ops._spmm(reduce, t_rowptr, t_col, t_val, B, want_arg=False)[0]
-            for exchange in ("full", "halo"):
+            with torch.no_grad():  # the single-GPU product: the same per-matrix plan the rank-local step takes
+                want = whole.matmul(B, reduce)
+            for exchange in ("full", "full_p2p", "halo"):
                 op = pd.RowPartitionedSpMM.from_global(t_rowptr, t_col, t_val, N, reduce=reduce, exchange=exchange)
                 b_local = op.local_dense_block(B)
                 assert torch.equal(op(b_local), want), (reduce, exchange)
+                assert torch.equal(op(b_local), want)  # second step: the object's buffers again
                 sliced = op(b_local, feature_chunks=4)  # K = 32 kernels: another summation order for sum / mean
                 if reduce == "max":
                     assert torch.equal(sliced, want)
@@ -198,6 +240,43 @@ def test_row_partitioned_spmm_world1_on_the_device():
                     assert bool(((sliced - want).abs() <= 1e-5 * S + 1e-30).all())
                 assert torch.equal(op.spmm_only(op.exchange_only(b_local)), want)
             assert op.halo.num_needed == int(torch.unique(t_col).numel()) and op.rows_received_per_step() == 0
+
+        # the rank-local step takes the block's per-matrix plan, like SparseTensor.matmul on one GPU:
+        # a power-law block (most rows empty or tiny, hub columns) runs the edge-range kernels on a
+        # compact copy of the hub rows; same bits as the tensor surface, which makes the same choices
+        rng = np.random.default_rng(11)
+        M2, N2, F2 = 40_000, 400_000, 64
+        deg = np.where(rng.random(M2) < 0.7, 0, rng.integers(1, 3, M2))
+        deg[::500] = 3000
+        rp = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+        hubs = rng.integers(0, N2, 50_000)  # the 50 000 ids drawn here take 60 % of the entries
+        c = np.where(rng.random(rp[-1]) < 0.6, hubs[rng.integers(0, hubs.size, rp[-1])], rng.integers(0, N2, rp[-1])).astype(np.int64)
+        v = rng.standard_normal(rp[-1]).astype(np.float32)
+        t_rp, t_c, t_v = (torch.from_numpy(x).cuda() for x in (rp, c, v))
+        B2 = torch.randn(N2, F2, device="cuda")
+        G2 = torch.randn(M2, F2, device="cuda")
+        tensor = SparseTensor(rowptr=t_rp, col=t_c, value=t_v, sparse_sizes=(M2, N2), is_sorted=True, trust_data=True)
+        for exchange in ("full", "halo"):
+            op = pd.RowPartitionedSpMM.from_global(t_rp, t_c, t_v, N2, exchange=exchange)
+            st = op.local_storage()
+            assert st._spmm_algo() == "edge_ranges" and tensor.storage._spmm_algo() == "edge_ranges"
+            if exchange == "full":
+                assert st._hot_columns() is not None
+            b_local = op.local_dense_block(B2)
+            Bg = B2.clone().requires_grad_(True)
+            want = tensor.matmul(Bg)
+            want.backward(G2)
+            assert torch.equal(op(b_local), want.detach())
+            raw = pd.RowPartitionedSpMM.from_global(t_rp, t_c, t_v, N2, exchange=exchange, plan=False)
+            S = ops._spmm("sum", t_rp, t_c, t_v.abs(), B2.abs())[0]
+            assert bool(((raw(b_local) - want.detach()).abs() <= 1e-5 * S + 1e-30).all())
+            # backward through the step: reduce_scatter (full) / the halo run backwards
+            bl = b_local.clone().requires_grad_(True)
+            op.apply(bl).backward(G2)
+            # |A|^T |G| bounds the rounding of either summation order
+            bound = 1e-5 * SparseTensor(rowptr=t_rp, col=t_c, value=t_v.abs(), sparse_sizes=(M2, N2), is_sorted=True,
+                                         trust_data=True).t().matmul(G2.abs()) + 1e-30
+            assert bool(((bl.grad[:N2] - Bg.grad).abs() <= bound).all())
     finally:
         dist.destroy_process_group()
 

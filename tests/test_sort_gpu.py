@@ -292,3 +292,47 @@ def test_huge_inputs_take_the_16384_key_tiles(n, bits):
     pay = torch.arange(n, dtype=torch.int32, device="cuda")
     out2, pay2 = ops.sort_pairs(keys, pay, 1 << bits)
     assert torch.equal(out2, out) and torch.equal(pay2.long(), perm)
+
+
+def test_a_sort_whose_lookback_gave_up_is_never_handed_back_as_an_order():
+    """VERDICT r02 #5.  The spin limit of the look-back is set to 0 (psa_sort_set_spin_limit): every
+    wait that does not succeed at its first poll gives up, which across ~500 concurrently running tiles
+    is certain.  Then (a) the fault word reads non-zero, (b) the last pass stored -1 over the outputs of
+    the tiles that ran after the fault instead of positions, (c) the callers whose result no host read
+    follows — the SparseStorage constructor sort and csr2csc — raise HipCoreError, as do the checked
+    forms of the ops and the count read behind a sort.  With the limit restored the same calls succeed
+    and give the stable order (the reference's argsort cannot return garbage: storage.py:164-169)."""
+    from paddle_sparse_amd import SparseStorage, _lib, ops
+    from paddle_sparse_amd._lib import HipCoreError
+
+    n, M = 4_000_000, 1 << 20
+    rng = np.random.default_rng(5)
+    row = rng.integers(0, M, n, dtype=np.int64)
+    col = rng.integers(0, M, n, dtype=np.int64)
+    keys = dev(row * M + col)
+    lib = _lib.load()
+    prev = lib.psa_sort_set_spin_limit(0)
+    try:
+        srt, perm, status = ops.index_sort_checked(keys, M * M)
+        assert status == 1
+        assert int((perm < 0).sum()) > 0 and int((srt < 0).sum()) > 0  # marked, not plausible
+        with pytest.raises(HipCoreError, match="gave up"):
+            ops.index_sort(keys, M * M, check=True)
+        with pytest.raises(HipCoreError, match="gave up"):
+            ops.sort_pairs(keys, torch.zeros(n, device="cuda"), M * M, check=True)
+        with pytest.raises(HipCoreError, match="gave up"):  # constructor sort, fp32 value rides the sort
+            SparseStorage(row=dev(row), col=dev(col), value=torch.ones(n, device="cuda"), sparse_sizes=(M, M))
+        with pytest.raises(HipCoreError, match="gave up"):  # constructor sort, permutation form
+            SparseStorage(row=dev(row), col=dev(col), value=torch.ones(n, 2, device="cuda"), sparse_sizes=(M, M))
+        lib.psa_sort_set_spin_limit(-1)
+        st = SparseStorage(row=dev(row), col=dev(col), sparse_sizes=(M, M))
+        lib.psa_sort_set_spin_limit(0)
+        with pytest.raises(HipCoreError, match="gave up"):
+            st.csr2csc()
+        assert st._csr2csc is None  # nothing half-built is kept
+    finally:
+        lib.psa_sort_set_spin_limit(prev)
+    assert lib.psa_sort_set_spin_limit(-1) == prev == 1 << 22
+    perm_ok = st.csr2csc().cpu().numpy()
+    col_sorted = st.col().cpu().numpy()
+    assert np.array_equal(perm_ok, np.argsort(col_sorted, kind="stable"))

@@ -1,0 +1,23 @@
+#!/bin/bash
+# rocprofv3 passes of round 3 (on the GPU box): bash tools/profile_r03.sh <what>
+#   backward   stats + FETCH_SIZE / WRITE_SIZE / TCC hit-miss passes of the CSC-view backward kernels at config 3
+#   breadth    stats of a bench.py run including c3_other_ops / power_law
+#   bench      stats of the headline bench.py run (no extra legs)
+set -e -o pipefail
+WHAT=$1
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+cd $REPO
+case $WHAT in
+  backward)
+    bash tools/prof_stats.sh r03_bw $REPO/tools/pmc_backward.py 10 | tee gpurun_out/r03_bw_stats.txt
+    for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"; do
+      tag=r03_bw_$(echo $c | tr ' ' '_' | cut -c1-24)
+      bash tools/prof_pmc.sh $tag "$c" $REPO/tools/pmc_backward.py 3 | tee gpurun_out/$tag.txt
+    done ;;
+  breadth)
+    bash tools/prof_stats.sh r03_breadth $REPO/bench.py --steps 20 --warmup 5 --no-cpu | tee gpurun_out/r03_breadth_stats.txt
+    cp gpurun_out/stats_r03_breadth/*/*_kernel_stats.csv gpurun_out/r03_kernel_stats_breadth.csv ;;
+  bench)
+    bash tools/prof_stats.sh r03_bench $REPO/bench.py --steps 40 --warmup 5 --no-cpu --no-extra | tee gpurun_out/r03_bench_stats.txt
+    cp gpurun_out/stats_r03_bench/*/*_kernel_stats.csv gpurun_out/r03_kernel_stats.csv ;;
+esac
