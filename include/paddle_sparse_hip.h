@@ -352,6 +352,11 @@ int psa_spmm_minmax_bw_eb(const int64_t* colptr, const int64_t* col_csc,
  * The gathered grad row serves both, mat[c, :] is the column's own row, and
  * value is read through csr2csc — so the separate psa_spmm_value_bw (a second
  * full gather, of mat rows) and psa_transpose_weights passes are not needed.
+ * csr2csc = NULL: `value` is in CSC order already (value[csr2csc], e.g. from
+ * psa_permute_apply_u32: 0.12 ms at 20 M entries) and is read as a stream — the
+ * nnz dependent 4-byte reads value[csr2csc[j]] were 18 % of this pass's memory
+ * requests (profiles/r03_pmc_backward.json).  psa_spmm_minmax_bw_csc takes the
+ * same convention when arg_out is NULL (the exact arg_bytes forms).
  * row_scale: f32[M] or NULL; with it both gradients carry the factor
  * row_scale[r] (mean: 1 / max(deg(r), 1), folded in per edge instead of a
  * pre-scaling pass over grad).
@@ -515,6 +520,25 @@ int psa_coalesce_small_fused(const int64_t* row, const int64_t* col,
 int psa_make_keys_checked(const int64_t* row, const int64_t* col, int64_t n,
                           int64_t M, int64_t N, int64_t* keys, int64_t* status,
                           psa_stream_t stream);
+
+/* ---- a 4-byte array through a FIXED permutation, planned ---------------------- */
+
+/* dst[i] = src[perm[i]] for 4-byte elements, n < 2^31, as two streaming passes over a plan
+ * built once per permutation (csrc/permute.hip) instead of n dependent 4-byte reads: the
+ * value[csr2csc] gathers of tensor.py:254-257 / transpose.py:19-22 and the way of grad_value
+ * from CSC back to CSR order.  T = psa_permute_tile() (32 768).
+ * Plan (structure only, 8 bytes per element), with dest = the INVERSE of perm (dest[s] = where
+ * source s goes), tile(s) = s / T, block(s) = dest[s] / T:
+ *   perm_ts  = stable sorting permutation of the keys tile(s) * ceil(n / T) + block(s)
+ *   perm_mid = stable sorting permutation of block(s);  gslot = its inverse
+ *   psa_permute_plan_pack(perm_ts, gslot, perm_mid, dest, n, sl, gs, lo):
+ *     sl: uint16[n], gs: int32[n], lo: uint16[n]
+ * psa_permute_apply_u32: mid = scratch of n 4-byte elements; src, mid, dst distinct. */
+int64_t psa_permute_tile(void);
+int psa_permute_plan_pack(const int64_t* perm_ts, const int64_t* gslot, const int64_t* perm_mid,
+                          const int64_t* dest, int64_t n, void* sl, void* gs, void* lo, psa_stream_t stream);
+int psa_permute_apply_u32(const void* src, const void* sl, const void* gs, const void* lo, int64_t n, void* mid,
+                          void* dst, psa_stream_t stream);
 
 /* Test/bench hook: scatter kernel variant of psa_index_sort for this process
  * (0 = production: single-sweep passes with decoupled look-back, 512 threads x

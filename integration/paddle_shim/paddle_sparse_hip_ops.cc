@@ -461,6 +461,43 @@ std::vector<paddle::Tensor> invert_permutation(paddle::Tensor& perm) {
 }
 PD_BUILD_OP(invert_permutation).Inputs({"perm"}).Outputs({"inv"}).SetKernelFn(PD_KERNEL(invert_permutation));
 
+// permute_plan_pack / permute_apply: a 4-byte array through a fixed permutation in two streaming
+// passes (value[csr2csc] of tensor.py:254-257 / transpose.py:19-22, grad_value's way back from
+// the pass over the CSC view).  The plan's sorts and inverse are the index_sort /
+// invert_permutation ops above, composed as paddle_sparse_amd/ops.py::permute_plan does.
+std::vector<paddle::Tensor> permute_plan_pack(paddle::Tensor& perm_ts, paddle::Tensor& gslot, paddle::Tensor& perm_mid,
+                                              paddle::Tensor& dest) {
+  CHECK_GPU(dest);
+  CHECK_I64(perm_ts);
+  CHECK_I64(gslot);
+  CHECK_I64(perm_mid);
+  CHECK_I64(dest);
+  const int64_t n = dest.numel();
+  auto sl = paddle::empty({n}, paddle::DataType::INT16, dest.place());
+  auto gs = paddle::empty({n}, paddle::DataType::INT32, dest.place());
+  auto lo = paddle::empty({n}, paddle::DataType::INT16, dest.place());
+  PSA_CALL(psa_permute_plan_pack(i64(perm_ts), i64(gslot), i64(perm_mid), i64(dest), n, sl.data(), gs.data(), lo.data(),
+                                 stream_of(dest)));
+  return {sl, gs, lo};
+}
+PD_BUILD_OP(permute_plan_pack)
+    .Inputs({"perm_ts", "gslot", "perm_mid", "dest"})
+    .Outputs({"sl", "gs", "lo"})
+    .SetKernelFn(PD_KERNEL(permute_plan_pack));
+
+std::vector<paddle::Tensor> permute_apply(paddle::Tensor& src, paddle::Tensor& sl, paddle::Tensor& gs, paddle::Tensor& lo) {
+  CHECK_GPU(src);
+  const int64_t n = src.numel();
+  PD_CHECK(n == sl.numel() && n == gs.numel() && n == lo.numel(), "permute_apply: the plan is for another length");
+  PD_CHECK(src.dtype() == paddle::DataType::FLOAT32 || src.dtype() == paddle::DataType::INT32,
+           "permute_apply takes 4-byte elements");
+  auto mid = paddle::empty({n}, src.dtype(), src.place());
+  auto out = paddle::empty({n}, src.dtype(), src.place());
+  PSA_CALL(psa_permute_apply_u32(src.data(), sl.data(), gs.data(), lo.data(), n, mid.data(), out.data(), stream_of(src)));
+  return {out};
+}
+PD_BUILD_OP(permute_apply).Inputs({"src", "sl", "gs", "lo"}).Outputs({"out"}).SetKernelFn(PD_KERNEL(permute_apply));
+
 // make_keys / split_keys: row * N + col and back (storage.py:159-163, 166-168)
 std::vector<paddle::Tensor> make_keys(paddle::Tensor& a, paddle::Tensor& b, int64_t mul) {
   CHECK_GPU(a);

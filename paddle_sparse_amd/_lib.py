@@ -99,6 +99,10 @@ SIGNATURES = {
     "psa_gather_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "psa_gather_rows_window": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     "psa_invert_permutation": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "psa_permute_tile": (c_int64, []),
+    "psa_permute_plan_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                      c_void_p]),
+    "psa_permute_apply_u32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "psa_bincount": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "psa_count2ptr_workspace_bytes": (c_size_t, [c_int64]),
     "psa_count2ptr": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),

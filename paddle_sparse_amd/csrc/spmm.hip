@@ -183,8 +183,12 @@ __device__ __forceinline__ void reduce_edge_range(
     if (lane < n) {
       c_l = col[base + lane];
       if (INDIRECT) {
-        id_l = m.edge_id[base + lane];
-        v_l = val ? val[id_l] : 1.f;
+        if (m.edge_id) {  // values in CSR order, read through the entry's CSR id
+          id_l = m.edge_id[base + lane];
+          v_l = val ? val[id_l] : 1.f;
+        } else {  // values handed over in CSC order already (psa_permute_apply_u32): a stream
+          v_l = val ? val[base + lane] : 1.f;
+        }
         if (MODE == M_CSC && m.row_scale) s_l = m.row_scale[c_l];  // multiplied in where the weight is consumed
         if (MASK) {  // the tag rides in the top bits of the edge id (ids stay below 2^48)
           if (AW == 2) id_l |= static_cast<int64_t>(reinterpret_cast<const uint16_t*>(m.tag)[base + lane]) << 48;
@@ -1275,7 +1279,9 @@ int psa_spmm_minmax_bw_csc(const int64_t* rowptr, const int64_t* colptr,
     return PSA_ERR_UNSUPPORTED;
   }
   PSA_REQUIRE(colptr && grad_mat, "NULL pointer");
-  PSA_REQUIRE(nnz == 0 || (rowptr && row_csc && csr2csc && tag && grad), "NULL pointer");
+  PSA_REQUIRE(nnz == 0 || (rowptr && row_csc && tag && grad), "NULL pointer");
+  PSA_REQUIRE(nnz == 0 || csr2csc != nullptr || arg_out == nullptr,
+              "csr2csc = NULL (value in CSC order) goes with the exact arg_bytes forms only: arg_out is compared with CSR edge ids");
   PSA_REQUIRE(nnz == 0 || arg_out != nullptr || arg_bytes != nullptr, "arg_out and arg_bytes are both NULL");
   PSA_REQUIRE(arg_width == 1 || arg_width == 2, "arg_width must be 1 or 2");
   PSA_REQUIRE(arg_bytes == nullptr || psa::aligned(arg_bytes, 4 * arg_width), "arg_bytes alignment");
@@ -1372,7 +1378,7 @@ int psa_spmm_sum_bw_csc(const int64_t* colptr, const int64_t* row_csc, const int
     return PSA_ERR_UNSUPPORTED;
   }
   PSA_REQUIRE(colptr && grad_mat, "NULL pointer");
-  PSA_REQUIRE(nnz == 0 || (row_csc && csr2csc && grad), "NULL pointer");
+  PSA_REQUIRE(nnz == 0 || (row_csc && grad), "NULL pointer");  // csr2csc = NULL: value is in CSC order already
   PSA_REQUIRE(grad_value == nullptr || mat != nullptr || nnz == 0, "grad_value needs mat");
   PSA_REQUIRE(max_long_chunks(nnz) < (1ll << 32), "too many chunks");
   if (workspace == nullptr || workspace_bytes < psa_spmm_sum_bw_csc_workspace_bytes(K, nnz)) {

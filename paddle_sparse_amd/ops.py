@@ -671,6 +671,58 @@ def invert_permutation(perm: torch.Tensor) -> torch.Tensor:
     return inv
 
 
+class PermutePlan:
+    """Route of every element of a 4-byte array through a fixed permutation (psa_permute_apply_u32):
+    structure only, 8 bytes per element; built by permute_plan, cached by the caller."""
+
+    def __init__(self, sl, gs, lo, n):
+        self.sl, self.gs, self.lo, self.n = sl, gs, lo, n
+
+
+PERMUTE_PLAN_FROM = 1 << 20  # elements from which the planned two-pass form beats n dependent 4-byte reads
+
+
+def permute_plan(dest: torch.Tensor) -> PermutePlan:
+    """Plan for out[i] = src[perm[i]] given dest = the INVERSE of perm (dest[s] = where source s
+    goes; csr2csc / csc2csr are each other's).  Two stable sorts, one inverse, one pack pass — once
+    per permutation (see include/paddle_sparse_hip.h)."""
+    dest = _index(dest, "dest")
+    n, dev = dest.numel(), dest.device
+    if n >= (1 << 31):
+        raise ValueError("permute_plan: n must be below 2^31")
+    lib = _lib.load()
+    T = int(lib.psa_permute_tile())
+    nb = max((n + T - 1) // T, 1)
+    block, _ = split_keys(dest, T, want_lo=False)
+    tile, _ = split_keys(torch.arange(n, dtype=torch.int64, device=dev), T, want_lo=False)
+    keys_ts, _ = make_keys(tile, block, nb)
+    del tile
+    _, perm_ts = index_sort(keys_ts, nb * nb, check=True)
+    del keys_ts
+    _, perm_mid = index_sort(block, nb, check=True)
+    del block
+    gslot = invert_permutation(perm_mid)
+    sl = torch.empty(n, dtype=torch.int16, device=dev)
+    gs = torch.empty(n, dtype=torch.int32, device=dev)
+    lo = torch.empty(n, dtype=torch.int16, device=dev)
+    with _on(dev):
+        check(lib.psa_permute_plan_pack(_ptr(perm_ts), _ptr(gslot), _ptr(perm_mid), _ptr(dest), n, _ptr(sl), _ptr(gs),
+                                        _ptr(lo), _stream()))
+    return PermutePlan(sl, gs, lo, n)
+
+
+def permute_apply(src: torch.Tensor, plan: PermutePlan) -> torch.Tensor:
+    """src[perm] for a contiguous 1-D 4-byte array along the plan of `perm` (no autograd)."""
+    _gpu(src, "src")
+    if src.dim() != 1 or src.element_size() != 4 or src.numel() != plan.n or not src.is_contiguous():
+        raise ValueError("permute_apply takes a contiguous 1-D array of 4-byte elements, one per planned element")
+    out, mid = torch.empty_like(src), torch.empty_like(src)
+    with _on(src.device):
+        check(_lib.load().psa_permute_apply_u32(_ptr(src), _ptr(plan.sl), _ptr(plan.gs), _ptr(plan.lo), plan.n, _ptr(mid),
+                                                _ptr(out), _stream()))
+    return out
+
+
 class _SegmentCsr(torch.autograd.Function):
     """segment_csr with paddle_scatter's differentiability for sum / mean (the
     coalesce and reduce(dim) call sites, storage.py:471, reduce.py:51): every
@@ -860,7 +912,8 @@ def minmax_bw_csc_supported(K: int) -> bool:
 
 def spmm_minmax_bw_csc(rowptr, colptr, row_csc, csr2csc, tag, value, mat, grad, arg_out,
                        want_value: bool = True, csc2csr: Optional[torch.Tensor] = None,
-                       arg_bytes: Optional[torch.Tensor] = None, hot_ids: Optional[torch.Tensor] = None):
+                       arg_bytes: Optional[torch.Tensor] = None, hot_ids: Optional[torch.Tensor] = None,
+                       to_csr_plan: Optional["PermutePlan"] = None, value_csc: Optional[torch.Tensor] = None):
     """Backward of spmm_min / spmm_max in one pass over the CSC view, no atomics
     (see include/paddle_sparse_hip.h).  Returns (grad_value f32[nnz] | None,
     grad_mat f32[N, K]); grad_value is in CSR order (the pass writes it in CSC
@@ -878,6 +931,11 @@ def spmm_minmax_bw_csc(rowptr, colptr, row_csc, csr2csc, tag, value, mat, grad, 
         arg_out = arg_out.contiguous()
     if value is not None:
         value = _f32(value, "value")
+    edge_ids = csr2csc
+    if value_csc is not None:
+        if arg_out is not None:
+            raise ValueError("value_csc goes with the exact arg_bytes forms (arg_out is compared with CSR edge ids)")
+        value, edge_ids = _f32(value_csc, "value_csc"), None
     _gpu(tag, "tag")
     if tag.dtype not in (torch.uint8, torch.int16) or tag.numel() != csr2csc.numel():
         raise ValueError("tag must be uint8[nnz] or int16[nnz] (ops.csc_edge_tags)")
@@ -907,13 +965,16 @@ def spmm_minmax_bw_csc(rowptr, colptr, row_csc, csr2csc, tag, value, mat, grad, 
     lib = _lib.load()
     ws = _workspace(lib.psa_spmm_minmax_bw_csc_workspace_bytes(M, K, nnz), grad.device)
     with _on(grad.device):
-        check(lib.psa_spmm_minmax_bw_csc(_ptr(rowptr), _ptr(colptr), _ptr(row_csc), _ptr(csr2csc),
+        check(lib.psa_spmm_minmax_bw_csc(_ptr(rowptr), _ptr(colptr), _ptr(row_csc), _ptr(edge_ids),
                                          _ptr(tag.contiguous()), _ptr(value),
                                          _ptr(mat) if want_value else None, _ptr(grad), _ptr(arg_out),
                                          _ptr(arg_bytes), width, _ptr(hot_grad), _ptr(hot_bytes), num_hot,
                                          M, N, K, nnz, _ptr(gv), _ptr(gm), _ptr(ws), ws.numel(), _stream()))
     if gv is not None:
-        gv = gather_rows(gv, csc2csr if csc2csr is not None else invert_permutation(csr2csc))
+        if to_csr_plan is not None:
+            gv = permute_apply(gv, to_csr_plan)
+        else:
+            gv = gather_rows(gv, csc2csr if csc2csr is not None else invert_permutation(csr2csc))
     return gv, gm
 
 
@@ -952,7 +1013,8 @@ def spmm_minmax_bw_eb(colptr, col_csc, row_csc, tag, weight_csc, grad, arg_bytes
 
 def spmm_sum_bw_csc(colptr, row_csc, csr2csc, value, mat, grad, want_value: bool = True,
                     csc2csr: Optional[torch.Tensor] = None, row_scale: Optional[torch.Tensor] = None,
-                    hot_ids: Optional[torch.Tensor] = None):
+                    hot_ids: Optional[torch.Tensor] = None, to_csr_plan: Optional["PermutePlan"] = None,
+                    value_csc: Optional[torch.Tensor] = None):
     """sum backward, both gradients in one pass over the CSC view (see
     include/paddle_sparse_hip.h).  Returns (grad_value f32[nnz] | None, in CSR
     order, grad_mat f32[N, K]).  For mean, pass row_scale = 1 / max(deg, 1)
@@ -963,6 +1025,10 @@ def spmm_sum_bw_csc(colptr, row_csc, csr2csc, value, mat, grad, want_value: bool
     if value is not None:
         value = _f32(value, "value")
     (M, K), N, nnz = grad.shape, colptr.numel() - 1, csr2csc.numel()
+    if value_csc is not None:  # value[csr2csc] at hand (SparseStorage._permute_plan("to_csc")): the pass reads it as a stream
+        value, edge_ids = _f32(value_csc, "value_csc"), None
+    else:
+        edge_ids = csr2csc
     hot_grad, num_hot = None, 0
     if hot_ids is not None and hot_ids.numel():
         hot_ids = _index(hot_ids, "hot_ids")
@@ -984,12 +1050,15 @@ def spmm_sum_bw_csc(colptr, row_csc, csr2csc, value, mat, grad, want_value: bool
     lib = _lib.load()
     ws = _workspace(lib.psa_spmm_sum_bw_csc_workspace_bytes(K, nnz), grad.device)
     with _on(grad.device):
-        check(lib.psa_spmm_sum_bw_csc(_ptr(colptr), _ptr(row_csc), _ptr(csr2csc), _ptr(value),
+        check(lib.psa_spmm_sum_bw_csc(_ptr(colptr), _ptr(row_csc), _ptr(edge_ids), _ptr(value),
                                       _ptr(row_scale), _ptr(mat) if want_value else None, _ptr(grad),
                                       _ptr(hot_grad), num_hot, M, N, K, nnz,
                                       _ptr(gv), _ptr(gm), _ptr(ws), ws.numel(), _stream()))
     if gv is not None:
-        gv = gather_rows(gv, csc2csr if csc2csr is not None else invert_permutation(csr2csc))
+        if to_csr_plan is not None:
+            gv = permute_apply(gv, to_csr_plan)
+        else:
+            gv = gather_rows(gv, csc2csr if csc2csr is not None else invert_permutation(csr2csc))
     return gv, gm
 
 

@@ -124,6 +124,7 @@ class SparseStorage(object):
         self._value_csc_memo = None  # (value, version, value[csr2csc]): see _value_in_csc_order
         self._hot_memo = None  # False | (hot column ids, col redirected into the compact copy): see _hot_columns
         self._csc_view_memo = None  # SparseStorage of the transpose over the CSC caches: see _csc_view
+        self._perm_plans = {}  # "to_csr" / "to_csc": planned routes of a 4-byte array between the two orders
 
         # storage.py:158-171 — sort by (row, col) unless told it is sorted
         if not is_sorted and nnz > 0:
@@ -326,6 +327,23 @@ class SparseStorage(object):
                                                 is_sorted=True, trust_data=True)
         return self._csc_view_memo
 
+    def _permute_plan(self, direction: str):
+        """Planned route (ops.PermutePlan, structure only, memoised) of an nnz-sized 4-byte array
+        between CSR and CSC order — "to_csc": out[j] = src[csr2csc[j]] (value[csr2csc],
+        tensor.py:254-257), "to_csr": out[i] = src[csc2csr[i]] (grad_value's way back from the
+        pass over the CSC view).  None below ops.PERMUTE_PLAN_FROM entries, where the plain gather
+        is as fast (everything is cache resident) and the plan's 8 bytes per entry buy nothing."""
+        nnz = self._col.numel()
+        if nnz < ops.PERMUTE_PLAN_FROM or nnz >= (1 << 31):
+            return None
+        plans = getattr(self, "_perm_plans", None)
+        if plans is None:
+            plans = self._perm_plans = {}
+        if direction not in plans:
+            # dest = the inverse of the gather's index array
+            plans[direction] = ops.permute_plan(self.csc2csr() if direction == "to_csc" else self.csr2csc())
+        return plans[direction]
+
     def _longest_row(self) -> int:
         """Entries of the longest row (memoised; the min/max forward asks whether
         the one-byte form of arg_out is complete, i.e. no row above 128)."""
@@ -350,7 +368,8 @@ class SparseStorage(object):
         if (memo is not None and memo[0] is value and memo[1] == value._version
                 and memo[2]._version == memo[3]):  # neither side written in place since
             return memo[2]
-        out = ops.gather_rows(value, perm)
+        plan = self._permute_plan("to_csc") if (value.dim() == 1 and value.element_size() == 4) else None
+        out = ops.permute_apply(value.contiguous(), plan) if plan is not None else ops.gather_rows(value, perm)
         self._value_csc_memo = (value, value._version, out, out._version)
         return out
 
@@ -448,6 +467,7 @@ class SparseStorage(object):
         self._value_csc_memo = None
         self._hot_memo = None
         self._csc_view_memo = None
+        self._perm_plans = {}
         return self
 
     def cached_keys(self) -> List[str]:
@@ -469,6 +489,7 @@ class SparseStorage(object):
             out._spmm_algo_memo = self._spmm_algo_memo
             out._hot_memo = self._hot_memo
             out._csc_view_memo = self._csc_view_memo
+            out._perm_plans = self._perm_plans
         return out
 
     def _map(self, fn: Callable[[torch.Tensor], torch.Tensor]):

@@ -80,6 +80,41 @@ out.update({"co_row": row, "co_col": col, "co_val": val, "co_shape": np.array([m
 for op, tr in (("add", "sum"), ("mean", "mean"), ("min", "min"), ("max", "max")):
     out[f"co_{op}"] = torch.segment_reduce(torch.tensor(val)[perm], tr, offsets=offsets, axis=0).numpy()
 
+# ---- spspmm: scipy.sparse CSR @ CSR on seeded matrices (README.md:308-353 holds one 3 x 3 vector) ------------
+# float64 products and sums inside scipy, results frozen in float64; the tests hold fp32 results to
+# 1e-5 * (|A| @ |B|) and the index structure exactly.  Integer-valued operands give exact answers.
+import scipy.sparse as sp  # noqa: E402
+
+for tag, (m, k, n, nnzA, nnzB, integer) in {"a": (60, 50, 70, 400, 500, False), "b": (200, 33, 150, 1500, 900, False),
+                                           "c": (45, 45, 45, 300, 300, True)}.items():
+    def draw(rows, cols, nnz):
+        key = np.unique(rng.integers(0, rows * cols, nnz))
+        r, c = key // cols, key % cols
+        v = (rng.integers(-4, 5, key.size).astype(np.float32) if integer
+             else rng.standard_normal(key.size).astype(np.float32))
+        v[v == 0] = 1  # explicit zeros would make "stored entries" ambiguous between implementations
+        return r.astype(np.int64), c.astype(np.int64), v
+
+    ra, ca, va = draw(m, k, nnzA)
+    rb, cb, vb = draw(k, n, nnzB)
+    A = sp.csr_matrix((va.astype(np.float64), (ra, ca)), shape=(m, k))
+    Bm = sp.csr_matrix((vb.astype(np.float64), (rb, cb)), shape=(k, n))
+    # The stored structure of the product is the STRUCTURAL one (every (i, j) with some A[i, c] and B[c, j] stored):
+    # upstream keeps an entry whose terms cancel, scipy's csr_matmat drops it — so the structure comes from
+    # |A| @ |B| (nothing cancels) and the values from scipy's A @ B read at those positions (0 where it dropped one).
+    C = (A @ Bm).tocsr()
+    S = (abs(A) @ abs(Bm)).tocsr()
+    S.sort_indices()
+    Sc = S.tocoo()
+    value = np.asarray(C[Sc.row, Sc.col]).ravel()
+    dense = A.toarray() @ Bm.toarray()
+    assert np.allclose(value, dense[Sc.row, Sc.col], rtol=1e-12, atol=1e-12)
+    out.update({f"spspmm_{tag}_shape": np.array([m, k, n]), f"spspmm_{tag}_indexA": np.stack([ra, ca]),
+                f"spspmm_{tag}_valueA": va, f"spspmm_{tag}_indexB": np.stack([rb, cb]), f"spspmm_{tag}_valueB": vb,
+                f"spspmm_{tag}_index": np.stack([Sc.row.astype(np.int64), Sc.col.astype(np.int64)]),
+                f"spspmm_{tag}_value": value, f"spspmm_{tag}_abs": S.data.copy(),
+                f"spspmm_{tag}_cancelled": np.array([int((value == 0).sum())])})
+
 path = Path(__file__).resolve().parent / "third_party.npz"
 np.savez_compressed(path, **out)
 print(path, f"{path.stat().st_size / 1024:.0f} KiB,", len(out), "arrays")

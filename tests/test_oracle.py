@@ -425,3 +425,18 @@ def test_oracle_reduce_and_coalesce_vs_golden(golden):
         ci, cv = oracle.coalesce_c(g["co_row"], g["co_col"], g["co_val"], m, n, op)[:2]
         assert np.array_equal(ci, g["co_index"])
         np.testing.assert_allclose(cv, g[f"co_{op}"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_oracle_spspmm_vs_golden(golden, tag):
+    """scipy.sparse CSR @ CSR on seeded matrices (tests/golden/make_golden.py): the structural product —
+    entries whose terms cancel stay stored (tag c holds 22 of them) — and its values to 1e-5 * (|A| @ |B|).
+    The reference holds one 3 x 3 vector for spspmm (README.md:308-353)."""
+    g = golden
+    m, k, n = (int(x) for x in g[f"spspmm_{tag}_shape"])
+    index, value = oracle.spspmm(g[f"spspmm_{tag}_indexA"], g[f"spspmm_{tag}_valueA"], g[f"spspmm_{tag}_indexB"],
+                                 g[f"spspmm_{tag}_valueB"], m, k, n)
+    assert np.array_equal(index, g[f"spspmm_{tag}_index"])
+    assert np.all(np.abs(value - g[f"spspmm_{tag}_value"]) <= 1e-5 * g[f"spspmm_{tag}_abs"] + 1e-30)
+    if tag == "c":  # integer-valued operands: exact, cancelled entries are stored zeros
+        assert np.array_equal(value, g[f"spspmm_{tag}_value"]) and int((value == 0).sum()) == int(g["spspmm_c_cancelled"][0]) > 0

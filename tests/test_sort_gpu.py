@@ -336,3 +336,55 @@ def test_a_sort_whose_lookback_gave_up_is_never_handed_back_as_an_order():
     perm_ok = st.csr2csc().cpu().numpy()
     col_sorted = st.col().cpu().numpy()
     assert np.array_equal(perm_ok, np.argsort(col_sorted, kind="stable"))
+
+
+@pytest.mark.parametrize("n", [1, 5, 32_767, 32_768, 32_769, 100_003, 3 * 32_768 + 5, 2_500_000])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.int32])
+def test_planned_permutation_equals_the_gather(n, dtype):
+    """ops.permute_apply(src, plan of perm) == src[perm] bit for bit: random permutations, sizes
+    around the 32 768-element tile, a last partial tile / block, and structured permutations
+    (identity, reversal, a transpose-like stride) whose blocks receive from one or from every tile."""
+    from paddle_sparse_amd import ops
+
+    rng = np.random.default_rng(n)
+    perms = [rng.permutation(n), np.arange(n), np.arange(n)[::-1].copy()]
+    if n > 1000:
+        w = 257
+        idx = np.arange(n)
+        perms.append(np.argsort((idx % w) * (n // w + 1) + idx // w, kind="stable"))
+    src = dev(rng.integers(-2**31, 2**31 - 1, n).astype(np.int32)).view(dtype)
+    for perm in perms:
+        perm = perm.astype(np.int64)
+        inv = np.empty_like(perm)
+        inv[perm] = np.arange(n)
+        plan = ops.permute_plan(dev(inv))
+        got = ops.permute_apply(src, plan)
+        assert torch.equal(got.view(torch.int32), src.view(torch.int32)[dev(perm)])
+    with pytest.raises(ValueError):
+        ops.permute_apply(torch.zeros(n + 1, device="cuda"), plan)
+
+
+def test_storage_plans_route_values_between_csr_and_csc_order():
+    """SparseStorage._permute_plan: "to_csc" = value[csr2csc], "to_csr" = its inverse; None below
+    ops.PERMUTE_PLAN_FROM entries.  The one-pass backward gives the same bits with the plan as with
+    the gather through csc2csr."""
+    from paddle_sparse_amd import SparseStorage, ops
+
+    M, N, nnz, K = 300_000, 200_000, 1_200_000, 32
+    rng = np.random.default_rng(3)
+    row = np.sort(rng.integers(0, M, nnz)).astype(np.int64)
+    col = rng.integers(0, N, nnz).astype(np.int64)
+    val = torch.randn(nnz, device="cuda")
+    st = SparseStorage(row=dev(row), col=dev(col), value=val, sparse_sizes=(M, N), is_sorted=True, trust_data=True)
+    to_csc, to_csr = st._permute_plan("to_csc"), st._permute_plan("to_csr")
+    assert to_csc is not None and st._permute_plan("to_csc") is to_csc
+    v_csc = ops.permute_apply(val, to_csc)
+    assert torch.equal(v_csc, val[st.csr2csc()])
+    assert torch.equal(ops.permute_apply(v_csc, to_csr), val)
+    B, G = torch.randn(N, K, device="cuda"), torch.randn(M, K, device="cuda")
+    args = (st.colptr(), st._row_in_csc_order(), st.csr2csc(), val, B, G, True)
+    gv0, gm0 = ops.spmm_sum_bw_csc(*args, csc2csr=st.csc2csr())
+    gv1, gm1 = ops.spmm_sum_bw_csc(*args, csc2csr=st.csc2csr(), to_csr_plan=to_csr)
+    assert torch.equal(gv0, gv1) and torch.equal(gm0, gm1)
+    small = SparseStorage(row=dev(row[:1000]), col=dev(col[:1000]), sparse_sizes=(M, N), is_sorted=True, trust_data=True)
+    assert small._permute_plan("to_csr") is None

@@ -122,3 +122,25 @@ def test_square_of_a_graph_matches_dense():
     got = np.zeros_like(ref)
     got[idx[0].cpu().numpy(), idx[1].cpu().numpy()] = val.cpu().numpy()
     np.testing.assert_allclose(got, ref, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_vs_frozen_scipy_products(tag, dtype):
+    """tests/golden/third_party.npz: scipy.sparse CSR @ CSR on seeded matrices, structural product
+    (entries whose terms cancel stay stored), float64 answers; both routes of the HIP path — the
+    column walk for 4-byte values and the row-order walk for 8-byte ones — are held to them."""
+    from pathlib import Path
+
+    from paddle_sparse_amd import spspmm
+
+    g = np.load(Path(__file__).resolve().parent / "golden" / "third_party.npz")
+    m, k, n = (int(x) for x in g[f"spspmm_{tag}_shape"])
+    idx, val = spspmm(dev(g[f"spspmm_{tag}_indexA"]), dev(g[f"spspmm_{tag}_valueA"], dtype),
+                      dev(g[f"spspmm_{tag}_indexB"]), dev(g[f"spspmm_{tag}_valueB"], dtype), m, k, n)
+    assert np.array_equal(idx.cpu().numpy(), g[f"spspmm_{tag}_index"])
+    got, want, scale = val.cpu().numpy().astype(np.float64), g[f"spspmm_{tag}_value"], g[f"spspmm_{tag}_abs"]
+    tol = 1e-5 if dtype == torch.float32 else 1e-12
+    assert np.all(np.abs(got - want) <= tol * scale + 1e-30)
+    if tag == "c":  # integer-valued operands: exact in either width
+        assert np.array_equal(got, want) and int((got == 0).sum()) == int(g["spspmm_c_cancelled"][0])

@@ -17,6 +17,13 @@ case $WHAT in
   breadth)
     bash tools/prof_stats.sh r03_breadth $REPO/bench.py --steps 20 --warmup 5 --no-cpu | tee gpurun_out/r03_breadth_stats.txt
     cp gpurun_out/stats_r03_breadth/*/*_kernel_stats.csv gpurun_out/r03_kernel_stats_breadth.csv ;;
+  sort)
+    bash tools/prof_stats.sh r03_sort $REPO/tools/pmc_sort.py | tee gpurun_out/r03_sort_stats.txt
+    for c in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INST_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
+             "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_ANY" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INST_CYCLES_VMEM"; do
+      tag=r03_sort_$(echo $c | tr ' ' '_' | cut -c1-28)
+      bash tools/prof_pmc.sh $tag "$c" $REPO/tools/pmc_sort.py | grep -A8 "os_pass_kernel<false, false" | tee -a gpurun_out/r03_sort_pmc.txt
+    done ;;
   bench)
     bash tools/prof_stats.sh r03_bench $REPO/bench.py --steps 40 --warmup 5 --no-cpu --no-extra | tee gpurun_out/r03_bench_stats.txt
     cp gpurun_out/stats_r03_bench/*/*_kernel_stats.csv gpurun_out/r03_kernel_stats.csv ;;
