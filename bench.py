@@ -165,22 +165,40 @@ def breadth(rowptr, col, val, B, reps: int):
     survey_bwd = algorithmic_bytes(nnz, N, F, True, False) + nnz * 16 + nnz * (8 + 8 + 8 * F + 4)
     out = {}
 
-    def put(name, ms, nbytes, survey=None):
-        out[name] = {"ms": round(ms, 4), "gedges_per_s": round(nnz / ms / 1e6, 3),
-                     "algorithmic_gb": round(nbytes / 1e9, 3), "frac_of_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    WARM_MS = 60.0  # every leg runs this long untimed first: the same warm-up for all (see below)
+
+    def put(name, fn, nbytes, survey=None, n=reps, cold=False):
+        """Times fn over n launches after WARM_MS of untimed launches.  The shader clock ramps for ~40 ms after
+        the chip has idled (profiles/r03_warmup_probe.txt: the drift comes back after 2 s of idle, not after
+        empty_cache or with fresh operands); the fp32 kernels do not feel it, the half-width one does (0.98 ->
+        0.88 ms over its first 40 launches).  cold=True also records the first 10 launches after 1 s of idle."""
+        rec = {}
+        if cold:
+            fn()
+            torch.cuda.synchronize()
+            time.sleep(1.0)
+            rec["ms_first_10_launches_after_1s_idle"] = round(event_ms(fn, 10), 4)
+        fn()
+        torch.cuda.synchronize()
+        t_w = time.perf_counter()
+        while (time.perf_counter() - t_w) * 1e3 < WARM_MS:
+            for _ in range(5):
+                fn()
+            torch.cuda.synchronize()
+        ms = event_ms(fn, n)
+        rec.update({"ms": round(ms, 4), "gedges_per_s": round(nnz / ms / 1e6, 3),
+                    "algorithmic_gb": round(nbytes / 1e9, 3), "frac_of_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4)})
         if survey is not None:
-            out[name]["survey_model_gb"] = round(survey / 1e9, 3)
+            rec["survey_model_gb"] = round(survey / 1e9, 3)
+        out[name] = rec
 
     for op, nb in (("spmm_mean", fwd), ("spmm_max", fwd_arg)):
         fn = getattr(ops, op)
-        fn(rowptr, col, val, B)
-        put(f"{op}_fwd", event_ms(lambda: fn(rowptr, col, val, B), reps), nb)
+        put(f"{op}_fwd", lambda: fn(rowptr, col, val, B), nb)
     # half-width dense operand (bf16 B and out, fp32 sums): 2 F of every (12 + 2 F) bytes per edge
     Bh = B.to(torch.bfloat16)
     half_bytes = nnz * (8 + 4 + 2 * F) + M * (8 + 2 * F)
-    for _ in range(40):  # this kernel's time settles over its first ~40 launches (0.97 -> 0.88 ms; the fp32 ones do not drift:
-        ops._spmm("sum", rowptr, col, val, Bh)  # profiles/r02_half_variants.txt, tools/warmup_probe.py)
-    put("spmm_sum_bf16_fwd", event_ms(lambda: ops._spmm("sum", rowptr, col, val, Bh), reps), half_bytes)
+    put("spmm_sum_bf16_fwd", lambda: ops._spmm("sum", rowptr, col, val, Bh), half_bytes, cold=True)
     del Bh
     row = ops.ptr2ind(rowptr, nnz)
     G = torch.randn(M, F, device=B.device)
@@ -194,8 +212,21 @@ def breadth(rowptr, col, val, B, reps: int):
         a.matmul(Bt, reduce).backward(G)
 
     for reduce, nb, sv in (("sum", fwd + bwd, fwd + survey_bwd), ("max", fwd + M * F + bwd_minmax, fwd_arg + survey_bwd)):
-        fwd_bwd(reduce)
-        put(f"spmm_{reduce}_fwd_bwd", event_ms(lambda: fwd_bwd(reduce), max(3, reps // 4)), nb, sv)
+        put(f"spmm_{reduce}_fwd_bwd", lambda: fwd_bwd(reduce), nb, sv, n=max(3, reps // 4))
+    # trained values with a half-width dense operand: half-width forward, ONE half-width pass over the CSC view for
+    # both gradients (psa_spmm_half_sum_bw_csc), value[csr2csc] and grad_value's way back along planned routes
+    vb = val.clone().requires_grad_()
+    Bb = B.detach().to(torch.bfloat16, copy=True).requires_grad_()
+    Gb = G.to(torch.bfloat16)
+    ab = SparseTensor(row=row, rowptr=rowptr, col=col, value=vb, sparse_sizes=(M, N), is_sorted=True, trust_data=True)
+
+    def half_step():
+        vb.grad = Bb.grad = None
+        ab.matmul(Bb, "sum").backward(Gb)
+
+    half_bwd = nnz * (8 + 4 + 16 + 2 * F + 4 + 16) + N * (8 + 4 * F)
+    put("spmm_sum_bf16_fwd_bwd", half_step, half_bytes + half_bwd, n=max(3, reps // 4))
+    del ab, vb, Bb, Gb
     # fixed adjacency (gradient wrt the dense operand only): the backward is a forward over the CSC view
     del a, v, Bt
     fixed = SparseTensor(row=row, rowptr=rowptr, col=col, value=val, sparse_sizes=(M, N), is_sorted=True, trust_data=True)
@@ -209,9 +240,7 @@ def breadth(rowptr, col, val, B, reps: int):
             Bd.grad = None
             fixed.matmul(Bd, "sum").backward(Gd)
 
-        for _ in range(20 if dtype == torch.bfloat16 else 1):
-            step()
-        put(name, event_ms(step, max(3, reps // 4)), nb)
+        put(name, step, nb, n=max(3, reps // 4))
         del Bd, Gd
     return out
 

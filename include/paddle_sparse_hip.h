@@ -212,6 +212,19 @@ int psa_spmm_half_coo(int reduce, int dtype, const int64_t* rowptr,
                       int64_t* arg_out, int algo, void* workspace,
                       size_t workspace_bytes, psa_stream_t stream);
 
+/* sum / mean backward with BOTH gradients in one pass over the CSC view, half-width dense
+ * operands (the fp32 form is psa_spmm_sum_bw_csc): mat f16/bf16 [N, K] (the forward's dense
+ * operand), grad f16/bf16 [M, K], grad_mat f16/bf16 [N, K] out (fp32 sums, one rounding),
+ * grad_value_csc f32[nnz] out in CSC order or NULL.  weight_csc: f32[nnz] = value[csr2csc] (CSC
+ * order: psa_permute_apply_u32 / psa_transpose_weights) or NULL (weights 1); row_scale f32[M] or
+ * NULL multiplies both gradients per entry (mean: 1 / max(deg(r), 1)).  One wave per column, no
+ * long-column path: for matrices whose CSC view takes the row-wave family.  K % 8 == 0, K <= 512
+ * (the dot <mat[c, :], grad[r, :]> needs the whole row in one tile), else PSA_ERR_UNSUPPORTED.
+ * The dtype list the reference parametrises over: paddle_sparse/testing.py:12-21. */
+int psa_spmm_half_sum_bw_csc(int dtype, const int64_t* colptr, const int64_t* row_csc, const float* weight_csc,
+                             const float* row_scale, const void* mat, const void* grad, int64_t M, int64_t N,
+                             int64_t K, int64_t nnz, float* grad_value_csc, void* grad_mat, psa_stream_t stream);
+
 /* Test/bench hook: 0 = default (one row per wave), 1 = several rows per wave for
  * K <= 128, 2 = one row per wave with 8 gather steps in flight, 3 = default
  * without the XCD mixing of the row blocks.  Returns the previous value. */

@@ -428,6 +428,28 @@ PD_BUILD_OP(spmm_sum_bw_csc)
     .Attrs({"want_value: bool"})
     .SetKernelFn(PD_KERNEL(spmm_sum_bw_csc));
 
+// the same pass with fp16 / bf16 dense operands (fp32 sums; grad_value in CSC order, fp32): the caller brings it
+// to CSR order with permute_apply / gather_rows, as paddle_sparse_amd/matmul.py does
+std::vector<paddle::Tensor> spmm_half_sum_bw_csc(paddle::Tensor& colptr, paddle::Tensor& row_csc,
+                                                 const paddle::optional<paddle::Tensor>& weight_csc,
+                                                 const paddle::optional<paddle::Tensor>& row_scale, paddle::Tensor& mat,
+                                                 paddle::Tensor& grad, bool want_value) {
+  CHECK_GPU(grad);
+  const int64_t M = grad.shape()[0], K = grad.shape()[1], N = colptr.numel() - 1, nnz = row_csc.numel();
+  const auto place = grad.place();
+  auto gv_csc = paddle::empty({want_value ? nnz : 0}, paddle::DataType::FLOAT32, place);
+  auto gm = paddle::empty({N, K}, grad.dtype(), place);
+  PSA_CALL(psa_spmm_half_sum_bw_csc(dtype_id_of(grad), i64(colptr), i64(row_csc), f32_or_null(weight_csc),
+                                    f32_or_null(row_scale), want_value ? mat.data() : nullptr, grad.data(), M, N, K, nnz,
+                                    want_value ? gv_csc.data<float>() : nullptr, gm.data(), stream_of(grad)));
+  return {gv_csc, gm};
+}
+PD_BUILD_OP(spmm_half_sum_bw_csc)
+    .Inputs({"colptr", "row_csc", paddle::Optional("weight_csc"), paddle::Optional("row_scale"), "mat", "grad"})
+    .Outputs({"grad_value_csc", "grad_mat"})
+    .Attrs({"want_value: bool"})
+    .SetKernelFn(PD_KERNEL(spmm_half_sum_bw_csc));
+
 // ---- the index-arithmetic seams of storage.py / tensor.py / reduce.py ------
 // bincount + count2ptr: colcount / colptr (storage.py:397-398, 414-418)
 std::vector<paddle::Tensor> bincount(paddle::Tensor& index, int64_t size) {

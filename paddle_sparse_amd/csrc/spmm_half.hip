@@ -299,6 +299,124 @@ spmm_half_multirow_kernel(const int64_t* __restrict__ rowptr, const int64_t* __r
   __builtin_nontemporal_store(st, reinterpret_cast<U4*>(out + row * K + k0));
 }
 
+
+// ---- backward over the CSC view with half-width operands, trained edge values ---------------------
+// The fp32 pass (spmm.hip, M_CSC) with 2-byte dense operands: one wave per column c of the CSC
+// view; for every stored entry (r, c), in CSC order,
+//   grad_mat[c, :] += w * grad[r, :]                  (fp32 sums, one rounding on store)
+//   grad_value_csc[j] = s_r * <mat[c, :], grad[r, :]>  (fp32 out; s_r = 1 / deg(r) for mean, else 1)
+// w = weights in CSC ORDER (fp32: value[csr2csc] along the planned route, times s_r for mean is done
+// here), so the pass reads two streams (row ids, weights), gathers 2 K bytes per entry and writes
+// 2 K per column: half the bytes of the fp32 pass, and no fp32 copies of mat / grad (VERDICT r02
+// #9a: the widening route wrote and re-read 2 x 4 N K + 4 M K bytes per step before it even started).
+// The whole K must sit in ONE tile (the dot needs every column): K <= 512.
+template <typename T, int LPR, int U>
+__global__ void __launch_bounds__(kThreads)
+spmm_half_csc_bw_kernel(const int64_t* __restrict__ colptr, const int64_t* __restrict__ row_csc,
+                        const float* __restrict__ w_csc, const float* __restrict__ row_scale,
+                        const uint16_t* __restrict__ mat, const uint16_t* __restrict__ grad,
+                        uint16_t* __restrict__ grad_mat, float* __restrict__ grad_value, int64_t N, int64_t K,
+                        int mix_xcds) {
+  constexpr int G = 64 / LPR;
+  static_assert(64 % (G * U) == 0, "edge batch must divide the wave");
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int64_t rb = blockIdx.x;
+  if (mix_xcds) rb ^= static_cast<int64_t>((static_cast<uint32_t>(rb >> 3) * 0x9E3779B1u) >> 29);
+  const int64_t c = rb * kWaves + wave;
+  if (c >= N) return;
+  const int g = lane / LPR;
+  const int l = lane % LPR;
+  const int64_t k0 = static_cast<int64_t>(l) * 8;
+  const bool kact = k0 < K;
+  const uint16_t* gk = grad + k0;
+  const int64_t s = colptr[c], e = colptr[c + 1];
+
+  float acc[8], mr[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  {
+    uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+    if (kact && grad_value != nullptr) raw = *reinterpret_cast<const uint4*>(mat + c * K + k0);
+    widen8<T>(raw, mr);
+  }
+  for (int64_t base = s; base < e; base += 64) {
+    const int n = (e - base) < 64 ? static_cast<int>(e - base) : 64;
+    int64_t r_l = 0;
+    float v_l = 1.f, s_l = 1.f, gv_keep = 0.f;
+    if (lane < n) {
+      r_l = row_csc[base + lane];
+      if (w_csc != nullptr) v_l = w_csc[base + lane];
+      if (row_scale != nullptr) s_l = row_scale[r_l];
+    }
+    for (int j = 0; j < n; j += G * U) {
+      uint4 raw[U];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = j + u * G + g;  // < 64
+        const int64_t r = shfl_i64(r_l, idx);
+        ok[u] = (idx < n) && kact;
+        raw[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (ok[u]) raw[u] = *reinterpret_cast<const uint4*>(gk + r * K);
+      }
+      float dot[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int idx = j + u * G + g;
+        const float w = __shfl(v_l, idx) * __shfl(s_l, idx);  // fetched after the gathers are out
+        float b[8];
+        widen8<T>(raw[u], b);
+        dot[u] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          acc[i] += w * b[i];  // a masked slot adds w * 0
+          dot[u] += b[i] * mr[i];
+        }
+      }
+      if (grad_value != nullptr) {  // wave-uniform
+        static_assert((U & (U - 1)) == 0 && U <= LPR, "U must be a power of two <= LPR");
+        // fold the U partial dots of the lane group transposing as it goes (spmm.hip, value_bw_range): after
+        // log2(U) exchange steps lane l holds the partial of edge slot u = l % U, the remaining bits add up
+        int cnt = U;
+#pragma unroll
+        for (int bit = 1; bit < U; bit <<= 1, cnt >>= 1) {
+          const bool up = (l & bit) != 0;
+#pragma unroll
+          for (int i = 0; i < cnt / 2; ++i) {
+            const float keep = up ? dot[2 * i + 1] : dot[2 * i];
+            const float send = up ? dot[2 * i] : dot[2 * i + 1];
+            dot[i] = keep + __shfl_xor(send, bit);
+          }
+        }
+#pragma unroll
+        for (int bit = U; bit < LPR; bit <<= 1) dot[0] += __shfl_xor(dot[0], bit);
+        // lane l < U of group g now holds the dot of edge slot j + l * G + g; the lane that loaded that
+        // edge (lane == slot) keeps it for one 256-byte store per 64-edge batch
+        const unsigned rel = static_cast<unsigned>(lane - j);
+        const float got = __shfl(dot[0], static_cast<int>(((rel % G) * LPR + rel / G) & 63u));
+        if (rel < static_cast<unsigned>(G * U)) gv_keep = got;
+      }
+    }
+    if (grad_value != nullptr && lane < n) __builtin_nontemporal_store(gv_keep * s_l, grad_value + base + lane);
+  }
+#pragma unroll
+  for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] += __shfl_xor(acc[i], off);
+  }
+  if (g == 0 && kact) {
+    const uint4 packed = narrow8<T>(acc);
+    typedef unsigned int U4 __attribute__((ext_vector_type(4)));
+    U4 st;
+    st[0] = packed.x;
+    st[1] = packed.y;
+    st[2] = packed.z;
+    st[3] = packed.w;
+    __builtin_nontemporal_store(st, reinterpret_cast<U4*>(grad_mat + c * K + k0));
+  }
+}
+
 int g_half_variant = 0;  // A/B hook: 0 = one row per wave (U = 4 at K = 128), 1 = several rows per wave for K <= 128, 2 = one row per wave with U = 8
 
 template <typename T, int LPR, int U>
@@ -386,7 +504,59 @@ int dispatch_half(int red, bool track, bool val32, const int64_t* rowptr, const 
 #undef PSA_GO
 }
 
+
+template <typename T>
+int dispatch_half_csc_bw(const int64_t* colptr, const int64_t* row_csc, const float* w_csc, const float* row_scale,
+                         const uint16_t* mat, const uint16_t* grad, uint16_t* grad_mat, float* grad_value, int64_t N,
+                         int64_t K, hipStream_t s) {
+  const int64_t gx = psa::ceil_div(psa::ceil_div(N, kWaves), 8) * 8;
+  PSA_REQUIRE(gx <= 0x7fffffff, "problem too large for one launch");
+  const dim3 grid(static_cast<unsigned>(gx)), block(kThreads);
+  const int64_t q = K / 8;
+#define PSA_GO(LPR, U)                                                                                              \
+  do {                                                                                                              \
+    hipLaunchKernelGGL((spmm_half_csc_bw_kernel<T, LPR, U>), grid, block, 0, s, colptr, row_csc, w_csc, row_scale, \
+                       mat, grad, grad_mat, grad_value, N, K, 1);                                                   \
+    PSA_LAUNCH_CHECK();                                                                                             \
+    return PSA_OK;                                                                                                  \
+  } while (0)
+  if (q <= 1) PSA_GO(1, 1);
+  if (q <= 2) PSA_GO(2, 2);
+  if (q <= 4) PSA_GO(4, 4);
+  if (q <= 8) PSA_GO(8, 4);
+  if (q <= 16) PSA_GO(16, 4);
+  if (q <= 32) PSA_GO(32, 4);
+  PSA_GO(64, 8);
+#undef PSA_GO
+}
+
 }  // namespace
+
+extern "C" int psa_spmm_half_sum_bw_csc(int dtype, const int64_t* colptr, const int64_t* row_csc, const float* weight_csc,
+                                        const float* row_scale, const void* mat, const void* grad, int64_t M, int64_t N,
+                                        int64_t K, int64_t nnz, float* grad_value_csc, void* grad_mat,
+                                        psa_stream_t stream) {
+  PSA_REQUIRE(M >= 0 && N >= 0 && K >= 0 && nnz >= 0, "negative size");
+  if (dtype != PSA_F16 && dtype != PSA_BF16) {
+    psa::set_error("psa_spmm_half_sum_bw_csc: dtype must be PSA_F16 or PSA_BF16");
+    return PSA_ERR_UNSUPPORTED;
+  }
+  if (K % 8 != 0 || K > 512 || !psa::aligned(mat, 16) || !psa::aligned(grad, 16) || !psa::aligned(grad_mat, 16)) {
+    psa::set_error("psa_spmm_half_sum_bw_csc: needs K % 8 == 0, K <= 512 and 16-byte aligned operands");
+    return PSA_ERR_UNSUPPORTED;
+  }
+  if (N == 0 || K == 0) return PSA_OK;
+  PSA_REQUIRE(colptr && grad_mat, "NULL pointer");
+  PSA_REQUIRE(nnz == 0 || (row_csc && grad), "NULL pointer");
+  PSA_REQUIRE(grad_value_csc == nullptr || mat != nullptr || nnz == 0, "grad_value needs mat");
+  hipStream_t s = psa::as_stream(stream);
+  const uint16_t* m = static_cast<const uint16_t*>(mat);
+  const uint16_t* g = static_cast<const uint16_t*>(grad);
+  uint16_t* gm = static_cast<uint16_t*>(grad_mat);
+  if (dtype == PSA_BF16)
+    return dispatch_half_csc_bw<BF16>(colptr, row_csc, weight_csc, row_scale, m, g, gm, grad_value_csc, N, K, s);
+  return dispatch_half_csc_bw<F16>(colptr, row_csc, weight_csc, row_scale, m, g, gm, grad_value_csc, N, K, s);
+}
 
 extern "C" int psa_spmm_half_set_variant(int v) {
   const int prev = g_half_variant;

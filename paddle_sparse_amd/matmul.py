@@ -165,6 +165,21 @@ class _SpMM(torch.autograd.Function):
             if value is not None or mean:
                 w = _csc_weights(st, None if value is None else value.detach().float(), csr2csc, st._row_in_csc_order(), mean)
             return None, _spmm_sum_planned(st._csc_view(), w, grad_out), None, None, None
+        if (ctx.half is not None and reduce in ("sum", "mean") and need_value and need_mat and grad_out.dtype == ctx.half
+                and ops.half_sum_bw_csc_supported(grad_out.shape[1]) and st._csc_view()._spmm_algo() == "row_waves"):
+            # trained values, half-width operands: both gradients in one pass over the CSC view that gathers
+            # 2-byte rows of grad_out and keeps fp32 sums — no fp32 copies of mat / grad_out (one wave per
+            # column: matrices whose transpose takes the row-wave family; power-law ones widen as before)
+            csr2csc = st.csr2csc()
+            v32 = value.detach().float()
+            w = _streamed_values(st, v32)
+            if w is None:
+                w = ops.transpose_weights(v32, csr2csc, None, None, False)
+            scale = (1.0 / st.rowcount().clamp(min=1).to(torch.float32)) if reduce == "mean" else None
+            gv, gm = ops.spmm_half_sum_bw_csc(st.colptr(), st._row_in_csc_order(), w, mat, grad_out, True, row_scale=scale)
+            plan = st._permute_plan("to_csr")
+            gv = ops.permute_apply(gv, plan) if plan is not None else ops.gather_rows(gv, st.csc2csr())
+            return gv.to(value.dtype), gm, None, None, None
         if ctx.half is not None:
             gv, gm = _SpMM._backward_fp32(st, reduce, None if value is None else value.float(), mat.float(),
                                           grad_out.float(), arg, None, need_value, need_mat)

@@ -1062,6 +1062,43 @@ def spmm_sum_bw_csc(colptr, row_csc, csr2csc, value, mat, grad, want_value: bool
     return gv, gm
 
 
+def half_sum_bw_csc_supported(K: int) -> bool:
+    return K % 8 == 0 and 0 < K <= 512
+
+
+def spmm_half_sum_bw_csc(colptr, row_csc, weight_csc, mat, grad, want_value: bool = True,
+                         row_scale: Optional[torch.Tensor] = None):
+    """sum / mean backward over the CSC view with fp16 / bf16 dense operands (psa_spmm_half_sum_bw_csc):
+    returns (grad_value f32[nnz] IN CSC ORDER | None, grad_mat [N, K] in grad's dtype).  weight_csc:
+    f32[nnz] = value[csr2csc] or None; row_scale f32[M] (mean) or None.  The caller brings
+    grad_value to CSR order (SparseStorage._permute_plan("to_csr") / csc2csr)."""
+    colptr, row_csc = _index(colptr, "colptr"), _index(row_csc, "row_csc")
+    _gpu(grad, "grad")
+    if grad.dtype not in (torch.float16, torch.bfloat16) or grad.dim() != 2:
+        raise TypeError("grad must be a 2-D float16 / bfloat16 tensor")
+    grad = grad.contiguous()
+    (M, K), N, nnz = grad.shape, colptr.numel() - 1, row_csc.numel()
+    if weight_csc is not None:
+        weight_csc = _f32(weight_csc, "weight_csc")
+    if row_scale is not None:
+        row_scale = _f32(row_scale, "row_scale")
+        if row_scale.shape != (M,):
+            raise ValueError("row_scale must be f32[M]")
+    gv = None
+    if want_value:
+        _gpu(mat, "mat")
+        if mat.dtype != grad.dtype or mat.shape != (N, K):
+            raise ValueError("mat must be [N, K] in grad's dtype")
+        mat = mat.contiguous()
+        gv = torch.empty(nnz, dtype=torch.float32, device=grad.device)
+    gm = torch.empty((N, K), dtype=grad.dtype, device=grad.device)
+    with _on(grad.device):
+        check(_lib.load().psa_spmm_half_sum_bw_csc(_DTYPE_ID[grad.dtype], _ptr(colptr), _ptr(row_csc), _ptr(weight_csc),
+                                                   _ptr(row_scale), _ptr(mat) if want_value else None, _ptr(grad), M, N, K,
+                                                   nnz, _ptr(gv), _ptr(gm), _stream()))
+    return gv, gm
+
+
 def bincount(index: torch.Tensor, size: int) -> torch.Tensor:
     """int64[size] occurrence counts (colcount, storage.py:414-418)."""
     index = _index(index, "index")

@@ -327,12 +327,15 @@ class SparseStorage(object):
                                                 is_sorted=True, trust_data=True)
         return self._csc_view_memo
 
-    def _permute_plan(self, direction: str):
+    def _permute_plan(self, direction: str, force: bool = False):
         """Planned route (ops.PermutePlan, structure only, memoised) of an nnz-sized 4-byte array
         between CSR and CSC order — "to_csc": out[j] = src[csr2csc[j]] (value[csr2csc],
         tensor.py:254-257), "to_csr": out[i] = src[csc2csr[i]] (grad_value's way back from the
         pass over the CSC view).  None below ops.PERMUTE_PLAN_FROM entries, where the plain gather
-        is as fast (everything is cache resident) and the plan's 8 bytes per entry buy nothing."""
+        is as fast (everything is cache resident) and the plan's 8 bytes per entry buy nothing —
+        and None the FIRST time a direction is asked for: building a plan costs two sorts (~2 ms at
+        20 M entries, five plain gathers' worth), which a one-off `t()` or `sum(dim=0)` never earns
+        back; the second request (a training loop's second step) builds it.  force: build now."""
         nnz = self._col.numel()
         if nnz < ops.PERMUTE_PLAN_FROM or nnz >= (1 << 31):
             return None
@@ -340,6 +343,10 @@ class SparseStorage(object):
         if plans is None:
             plans = self._perm_plans = {}
         if direction not in plans:
+            seen = plans.get(("asked", direction), 0)
+            if not force and seen < 1:
+                plans[("asked", direction)] = seen + 1
+                return None
             # dest = the inverse of the gather's index array
             plans[direction] = ops.permute_plan(self.csc2csr() if direction == "to_csc" else self.csr2csc())
         return plans[direction]

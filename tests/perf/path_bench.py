@@ -292,4 +292,26 @@ ms = gpu_ms(lambda: ops.spmm_minmax_bw_csc(rowptr_d, colptr_d, row_csc, csr2csc,
                                            arg_bytes=local), reps=10)
 report("a13", "  same, grad of mat only (fixed adjacency)", ms, E * (8 + 8 + 4 + 4 * F + F + 1) + N * (8 + 4 * F))
 ms = gpu_ms(lambda: ops.spmm_sum_bw_csc(colptr_d, row_csc, csr2csc, val_c, B_d, g_d, True, csc2csr=inv), reps=10)
-report("a13", "spmm_sum backward, one CSC pass (both grads)", ms, E * (8 + 8 + 4 + 4 * F + 4 + 16) + N * (8 + 8 * F))
+report("a13", "spmm_sum backward, one CSC pass (both grads), gathers through csr2csc / csc2csr", ms, E * (8 + 8 + 4 + 4 * F + 4 + 16) + N * (8 + 8 * F))
+# what autograd runs from the second step on: value[csr2csc] and grad_value's way back along planned routes
+to_csc, to_csr = A.storage._permute_plan("to_csc", force=True), A.storage._permute_plan("to_csr", force=True)
+
+
+def sum_bw_planned():
+    return ops.spmm_sum_bw_csc(colptr_d, row_csc, csr2csc, val_c, B_d, g_d, True, csc2csr=inv, to_csr_plan=to_csr,
+                               value_csc=ops.permute_apply(val_c, to_csc))
+
+
+def max_bw_planned():
+    return ops.spmm_minmax_bw_csc(rowptr_d, colptr_d, row_csc, csr2csc, tags, val_c, B_d, g_d, None, csc2csr=inv,
+                                  arg_bytes=local, to_csr_plan=to_csr, value_csc=ops.permute_apply(val_c, to_csc))
+
+
+ms = gpu_ms(sum_bw_planned, reps=10)
+report("a13", "spmm_sum backward as autograd runs it: planned value[csr2csc] + pass + planned way back", ms,
+       E * (8 + 8 + 4 + 4 * F + 4 + 16) + N * (8 + 8 * F))
+ms = gpu_ms(max_bw_planned, reps=10)
+report("a13", "spmm_max backward as autograd runs it (row-local arg, planned routes)", ms,
+       E * (8 + 8 + 4 + 4 * F + F + 1 + 4 + 16) + N * (8 + 8 * F))
+ms = gpu_ms(lambda: ops.permute_apply(val_c, to_csc), reps=20)
+report("a13", "  value[csr2csc] along the planned route (two streaming passes)", ms, E * 24)

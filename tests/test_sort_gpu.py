@@ -376,7 +376,7 @@ def test_storage_plans_route_values_between_csr_and_csc_order():
     col = rng.integers(0, N, nnz).astype(np.int64)
     val = torch.randn(nnz, device="cuda")
     st = SparseStorage(row=dev(row), col=dev(col), value=val, sparse_sizes=(M, N), is_sorted=True, trust_data=True)
-    to_csc, to_csr = st._permute_plan("to_csc"), st._permute_plan("to_csr")
+    to_csc, to_csr = st._permute_plan("to_csc", force=True), st._permute_plan("to_csr", force=True)
     assert to_csc is not None and st._permute_plan("to_csc") is to_csc
     v_csc = ops.permute_apply(val, to_csc)
     assert torch.equal(v_csc, val[st.csr2csc()])
@@ -387,4 +387,7 @@ def test_storage_plans_route_values_between_csr_and_csc_order():
     gv1, gm1 = ops.spmm_sum_bw_csc(*args, csc2csr=st.csc2csr(), to_csr_plan=to_csr)
     assert torch.equal(gv0, gv1) and torch.equal(gm0, gm1)
     small = SparseStorage(row=dev(row[:1000]), col=dev(col[:1000]), sparse_sizes=(M, N), is_sorted=True, trust_data=True)
-    assert small._permute_plan("to_csr") is None
+    assert small._permute_plan("to_csr", force=True) is None
+    # a one-off use does not pay for a plan: the first request answers None, the second builds it
+    again = SparseStorage(row=dev(row), col=dev(col), value=val, sparse_sizes=(M, N), is_sorted=True, trust_data=True)
+    assert again._permute_plan("to_csr") is None and again._permute_plan("to_csr") is not None

@@ -40,12 +40,12 @@ t("max backward, both gradients (bytes only)", lambda: ops.spmm_minmax_bw_csc(ro
 t("max backward, grad_mat only", lambda: ops.spmm_minmax_bw_csc(rowptr, colptr, row_csc, csr2csc, tags, val, B, G, None, want_value=False, arg_bytes=arg_bytes), None)
 gv = torch.randn(nnz, device=dev)
 t("gather of a 4-byte array through csc2csr (grad_value's way back)", lambda: ops.gather_rows(gv, inv), nnz * 16)
-plan = st._permute_plan("to_csr")
+plan = st._permute_plan("to_csr", force=True)
 assert torch.equal(ops.permute_apply(gv, plan), ops.gather_rows(gv, inv))
 t("  the same through the planned two-pass permutation", lambda: ops.permute_apply(gv, plan), nnz * 24)
 t("sum backward, both gradients, planned way back", lambda: ops.spmm_sum_bw_csc(colptr, row_csc, csr2csc, val, B, G, True, csc2csr=inv, to_csr_plan=plan), bw)
 t("max backward, both gradients, planned way back", lambda: ops.spmm_minmax_bw_csc(rowptr, colptr, row_csc, csr2csc, tags, val, B, G, None, csc2csr=inv, arg_bytes=arg_bytes, to_csr_plan=plan), bw + nnz * (F + 1))
-to_csc = st._permute_plan("to_csc")
+to_csc = st._permute_plan("to_csc", force=True)
 def sum_bw_streamed():
     v_csc = ops.permute_apply(val, to_csc)
     return ops.spmm_sum_bw_csc(colptr, row_csc, csr2csc, val, B, G, True, csc2csr=inv, to_csr_plan=plan, value_csc=v_csc)
