@@ -27,7 +27,7 @@
 //                         blocks of an XCD fit its 4 MiB L2 and partial lines
 //                         complete there.  Measured 5.9 ms for 100 M 48-bit
 //                         keys (rocPRIM onesweep via torch.sort: 8.0 ms).
-//      variants 1-4 kept for A/B (tools/sort_bench.py): 256-thread staged
+//      variants 1-4 kept for A/B (tools/archive/sort_bench.py): 256-thread staged
 //      tile 7.6 ms, direct per-lane stores 8.9 ms, 512-thread tile 6.6 ms.
 // HBM traffic per pass: 8n (hist) + 12n read + 12n written (key64 + idx32).
 #include "coalesce_internal.h"

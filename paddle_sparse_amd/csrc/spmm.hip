@@ -1046,7 +1046,7 @@ int launch_fused(int red, const int64_t* rowptr, const int64_t* col, const float
   const dim3 cgrid(kLongBlocks), cblock(psa::kLongThreads);
   MaskArgs plain;
   plain.xcd_rows = g_variant == 16;
-  plain.mix_xcds = g_variant == 28;  // A/B: XCD mixing of the row blocks in the forward too (tools/mix_xcds_fwd.py)
+  plain.mix_xcds = g_variant == 28;  // A/B: XCD mixing of the row blocks in the forward too (tools/archive/mix_xcds_fwd.py)
   plain.temporal_out = g_variant == 17;
   plain.nt_gather = nt_gather;
   plain.chunk_blocks = kFusedChunkBlocks;
@@ -1520,7 +1520,7 @@ int spmm_dispatch(int reduce, const int64_t* rowptr, const int64_t* row, const i
       *bytes_done = arg_bytes.p != nullptr && minmax;
       // A dense operand far beyond the 256 MiB Infinity Cache is gathered with
       // non-temporal loads: nothing of it will be hit again, and not allocating
-      // the lines is worth 4-5 % at 8-16 GiB (tools/nt_gather_sweep.py: break-even
+      // the lines is worth 4-5 % at 8-16 GiB (tools/archive/nt_gather_sweep.py: break-even
       // at ~4 GiB, 0.85x at 1 GiB where a quarter of B does stay cached).
       const bool nt_gather = g_variant == 18 || ((g_variant == 0 || g_variant == 25) && N * K * 4 >= kNtGatherBytes);
       // K >= 192 runs as ceil(K / 128) tiles of the K = 128 form (32 lanes x float4,
