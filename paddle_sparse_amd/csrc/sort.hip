@@ -689,13 +689,20 @@ os_pass_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict_
     // A sort never returns garbage (storage.py:164-169): once any tile of any pass gave up,
     // the LAST pass stores -1 over its share of the outputs instead of a wrong order, so a
     // caller without a host read behind the sort cannot mistake the result for one either.
-    if (LAST && tid == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) s_fault = 1u;
+    // Every OTHER pass stops storing as well: a tile that gave up scatters to under-counted
+    // (in-range) positions and leaves slots of its output unwritten, so the NEXT pass would read
+    // keys that do not match the histograms its positions come from and could store past the
+    // end of the buffers (seen as a memory fault with PSA_POISON_WORKSPACE=1 and the spin limit
+    // at 0).  Within the faulting pass every position is an under-count of a true one: in range.
+    if (tid == 0 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) s_fault = 1u;
   }
   __syncthreads();
-  if (LAST && s_fault != 0u) {  // block-uniform
-    for (int p = tid; p < tile_n; p += THREADS) {
-      if (perm_out) perm_out[tile_begin + p] = -1;
-      if (keys_out) keys_out[tile_begin + p] = ~0ull;
+  if (s_fault != 0u) {  // block-uniform
+    if (LAST) {
+      for (int p = tid; p < tile_n; p += THREADS) {
+        if (perm_out) perm_out[tile_begin + p] = -1;
+        if (keys_out) keys_out[tile_begin + p] = ~0ull;
+      }
     }
     return;
   }

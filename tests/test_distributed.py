@@ -158,6 +158,64 @@ def test_row_partitioned_spmm_world2_gloo(tmp_path, reduce, balance, N):
         assert max(share) <= 0.75 * sum(share)
 
 
+def _worker_strong_split(rank, world, port, M, N, F):
+    """bench.py --scaling strong in miniature: every rank builds the ONE matrix from the same seed, keeps its block of
+    rows (balanced by nnz), owns an equal block of B; every exchange gives the single-process result, bit for bit,
+    also when a rank's block is EMPTY (more ranks than rows with entries) and when N is not a multiple of the world."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle
+        from paddle_sparse_amd import distributed as pd
+
+        rng = np.random.default_rng(17)
+        deg = rng.integers(0, 7, M)
+        if M <= world:  # fewer rows than ranks: some blocks are empty
+            deg[:] = 3
+        deg[M // 3] = 40  # one heavy row
+        rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+        row = np.repeat(np.arange(M), deg)
+        col = rng.integers(0, N, rowptr[-1]).astype(np.int64)
+        val = rng.standard_normal(rowptr[-1]).astype(np.float32)
+        B = rng.standard_normal((N, F)).astype(np.float32)
+        G = rng.standard_normal((M, F)).astype(np.float32)
+        t = (torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val))
+        bounds = pd.partition_rows_by_nnz(t[0], world)
+        assert bounds[0] == 0 and bounds[-1] == M and all(a <= b for a, b in zip(bounds, bounds[1:]))
+        shard = pd.shard_csr(*t, N, bounds, rank)
+        ref, _ = oracle.spmm("sum", rowptr, col, val, B)
+        nb = pd.dense_block_rows(N, world)
+        want_g = np.zeros((world * nb, F), np.float64)
+        np.add.at(want_g, col, val[:, None].astype(np.float64) * G[row].astype(np.float64))
+        outs = []
+        for exchange in pd.EXCHANGES:
+            op = pd.RowPartitionedSpMM(shard, exchange=exchange, local_spmm=_oracle_local_spmm)
+            b_local = op.local_dense_block(torch.from_numpy(B))
+            assert b_local.shape == (nb, F)
+            for chunks in (1, 3):
+                out = op(b_local, feature_chunks=chunks)
+                assert out.shape == (shard.num_rows, F)
+                assert np.array_equal(out.numpy(), ref[shard.row_begin:shard.row_end]), (exchange, chunks)
+            outs.append(out)
+            bl = b_local.clone().requires_grad_(True)
+            op.apply(bl).backward(torch.from_numpy(G[shard.row_begin:shard.row_end]))
+            np.testing.assert_allclose(bl.grad.numpy(), want_g[rank * nb:(rank + 1) * nb], rtol=1e-4, atol=1e-4)
+        full = pd.gather_rows_to_root(outs[0], bounds)
+        if rank == 0:
+            assert np.array_equal(full.numpy(), ref)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,M,N", [(4, 90, 64), (4, 3, 10), (3, 50, 31)])
+def test_strong_split_every_exchange_more_ranks_gloo(world, M, N):
+    import oracle
+
+    oracle.build()
+    mp.spawn(_worker_strong_split, args=(world, _free_port(), M, N, 12), nprocs=world, join=True)
+
+
 def _worker_skewed_halo(rank, world, port, result_path):
     """Banded graph with a few hub columns: most of a rank's columns are its own
     rows' neighbours, so the halo is a small fraction of B; results identical."""

@@ -17,6 +17,12 @@ case $WHAT in
   breadth)
     bash tools/prof_stats.sh r03_breadth $REPO/bench.py --steps 20 --warmup 5 --no-cpu | tee gpurun_out/r03_breadth_stats.txt
     cp gpurun_out/stats_r03_breadth/*/*_kernel_stats.csv gpurun_out/r03_kernel_stats_breadth.csv ;;
+  traffic)
+    # HBM bytes of the headline kernel: separate FETCH_SIZE / WRITE_SIZE / TCC passes over the bench command
+    for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
+      tag=r03_traffic_$(echo $c | tr ' ' '_' | cut -c1-12)
+      bash tools/prof_pmc.sh $tag "$c" $REPO/bench.py --steps 10 --warmup 2 --no-cpu --no-extra | grep -A3 "spmm_fused_kernel<4, 32, 0, 4, 0" | tee -a gpurun_out/r03_traffic_pmc.txt
+    done ;;
   sort)
     bash tools/prof_stats.sh r03_sort $REPO/tools/pmc_sort.py | tee gpurun_out/r03_sort_stats.txt
     for c in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INST_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
