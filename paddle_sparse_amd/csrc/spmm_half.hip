@@ -310,8 +310,8 @@ spmm_half_multirow_kernel(const int64_t* __restrict__ rowptr, const int64_t* __r
 // 2 K per column: half the bytes of the fp32 pass, and no fp32 copies of mat / grad (VERDICT r02
 // #9a: the widening route wrote and re-read 2 x 4 N K + 4 M K bytes per step before it even started).
 // The whole K must sit in ONE tile (the dot needs every column): K <= 512.
-template <typename T, int LPR, int U>
-__global__ void __launch_bounds__(kThreads)
+template <typename T, int LPR, int U, bool GV>
+__global__ void __launch_bounds__(kThreads, 6)  // 78 VGPRs without spilling: 6 waves per SIMD (81 / 5 unconstrained)
 spmm_half_csc_bw_kernel(const int64_t* __restrict__ colptr, const int64_t* __restrict__ row_csc,
                         const float* __restrict__ w_csc, const float* __restrict__ row_scale,
                         const uint16_t* __restrict__ mat, const uint16_t* __restrict__ grad,
@@ -332,13 +332,20 @@ spmm_half_csc_bw_kernel(const int64_t* __restrict__ colptr, const int64_t* __res
   const uint16_t* gk = grad + k0;
   const int64_t s = colptr[c], e = colptr[c + 1];
 
-  float acc[8], mr[8];
+  // sums and products as pairs: v_pk_fma_f32 does two fp32 FMAs per issue slot, and a wave64 VALU
+  // instruction takes 4 issue cycles on this chip — with ~10 entries per column the pass is bound by
+  // instruction issue, not by bytes (profiles/r03_half_train_step.txt)
+  typedef float F2 __attribute__((ext_vector_type(2)));
+  F2 acc[4], mr[4];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
-  {
+  for (int i = 0; i < 4; ++i) acc[i] = F2{0.f, 0.f};
+  if constexpr (GV) {
     uint4 raw = make_uint4(0u, 0u, 0u, 0u);
-    if (kact && grad_value != nullptr) raw = *reinterpret_cast<const uint4*>(mat + c * K + k0);
-    widen8<T>(raw, mr);
+    if (kact) raw = *reinterpret_cast<const uint4*>(mat + c * K + k0);
+    float m8[8];
+    widen8<T>(raw, m8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mr[i] = F2{m8[2 * i], m8[2 * i + 1]};
   }
   for (int64_t base = s; base < e; base += 64) {
     const int n = (e - base) < 64 ? static_cast<int>(e - base) : 64;
@@ -364,17 +371,21 @@ spmm_half_csc_bw_kernel(const int64_t* __restrict__ colptr, const int64_t* __res
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int idx = j + u * G + g;
-        const float w = __shfl(v_l, idx) * __shfl(s_l, idx);  // fetched after the gathers are out
+        float w = __shfl(v_l, idx);  // fetched after the gathers are out
+        if (row_scale != nullptr) w *= __shfl(s_l, idx);
         float b[8];
         widen8<T>(raw[u], b);
-        dot[u] = 0.f;
+        const F2 w2 = F2{w, w};
+        F2 d2 = F2{0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          acc[i] += w * b[i];  // a masked slot adds w * 0
-          dot[u] += b[i] * mr[i];
+        for (int i = 0; i < 4; ++i) {
+          const F2 b2 = F2{b[2 * i], b[2 * i + 1]};
+          acc[i] = __builtin_elementwise_fma(w2, b2, acc[i]);  // a masked slot adds w * 0
+          if constexpr (GV) d2 = __builtin_elementwise_fma(b2, mr[i], d2);
         }
+        dot[u] = d2[0] + d2[1];
       }
-      if (grad_value != nullptr) {  // wave-uniform
+      if constexpr (GV) {
         static_assert((U & (U - 1)) == 0 && U <= LPR, "U must be a power of two <= LPR");
         // fold the U partial dots of the lane group transposing as it goes (spmm.hip, value_bw_range): after
         // log2(U) exchange steps lane l holds the partial of edge slot u = l % U, the remaining bits add up
@@ -398,15 +409,21 @@ spmm_half_csc_bw_kernel(const int64_t* __restrict__ colptr, const int64_t* __res
         if (rel < static_cast<unsigned>(G * U)) gv_keep = got;
       }
     }
-    if (grad_value != nullptr && lane < n) __builtin_nontemporal_store(gv_keep * s_l, grad_value + base + lane);
+    if (GV && lane < n) __builtin_nontemporal_store(gv_keep * s_l, grad_value + base + lane);
+  }
+  float a8[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a8[2 * i] = acc[i][0];
+    a8[2 * i + 1] = acc[i][1];
   }
 #pragma unroll
   for (int off = LPR; off < 64; off <<= 1) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[i] += __shfl_xor(acc[i], off);
+    for (int i = 0; i < 8; ++i) a8[i] += __shfl_xor(a8[i], off);
   }
   if (g == 0 && kact) {
-    const uint4 packed = narrow8<T>(acc);
+    const uint4 packed = narrow8<T>(a8);
     typedef unsigned int U4 __attribute__((ext_vector_type(4)));
     U4 st;
     st[0] = packed.x;
@@ -515,8 +532,12 @@ int dispatch_half_csc_bw(const int64_t* colptr, const int64_t* row_csc, const fl
   const int64_t q = K / 8;
 #define PSA_GO(LPR, U)                                                                                              \
   do {                                                                                                              \
-    hipLaunchKernelGGL((spmm_half_csc_bw_kernel<T, LPR, U>), grid, block, 0, s, colptr, row_csc, w_csc, row_scale, \
-                       mat, grad, grad_mat, grad_value, N, K, 1);                                                   \
+    if (grad_value != nullptr)                                                                                      \
+      hipLaunchKernelGGL((spmm_half_csc_bw_kernel<T, LPR, U, true>), grid, block, 0, s, colptr, row_csc, w_csc,     \
+                         row_scale, mat, grad, grad_mat, grad_value, N, K, 1);                                      \
+    else                                                                                                            \
+      hipLaunchKernelGGL((spmm_half_csc_bw_kernel<T, LPR, U, false>), grid, block, 0, s, colptr, row_csc, w_csc,    \
+                         row_scale, mat, grad, grad_mat, grad_value, N, K, 1);                                      \
     PSA_LAUNCH_CHECK();                                                                                             \
     return PSA_OK;                                                                                                  \
   } while (0)
@@ -524,7 +545,7 @@ int dispatch_half_csc_bw(const int64_t* colptr, const int64_t* row_csc, const fl
   if (q <= 2) PSA_GO(2, 2);
   if (q <= 4) PSA_GO(4, 4);
   if (q <= 8) PSA_GO(8, 4);
-  if (q <= 16) PSA_GO(16, 4);
+  if (q <= 16) PSA_GO(16, 4);  // K = 128, config 3 in bf16: 1.28 ms; U = 2 the same (1.29), U = 8 spills (6.8 ms)
   if (q <= 32) PSA_GO(32, 4);
   PSA_GO(64, 8);
 #undef PSA_GO
