@@ -221,6 +221,22 @@ int psa_spmm_half_coo(int reduce, int dtype, const int64_t* rowptr,
  * long-column path: for matrices whose CSC view takes the row-wave family.  K % 8 == 0, K <= 512
  * (the dot <mat[c, :], grad[r, :]> needs the whole row in one tile), else PSA_ERR_UNSUPPORTED.
  * The dtype list the reference parametrises over: paddle_sparse/testing.py:12-21. */
+/* psa_spmm_half that also leaves the row-local form of arg_out behind (min / max; arg_bytes: [M, K]
+ * entries of arg_width bytes as in psa_spmm_coo, or NULL; arg_out and arg_bytes are both optional). */
+int psa_spmm_half_arg(int reduce, int dtype, const int64_t* rowptr, const int64_t* col, const void* value,
+                      int value_dtype, const void* mat, int64_t M, int64_t N, int64_t K, int64_t nnz, void* out,
+                      int64_t* arg_out, void* arg_bytes, int arg_width, psa_stream_t stream);
+
+/* min / max backward over the CSC view with half-width dense operands, both gradients in one pass (the
+ * fp32 form is psa_spmm_minmax_bw_csc in its exact arg_bytes forms): an entry's term counts for column k
+ * only where arg_bytes[r, k] equals the entry's tag (psa_csc_edge_tags, same width).  arg_bytes must be
+ * exact (one byte: no row above 128 entries; two: none above 65 535).  weight_csc: f32[nnz] value[csr2csc]
+ * or NULL; grad_value_csc f32[nnz] in CSC order or NULL; grad_mat in grad's dtype.  K % 8 == 0, K <= 512. */
+int psa_spmm_half_minmax_bw_csc(int dtype, const int64_t* colptr, const int64_t* row_csc, const void* tag,
+                                const float* weight_csc, const void* mat, const void* grad, const void* arg_bytes,
+                                int arg_width, int64_t M, int64_t N, int64_t K, int64_t nnz, float* grad_value_csc,
+                                void* grad_mat, psa_stream_t stream);
+
 int psa_spmm_half_sum_bw_csc(int dtype, const int64_t* colptr, const int64_t* row_csc, const float* weight_csc,
                              const float* row_scale, const void* mat, const void* grad, int64_t M, int64_t N,
                              int64_t K, int64_t nnz, float* grad_value_csc, void* grad_mat, psa_stream_t stream);

@@ -450,6 +450,46 @@ PD_BUILD_OP(spmm_half_sum_bw_csc)
     .Attrs({"want_value: bool"})
     .SetKernelFn(PD_KERNEL(spmm_half_sum_bw_csc));
 
+// min / max with half-width operands: the forward that leaves the row-local arg_out (arg_width bytes per element)
+// and the masked pass over the CSC view that reads it (both gradients; grad_value in CSC order, fp32)
+std::vector<paddle::Tensor> spmm_half_arg(paddle::Tensor& rowptr, paddle::Tensor& col,
+                                          const paddle::optional<paddle::Tensor>& value, paddle::Tensor& mat,
+                                          int64_t reduce, int64_t arg_width) {
+  CHECK_GPU(mat);
+  const int64_t M = rowptr.numel() - 1, N = mat.shape()[0], K = mat.shape()[1], nnz = col.numel();
+  auto out = paddle::empty({M, K}, mat.dtype(), mat.place());
+  auto bytes = paddle::empty({M, K}, arg_width == 2 ? paddle::DataType::INT16 : paddle::DataType::UINT8, mat.place());
+  PSA_CALL(psa_spmm_half_arg(static_cast<int>(reduce), dtype_id_of(mat), i64(rowptr), i64(col),
+                             value ? value.get().data() : nullptr, value ? dtype_id_of(value.get()) : 0, mat.data(), M, N, K,
+                             nnz, out.data(), nullptr, bytes.data(), static_cast<int>(arg_width), stream_of(mat)));
+  return {out, bytes};
+}
+PD_BUILD_OP(spmm_half_arg)
+    .Inputs({"rowptr", "col", paddle::Optional("value"), "mat"})
+    .Outputs({"out", "arg_bytes"})
+    .Attrs({"reduce: int64_t", "arg_width: int64_t"})
+    .SetKernelFn(PD_KERNEL(spmm_half_arg));
+
+std::vector<paddle::Tensor> spmm_half_minmax_bw_csc(paddle::Tensor& colptr, paddle::Tensor& row_csc, paddle::Tensor& tag,
+                                                    const paddle::optional<paddle::Tensor>& weight_csc, paddle::Tensor& mat,
+                                                    paddle::Tensor& grad, paddle::Tensor& arg_bytes, bool want_value) {
+  CHECK_GPU(grad);
+  const int64_t M = grad.shape()[0], K = grad.shape()[1], N = colptr.numel() - 1, nnz = row_csc.numel();
+  const auto place = grad.place();
+  const int width = tag.dtype() == paddle::DataType::INT16 ? 2 : 1;
+  auto gv_csc = paddle::empty({want_value ? nnz : 0}, paddle::DataType::FLOAT32, place);
+  auto gm = paddle::empty({N, K}, grad.dtype(), place);
+  PSA_CALL(psa_spmm_half_minmax_bw_csc(dtype_id_of(grad), i64(colptr), i64(row_csc), tag.data(), f32_or_null(weight_csc),
+                                       want_value ? mat.data() : nullptr, grad.data(), arg_bytes.data(), width, M, N, K, nnz,
+                                       want_value ? gv_csc.data<float>() : nullptr, gm.data(), stream_of(grad)));
+  return {gv_csc, gm};
+}
+PD_BUILD_OP(spmm_half_minmax_bw_csc)
+    .Inputs({"colptr", "row_csc", "tag", paddle::Optional("weight_csc"), "mat", "grad", "arg_bytes"})
+    .Outputs({"grad_value_csc", "grad_mat"})
+    .Attrs({"want_value: bool"})
+    .SetKernelFn(PD_KERNEL(spmm_half_minmax_bw_csc));
+
 // ---- the index-arithmetic seams of storage.py / tensor.py / reduce.py ------
 // bincount + count2ptr: colcount / colptr (storage.py:397-398, 414-418)
 std::vector<paddle::Tensor> bincount(paddle::Tensor& index, int64_t size) {

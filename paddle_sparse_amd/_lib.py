@@ -44,6 +44,10 @@ SIGNATURES = {
                               c_int64, c_void_p, c_void_p, c_void_p]),
     "psa_spmm_half_sum_bw_csc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
                                          c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "psa_spmm_half_arg": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64,
+                                  c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "psa_spmm_half_minmax_bw_csc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "psa_spmm_half_set_variant": (c_int, [c_int]),
     "psa_csr_row_stats": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "psa_spmm_set_variant": (c_int, [c_int]),

@@ -20,6 +20,7 @@
 
 #include "common.h"
 #include "spmm_eb.h"
+#include "vec_io.h"
 
 namespace {
 
@@ -83,7 +84,7 @@ __global__ void __launch_bounds__(kThreads)
 spmm_half_row_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col,
                      const void* __restrict__ val, const uint16_t* __restrict__ mat,
                      uint16_t* __restrict__ out, int64_t* __restrict__ arg_out, int64_t M, int64_t K,
-                     int64_t nnz, int mean, int mix_xcds) {
+                     int64_t nnz, int mean, int mix_xcds, uint8_t* __restrict__ arg_bytes = nullptr, int arg_width = 1) {
   constexpr int G = 64 / LPR;
   static_assert(64 % (G * U) == 0, "edge batch must divide the wave");
   const int lane = threadIdx.x & 63;
@@ -193,6 +194,15 @@ spmm_half_row_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restri
           v[0] = arg[i];
           v[1] = arg[i + 1];
           __builtin_nontemporal_store(v, reinterpret_cast<V2*>(arg_out + row * K + k0 + i));
+        }
+      }
+      if (TRACK && arg_bytes != nullptr) {  // the row-local form the one-pass backward reads (vec_io.h)
+#pragma unroll
+        for (int h = 0; h < 8; h += 4) {
+          uint32_t f[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) f[i] = psa::arg_local(arg[h + i] - s, deg, arg_width);
+          psa::store_arg_local4(arg_bytes, row * K + k0 + h, f, arg_width);
         }
       }
     }
@@ -310,13 +320,18 @@ spmm_half_multirow_kernel(const int64_t* __restrict__ rowptr, const int64_t* __r
 // 2 K per column: half the bytes of the fp32 pass, and no fp32 copies of mat / grad (VERDICT r02
 // #9a: the widening route wrote and re-read 2 x 4 N K + 4 M K bytes per step before it even started).
 // The whole K must sit in ONE tile (the dot needs every column): K <= 512.
-template <typename T, int LPR, int U, bool GV>
-__global__ void __launch_bounds__(kThreads, 6)  // 78 VGPRs without spilling: 6 waves per SIMD (81 / 5 unconstrained)
+// MW (min / max): bytes per entry of the forward's row-local arg_out `words` [M, K] and of the per-entry
+// `tags` [nnz] (CSC order); an entry's term counts for column k only where words[r, k] == its tag — the
+// masked form of the fp32 pass (spmm.hip, M_MASK) in its exact forms (1 byte: no row above 128 entries;
+// 2 bytes: none above 65 535).  MW = 0: sum / mean, every term counts.
+template <typename T, int LPR, int U, bool GV, int MW = 0>
+__global__ void __launch_bounds__(kThreads, (MW != 0 && GV) ? 5 : 6)  // sum: 78 VGPRs without spilling at 6 waves per SIMD (81 / 5 unconstrained); masked + grad_value: 5
 spmm_half_csc_bw_kernel(const int64_t* __restrict__ colptr, const int64_t* __restrict__ row_csc,
                         const float* __restrict__ w_csc, const float* __restrict__ row_scale,
                         const uint16_t* __restrict__ mat, const uint16_t* __restrict__ grad,
                         uint16_t* __restrict__ grad_mat, float* __restrict__ grad_value, int64_t N, int64_t K,
-                        int mix_xcds) {
+                        int mix_xcds, const uint8_t* __restrict__ words = nullptr,
+                        const uint8_t* __restrict__ tags = nullptr) {
   constexpr int G = 64 / LPR;
   static_assert(64 % (G * U) == 0, "edge batch must divide the wave");
   const int lane = threadIdx.x & 63;
@@ -351,13 +366,18 @@ spmm_half_csc_bw_kernel(const int64_t* __restrict__ colptr, const int64_t* __res
     const int n = (e - base) < 64 ? static_cast<int>(e - base) : 64;
     int64_t r_l = 0;
     float v_l = 1.f, s_l = 1.f, gv_keep = 0.f;
+    uint32_t t_l = 0;
     if (lane < n) {
       r_l = row_csc[base + lane];
       if (w_csc != nullptr) v_l = w_csc[base + lane];
       if (row_scale != nullptr) s_l = row_scale[r_l];
+      if constexpr (MW == 1) t_l = tags[base + lane];
+      if constexpr (MW == 2) t_l = reinterpret_cast<const uint16_t*>(tags)[base + lane];
     }
     for (int j = 0; j < n; j += G * U) {
       uint4 raw[U];
+      using Words = typename std::conditional<MW == 2, uint4, uint2>::type;  // the 8 entries of words[r, k0 ..]: 8 or 16 bytes
+      Words wd[U];
       bool ok[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -366,6 +386,10 @@ spmm_half_csc_bw_kernel(const int64_t* __restrict__ colptr, const int64_t* __res
         ok[u] = (idx < n) && kact;
         raw[u] = make_uint4(0u, 0u, 0u, 0u);
         if (ok[u]) raw[u] = *reinterpret_cast<const uint4*>(gk + r * K);
+        if constexpr (MW != 0) {
+          wd[u] = {};
+          if (ok[u]) wd[u] = *reinterpret_cast<const Words*>(words + (r * K + k0) * MW);
+        }
       }
       float dot[U];
 #pragma unroll
@@ -375,6 +399,20 @@ spmm_half_csc_bw_kernel(const int64_t* __restrict__ colptr, const int64_t* __res
         if (row_scale != nullptr) w *= __shfl(s_l, idx);
         float b[8];
         widen8<T>(raw[u], b);
+        if constexpr (MW != 0) {  // only where the forward named this entry the winner
+          const uint32_t tag = static_cast<uint32_t>(__shfl(static_cast<int>(t_l), idx));
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            uint32_t f;
+            if constexpr (MW == 2) {
+              const uint32_t ws[4] = {wd[u].x, wd[u].y, wd[u].z, wd[u].w};
+              f = (ws[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+            } else {
+              f = ((i < 4 ? wd[u].x : wd[u].y) >> (8 * (i & 3))) & 0xffu;
+            }
+            if (f != tag) b[i] = 0.f;
+          }
+        }
         const F2 w2 = F2{w, w};
         F2 d2 = F2{0.f, 0.f};
 #pragma unroll
@@ -468,14 +506,14 @@ int launch_half_multirow(int red, bool track, bool val32, const int64_t* rowptr,
 template <typename T, int LPR, int U>
 int launch_half(int red, bool track, bool val32, const int64_t* rowptr, const int64_t* col, const void* val,
                 const uint16_t* mat, uint16_t* out, int64_t* arg_out, int64_t M, int64_t K, int64_t nnz, int mean,
-                hipStream_t s) {
+                hipStream_t s, uint8_t* arg_bytes = nullptr, int arg_width = 1) {
   const int64_t gx = psa::ceil_div(psa::ceil_div(M, kWaves), 8) * 8;  // whole groups of 8 row blocks (XCD mixing)
   const int64_t gy = psa::ceil_div(K, static_cast<int64_t>(LPR) * 8);
   PSA_REQUIRE(gx <= 0x7fffffff && gy <= 65535, "problem too large for one launch");
   const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(gy)), block(kThreads);
 #define PSA_H(R, TR, V32)                                                                              \
   hipLaunchKernelGGL((spmm_half_row_kernel<T, LPR, R, U, TR, V32>), grid, block, 0, s, rowptr, col, val, mat, out, \
-                     arg_out, M, K, nnz, mean, g_half_variant == 3 ? 0 : 1)
+                     arg_out, M, K, nnz, mean, g_half_variant == 3 ? 0 : 1, arg_bytes, arg_width)
 #define PSA_HV(R, TR)        \
   do {                       \
     if (val32) PSA_H(R, TR, true); \
@@ -498,10 +536,10 @@ int launch_half(int red, bool track, bool val32, const int64_t* rowptr, const in
 template <typename T>
 int dispatch_half(int red, bool track, bool val32, const int64_t* rowptr, const int64_t* col, const void* val,
                   const uint16_t* mat, uint16_t* out, int64_t* arg_out, int64_t M, int64_t K, int64_t nnz, int mean,
-                  hipStream_t s) {
+                  hipStream_t s, uint8_t* arg_bytes = nullptr, int arg_width = 1) {
   const int64_t q = K / 8;  // 16-byte pieces per dense row
 #define PSA_MULTI(LPR, U) return launch_half_multirow<T, LPR, U>(red, track, val32, rowptr, col, val, mat, out, arg_out, M, K, nnz, mean, s)
-  if (g_half_variant == 1) {
+  if (g_half_variant == 1 && arg_bytes == nullptr) {
     if (q <= 1) PSA_MULTI(1, 4);
     if (q <= 2) PSA_MULTI(2, 8);
     if (q <= 4) PSA_MULTI(4, 8);
@@ -509,7 +547,7 @@ int dispatch_half(int red, bool track, bool val32, const int64_t* rowptr, const 
     if (q <= 16) PSA_MULTI(16, 8);
   }
 #undef PSA_MULTI
-#define PSA_GO(LPR, U) return launch_half<T, LPR, U>(red, track, val32, rowptr, col, val, mat, out, arg_out, M, K, nnz, mean, s)
+#define PSA_GO(LPR, U) return launch_half<T, LPR, U>(red, track, val32, rowptr, col, val, mat, out, arg_out, M, K, nnz, mean, s, arg_bytes, arg_width)
   if (q <= 1) PSA_GO(1, 1);
   if (q <= 2) PSA_GO(2, 2);
   if (q <= 4) PSA_GO(4, 4);
@@ -522,10 +560,10 @@ int dispatch_half(int red, bool track, bool val32, const int64_t* rowptr, const 
 }
 
 
-template <typename T>
+template <typename T, int MW = 0>
 int dispatch_half_csc_bw(const int64_t* colptr, const int64_t* row_csc, const float* w_csc, const float* row_scale,
                          const uint16_t* mat, const uint16_t* grad, uint16_t* grad_mat, float* grad_value, int64_t N,
-                         int64_t K, hipStream_t s) {
+                         int64_t K, hipStream_t s, const uint8_t* words = nullptr, const uint8_t* tags = nullptr) {
   const int64_t gx = psa::ceil_div(psa::ceil_div(N, kWaves), 8) * 8;
   PSA_REQUIRE(gx <= 0x7fffffff, "problem too large for one launch");
   const dim3 grid(static_cast<unsigned>(gx)), block(kThreads);
@@ -533,11 +571,11 @@ int dispatch_half_csc_bw(const int64_t* colptr, const int64_t* row_csc, const fl
 #define PSA_GO(LPR, U)                                                                                              \
   do {                                                                                                              \
     if (grad_value != nullptr)                                                                                      \
-      hipLaunchKernelGGL((spmm_half_csc_bw_kernel<T, LPR, U, true>), grid, block, 0, s, colptr, row_csc, w_csc,     \
-                         row_scale, mat, grad, grad_mat, grad_value, N, K, 1);                                      \
+      hipLaunchKernelGGL((spmm_half_csc_bw_kernel<T, LPR, U, true, MW>), grid, block, 0, s, colptr, row_csc, w_csc, \
+                         row_scale, mat, grad, grad_mat, grad_value, N, K, 1, words, tags);                         \
     else                                                                                                            \
-      hipLaunchKernelGGL((spmm_half_csc_bw_kernel<T, LPR, U, false>), grid, block, 0, s, colptr, row_csc, w_csc,    \
-                         row_scale, mat, grad, grad_mat, grad_value, N, K, 1);                                      \
+      hipLaunchKernelGGL((spmm_half_csc_bw_kernel<T, LPR, U, false, MW>), grid, block, 0, s, colptr, row_csc, w_csc, \
+                         row_scale, mat, grad, grad_mat, grad_value, N, K, 1, words, tags);                         \
     PSA_LAUNCH_CHECK();                                                                                             \
     return PSA_OK;                                                                                                  \
   } while (0)
@@ -585,9 +623,9 @@ extern "C" int psa_spmm_half_set_variant(int v) {
   return prev;
 }
 
-extern "C" int psa_spmm_half(int reduce, int dtype, const int64_t* rowptr, const int64_t* col, const void* value,
-                             int value_dtype, const void* mat, int64_t M, int64_t N, int64_t K, int64_t nnz,
-                             void* out, int64_t* arg_out, psa_stream_t stream) {
+extern "C" int psa_spmm_half_arg(int reduce, int dtype, const int64_t* rowptr, const int64_t* col, const void* value,
+                                 int value_dtype, const void* mat, int64_t M, int64_t N, int64_t K, int64_t nnz,
+                                 void* out, int64_t* arg_out, void* arg_bytes, int arg_width, psa_stream_t stream) {
   (void)N;
   PSA_REQUIRE(reduce >= PSA_SUM && reduce <= PSA_MAX, "bad reduce");
   PSA_REQUIRE(M >= 0 && K >= 0 && nnz >= 0, "negative size");
@@ -600,19 +638,66 @@ extern "C" int psa_spmm_half(int reduce, int dtype, const int64_t* rowptr, const
     return PSA_ERR_UNSUPPORTED;
   }
   PSA_REQUIRE(value == nullptr || value_dtype == PSA_F32 || value_dtype == dtype, "value must be fp32 or mat's dtype");
+  PSA_REQUIRE(arg_bytes == nullptr || ((arg_width == 1 || arg_width == 2) && psa::aligned(arg_bytes, 8)),
+              "arg_bytes: width 1 or 2, 8-byte aligned");
   if (M == 0 || K == 0) return PSA_OK;
   PSA_REQUIRE(rowptr != nullptr && out != nullptr, "NULL pointer");
   PSA_REQUIRE(nnz == 0 || (col != nullptr && mat != nullptr), "col/mat is NULL");
   const bool minmax = reduce == PSA_MIN || reduce == PSA_MAX;
   const int red = reduce == PSA_MIN ? R_MIN : (reduce == PSA_MAX ? R_MAX : R_SUM);
-  const bool track = minmax && arg_out != nullptr;
+  uint8_t* ab = minmax ? static_cast<uint8_t*>(arg_bytes) : nullptr;
+  const bool track = minmax && (arg_out != nullptr || ab != nullptr);
   const bool val32 = value != nullptr && value_dtype == PSA_F32;
   hipStream_t s = psa::as_stream(stream);
   const uint16_t* m = static_cast<const uint16_t*>(mat);
   uint16_t* o = static_cast<uint16_t*>(out);
   if (dtype == PSA_BF16)
-    return dispatch_half<BF16>(red, track, val32, rowptr, col, value, m, o, arg_out, M, K, nnz, reduce == PSA_MEAN, s);
-  return dispatch_half<F16>(red, track, val32, rowptr, col, value, m, o, arg_out, M, K, nnz, reduce == PSA_MEAN, s);
+    return dispatch_half<BF16>(red, track, val32, rowptr, col, value, m, o, arg_out, M, K, nnz, reduce == PSA_MEAN, s, ab,
+                               arg_width);
+  return dispatch_half<F16>(red, track, val32, rowptr, col, value, m, o, arg_out, M, K, nnz, reduce == PSA_MEAN, s, ab,
+                            arg_width);
+}
+
+extern "C" int psa_spmm_half(int reduce, int dtype, const int64_t* rowptr, const int64_t* col, const void* value,
+                             int value_dtype, const void* mat, int64_t M, int64_t N, int64_t K, int64_t nnz,
+                             void* out, int64_t* arg_out, psa_stream_t stream) {
+  return psa_spmm_half_arg(reduce, dtype, rowptr, col, value, value_dtype, mat, M, N, K, nnz, out, arg_out, nullptr, 1,
+                           stream);
+}
+
+extern "C" int psa_spmm_half_minmax_bw_csc(int dtype, const int64_t* colptr, const int64_t* row_csc, const void* tag,
+                                           const float* weight_csc, const void* mat, const void* grad,
+                                           const void* arg_bytes, int arg_width, int64_t M, int64_t N, int64_t K,
+                                           int64_t nnz, float* grad_value_csc, void* grad_mat, psa_stream_t stream) {
+  PSA_REQUIRE(M >= 0 && N >= 0 && K >= 0 && nnz >= 0, "negative size");
+  if (dtype != PSA_F16 && dtype != PSA_BF16) {
+    psa::set_error("psa_spmm_half_minmax_bw_csc: dtype must be PSA_F16 or PSA_BF16");
+    return PSA_ERR_UNSUPPORTED;
+  }
+  if (K % 8 != 0 || K > 512 || !psa::aligned(mat, 16) || !psa::aligned(grad, 16) || !psa::aligned(grad_mat, 16)) {
+    psa::set_error("psa_spmm_half_minmax_bw_csc: needs K % 8 == 0, K <= 512 and 16-byte aligned operands");
+    return PSA_ERR_UNSUPPORTED;
+  }
+  PSA_REQUIRE(arg_width == 1 || arg_width == 2, "arg_width must be 1 or 2");
+  if (N == 0 || K == 0) return PSA_OK;
+  PSA_REQUIRE(colptr && grad_mat, "NULL pointer");
+  PSA_REQUIRE(nnz == 0 || (row_csc && grad && tag && arg_bytes), "NULL pointer");
+  PSA_REQUIRE(arg_bytes == nullptr || psa::aligned(arg_bytes, 8 * arg_width), "arg_bytes alignment");
+  PSA_REQUIRE(grad_value_csc == nullptr || mat != nullptr || nnz == 0, "grad_value needs mat");
+  hipStream_t s = psa::as_stream(stream);
+  const uint16_t* m = static_cast<const uint16_t*>(mat);
+  const uint16_t* g = static_cast<const uint16_t*>(grad);
+  uint16_t* gm = static_cast<uint16_t*>(grad_mat);
+  const uint8_t* words = static_cast<const uint8_t*>(arg_bytes);
+  const uint8_t* tags = static_cast<const uint8_t*>(tag);
+#define PSA_MM(T, MW) return dispatch_half_csc_bw<T, MW>(colptr, row_csc, weight_csc, nullptr, m, g, gm, grad_value_csc, N, K, s, words, tags)
+  if (dtype == PSA_BF16) {
+    if (arg_width == 2) PSA_MM(BF16, 2);
+    PSA_MM(BF16, 1);
+  }
+  if (arg_width == 2) PSA_MM(F16, 2);
+  PSA_MM(F16, 1);
+#undef PSA_MM
 }
 
 extern "C" size_t psa_spmm_half_workspace_bytes(int reduce, int64_t K, int64_t nnz) {

@@ -53,6 +53,14 @@ def _streamed_values(st: SparseStorage, value: Optional[torch.Tensor]) -> Option
     return None if plan is None else ops.permute_apply(value.detach().contiguous(), plan)
 
 
+def _half_minmax_bw_ok(st: SparseStorage, K: int) -> bool:
+    """Will the half-width masked pass over the CSC view serve the min / max backward of this matrix?  K in one
+    tile, an exact row-local form (no row above 65 535 entries), and a transpose that takes the row-wave family
+    (one wave per column; power-law transposes keep the fp32 route with its long-column and hub-row machinery)."""
+    return (ops.half_sum_bw_csc_supported(K) and st._longest_row() <= ops.ARG_WORDS_EXACT_ROW
+            and st._spmm_algo() == "row_waves" and st._csc_view()._spmm_algo() == "row_waves")
+
+
 def spmm_planned(st: SparseStorage, weights: Optional[torch.Tensor], mat: torch.Tensor, reduce: str = "sum",
                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """reduce-SpMM of the matrix `st` describes (values `weights`, given separately; `out` only, no
@@ -106,10 +114,20 @@ class _SpMM(torch.autograd.Function):
                 plan = storage._hot_columns()
                 if plan is not None:
                     hot_rows, col = ops._gather_rows_raw(mat.detach(), plan[0]), plan[1]
-            out, arg = ops._spmm(reduce, rowptr, col, value, mat, want_arg=need and reduce in ("min", "max"), row=row,
-                                 algo=algo, hot_rows=hot_rows)
+            arg_bytes = None
+            need_mat = track and ctx.needs_input_grad[1]
+            if (reduce in ("min", "max") and need and need_mat and algo == "auto" and _half_minmax_bw_ok(storage, mat.shape[1])
+                    and (value is None or value.dtype in (torch.float32, mat.dtype))):
+                # min / max whose backward will be the half-width masked pass over the CSC view: the forward leaves the
+                # row-local form of arg_out only (1 byte per element up to 128-entry rows, 2 up to 65 535) — no int64
+                # arg_out (8 bytes per element against the 2 of `out` itself)
+                width = 2 if storage._longest_row() > ops.ARG_BYTES_EXACT_ROW else 1
+                out, arg, arg_bytes = ops._spmm(reduce, rowptr, col, value, mat, want_arg=False, want_arg_bytes=width)
+            else:
+                out, arg = ops._spmm(reduce, rowptr, col, value, mat, want_arg=need and reduce in ("min", "max"), row=row,
+                                     algo=algo, hot_rows=hot_rows)
             ctx.storage, ctx.reduce, ctx.half = storage, reduce, mat.dtype
-            ctx.save_for_backward(value, mat, arg, None)
+            ctx.save_for_backward(value, mat, arg, arg_bytes)
             return out
         ctx.half = None
         algo = storage._spmm_algo()  # per-matrix choice, read once
@@ -180,6 +198,24 @@ class _SpMM(torch.autograd.Function):
             plan = st._permute_plan("to_csr")
             gv = ops.permute_apply(gv, plan) if plan is not None else ops.gather_rows(gv, st.csc2csr())
             return gv.to(value.dtype), gm, None, None, None
+        if (ctx.half is not None and reduce in ("min", "max") and arg_bytes is not None and need_mat
+                and grad_out.dtype == ctx.half):
+            # min / max, half-width operands: the masked half-width pass over the CSC view (both gradients when
+            # the values are trained), fed by the row-local arg_out the forward left — no fp32 copies
+            csr2csc = st.csr2csc()
+            width = arg_bytes.element_size()
+            w = None
+            if value is not None:
+                v32 = value.detach().float()
+                w = _streamed_values(st, v32)
+                if w is None:
+                    w = _csc_weights(st, v32, csr2csc, st._row_in_csc_order(), False)
+            gv, gm = ops.spmm_half_minmax_bw_csc(st.colptr(), st._row_in_csc_order(), st._csc_edge_tags(width), w, mat,
+                                                 grad_out, arg_bytes, want_value=need_value)
+            if gv is not None:
+                plan = st._permute_plan("to_csr")
+                gv = (ops.permute_apply(gv, plan) if plan is not None else ops.gather_rows(gv, st.csc2csr())).to(value.dtype)
+            return gv, gm, None, None, None
         if ctx.half is not None:
             gv, gm = _SpMM._backward_fp32(st, reduce, None if value is None else value.float(), mat.float(),
                                           grad_out.float(), arg, None, need_value, need_mat)

@@ -129,9 +129,10 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
             raise ValueError("row must have one entry per edge")
     _gpu(mat, "mat")
     if mat.dtype in (torch.float16, torch.bfloat16):
-        if out is not None or want_arg_bytes:
-            raise ValueError("the half-width SpMM takes neither `out` nor arg_bytes")
-        res = _spmm_half(reduce, rowptr, col, value, mat, want_arg, row=row, algo=algo, hot_rows=hot_rows)
+        if out is not None:
+            raise ValueError("the half-width SpMM does not take `out`")
+        res = _spmm_half(reduce, rowptr, col, value, mat, want_arg, row=row, algo=algo, hot_rows=hot_rows,
+                         want_arg_bytes=want_arg_bytes)
         return res
     if mat.dtype != torch.float32:
         raise TypeError(f"spmm takes float32, float16 or bfloat16 dense operands (mat is {mat.dtype})")
@@ -193,7 +194,7 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
 
 
 def _spmm_half(reduce: str, rowptr, col, value, mat, want_arg: bool = True, row=None, algo: str = "auto",
-               hot_rows=None):
+               hot_rows=None, want_arg_bytes=False):
     """fp16 / bf16 `mat` -> (out in mat's dtype, arg_out | None): fp32 products and sums,
     one rounding on store (psa_spmm_half / psa_spmm_half_coo).  value: None, float32[nnz] or
     mat's dtype[nnz].  algo="edge_ranges" (with `row`, `hot_rows` as for fp32; fp32 or no values):
@@ -209,6 +210,8 @@ def _spmm_half(reduce: str, rowptr, col, value, mat, want_arg: bool = True, row=
         if value.dtype not in (torch.float32, mat.dtype) or value.dim() != 1 or value.numel() != nnz:
             raise ValueError("value must be float32[nnz] or mat's dtype[nnz]")
         value = value.contiguous()
+    if want_arg_bytes and (K % 8 != 0 or algo == "edge_ranges"):
+        raise ValueError("the half-width SpMM writes arg_bytes on the row-wave kernels only (K % 8 == 0)")
     if K % 8 != 0:
         res = _spmm(reduce, rowptr, col, None if value is None else value.float(), mat.float(), want_arg=want_arg)
         return res[0].to(mat.dtype), res[1]
@@ -230,10 +233,15 @@ def _spmm_half(reduce: str, rowptr, col, value, mat, want_arg: bool = True, row=
         return out, arg
     if hot_rows is not None:
         raise ValueError("hot_rows needs algo='edge_ranges' and fp32 (or no) values")
+    arg_bytes, width = None, 2 if want_arg_bytes == 2 else 1
+    if want_arg_bytes and minmax:  # the row-local form for the half-width one-pass backward (one wave per row only)
+        arg_bytes = torch.empty((M, K), dtype=torch.int16 if width == 2 else torch.uint8, device=mat.device)
     with _on(mat.device):
-        check(_lib.load().psa_spmm_half(rid, _DTYPE_ID[mat.dtype], _ptr(rowptr), _ptr(col), _ptr(value),
-                                        _DTYPE_ID[value.dtype] if value is not None else 0, _ptr(mat), M, N, K, nnz,
-                                        _ptr(out), _ptr(arg), _stream()))
+        check(_lib.load().psa_spmm_half_arg(rid, _DTYPE_ID[mat.dtype], _ptr(rowptr), _ptr(col), _ptr(value),
+                                            _DTYPE_ID[value.dtype] if value is not None else 0, _ptr(mat), M, N, K, nnz,
+                                            _ptr(out), _ptr(arg), _ptr(arg_bytes), width, _stream()))
+    if want_arg_bytes:
+        return out, arg, arg_bytes
     return out, arg
 
 
@@ -1096,6 +1104,39 @@ def spmm_half_sum_bw_csc(colptr, row_csc, weight_csc, mat, grad, want_value: boo
         check(_lib.load().psa_spmm_half_sum_bw_csc(_DTYPE_ID[grad.dtype], _ptr(colptr), _ptr(row_csc), _ptr(weight_csc),
                                                    _ptr(row_scale), _ptr(mat) if want_value else None, _ptr(grad), M, N, K,
                                                    nnz, _ptr(gv), _ptr(gm), _stream()))
+    return gv, gm
+
+
+def spmm_half_minmax_bw_csc(colptr, row_csc, tag, weight_csc, mat, grad, arg_bytes, want_value: bool = True):
+    """min / max backward over the CSC view with fp16 / bf16 dense operands (psa_spmm_half_minmax_bw_csc):
+    returns (grad_value f32[nnz] IN CSC ORDER | None, grad_mat [N, K] in grad's dtype).  tag / arg_bytes:
+    uint8 or int16, the exact row-local forms (ops.csc_edge_tags / the third result of ops._spmm)."""
+    colptr, row_csc = _index(colptr, "colptr"), _index(row_csc, "row_csc")
+    _gpu(grad, "grad")
+    if grad.dtype not in (torch.float16, torch.bfloat16) or grad.dim() != 2:
+        raise TypeError("grad must be a 2-D float16 / bfloat16 tensor")
+    grad = grad.contiguous()
+    (M, K), N, nnz = grad.shape, colptr.numel() - 1, row_csc.numel()
+    _gpu(tag, "tag")
+    _gpu(arg_bytes, "arg_bytes")
+    if tag.dtype not in (torch.uint8, torch.int16) or arg_bytes.dtype != tag.dtype or arg_bytes.shape != grad.shape or tag.numel() != nnz:
+        raise ValueError("tag / arg_bytes must be uint8 or int16, tag [nnz], arg_bytes [M, K] like grad")
+    arg_bytes, tag = arg_bytes.contiguous(), tag.contiguous()
+    if weight_csc is not None:
+        weight_csc = _f32(weight_csc, "weight_csc")
+    gv = None
+    if want_value:
+        _gpu(mat, "mat")
+        if mat.dtype != grad.dtype or mat.shape != (N, K):
+            raise ValueError("mat must be [N, K] in grad's dtype")
+        mat = mat.contiguous()
+        gv = torch.empty(nnz, dtype=torch.float32, device=grad.device)
+    gm = torch.empty((N, K), dtype=grad.dtype, device=grad.device)
+    with _on(grad.device):
+        check(_lib.load().psa_spmm_half_minmax_bw_csc(_DTYPE_ID[grad.dtype], _ptr(colptr), _ptr(row_csc), _ptr(tag),
+                                                      _ptr(weight_csc), _ptr(mat) if want_value else None, _ptr(grad),
+                                                      _ptr(arg_bytes), tag.element_size(), M, N, K, nnz, _ptr(gv), _ptr(gm),
+                                                      _stream()))
     return gv, gm
 
 

@@ -321,3 +321,66 @@ def test_half_backward_with_trained_values_stays_half_width(dtype, reduce, K, va
     gv_S = oracle.spmm_value_bw(reduce, row, rowptr, col, np.abs(Bf), np.abs(Gf))
     cast = eps * np.abs(gv_ref) + tiny if value_dtype == "half" else 0.0
     assert np.all(np.abs(v.grad.float().cpu().numpy() - gv_ref) <= 1e-5 * gv_S + cast + 1e-30)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("reduce", ["min", "max"])
+@pytest.mark.parametrize("K", [8, 64, 128, 512])
+@pytest.mark.parametrize("mode", ["trained f32 values", "trained half values", "fixed adjacency", "no values"])
+@pytest.mark.parametrize("long_row", [0, 300])  # 0: one-byte row-local arg_out; 300: a row above 128 entries -> two bytes
+def test_half_minmax_backward_stays_half_width(dtype, reduce, K, mode, long_row):
+    """VERDICT r02 #9a, min / max: with a half-width dense operand the forward leaves the row-local arg_out only
+    (no int64 arg_out) and the backward is ONE masked half-width pass over the CSC view — no fp32 copies of mat /
+    grad_out, no fp32 kernel.  Winners are exact (a product of the rounded operands is the same fp32 number on
+    both sides), so grad_mat / grad_value are the oracle's on the rounded inputs up to the summation order and
+    the one rounding on store."""
+    from paddle_sparse_amd import SparseTensor, ops
+
+    rng = np.random.default_rng(K + long_row)
+    M, N = 2000, 1500
+    row, rowptr, col, val = random_csr(M, N, 24_000, seed=K + 1, sort_cols=True)
+    if long_row:
+        extra_c = rng.choice(N, long_row, replace=False)
+        row = np.concatenate([row, np.full(long_row, 7)])
+        col = np.concatenate([col, extra_c])
+        val = np.concatenate([val, rng.standard_normal(long_row).astype(np.float32)])
+    key = np.unique(row * N + col, return_index=True)[1]
+    row, col, val = row[key], col[key], val[key]
+    order = np.lexsort((col, row))
+    row, col, val = row[order], col[order], val[order]
+    rowptr = oracle.ind2ptr(row, M)
+    d = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()  # noqa: E731
+    Bd, Bf = rounded(rng.standard_normal((N, K)).astype(np.float32), dtype)
+    Gd, Gf = rounded(rng.standard_normal((M, K)).astype(np.float32), dtype)
+    if mode == "trained half values":
+        vd, vf = rounded(val, dtype)
+    elif mode == "no values":
+        vd, vf = None, np.ones(col.size, np.float32)
+    else:
+        vd, vf = d(val), val
+    trained = mode.startswith("trained")
+    v = None if vd is None else (vd.clone().requires_grad_() if trained else vd)
+    Bt = Bd.clone().requires_grad_()
+    a = SparseTensor(row=d(row), col=d(col), value=v, sparse_sizes=(M, N), is_sorted=True)
+    called = []
+    real = (ops.spmm_minmax_bw_csc, ops.spmm_minmax_bw, ops.spmm_minmax_bw_eb)
+    ops.spmm_minmax_bw_csc = lambda *x, **k: called.append("fp32 csc") or real[0](*x, **k)
+    ops.spmm_minmax_bw = lambda *x, **k: called.append("fp32 atomics") or real[1](*x, **k)
+    ops.spmm_minmax_bw_eb = lambda *x, **k: called.append("fp32 eb") or real[2](*x, **k)
+    try:
+        out = a.matmul(Bt, reduce)
+        out.backward(Gd)
+    finally:
+        ops.spmm_minmax_bw_csc, ops.spmm_minmax_bw, ops.spmm_minmax_bw_eb = real
+    assert called == [], called
+    ref_out, ref_arg = oracle.spmm(reduce, rowptr, col, vf, Bf)
+    eps, tiny = EPS[dtype], TINY[dtype]
+    assert np.all(np.abs(out.detach().float().cpu().numpy() - ref_out) <= eps * np.abs(ref_out) + tiny)
+    gv_ref, gm_ref = oracle.spmm_minmax_bw(col, vf, Bf, Gf, ref_arg)
+    gv_S, gm_S = oracle.spmm_minmax_bw(col, np.abs(vf), np.abs(Bf), np.abs(Gf), ref_arg)
+    assert Bt.grad.dtype == dtype
+    assert np.all(np.abs(Bt.grad.float().cpu().numpy() - gm_ref) <= 1e-5 * gm_S + eps * np.abs(gm_ref) + tiny + 1e-30)
+    if trained:
+        assert v.grad.dtype == vd.dtype
+        cast = eps * np.abs(gv_ref) + tiny if mode == "trained half values" else 0.0
+        assert np.all(np.abs(v.grad.float().cpu().numpy() - gv_ref) <= 1e-5 * gv_S + cast + 1e-30)

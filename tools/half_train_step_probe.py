@@ -21,7 +21,7 @@ for dtype in (torch.float32, torch.bfloat16, torch.float16):
     Bt = B.detach().to(dtype, copy=True).requires_grad_()  # a leaf of its own (B itself must stay without grad)
     Gd = G.to(dtype)
     a = SparseTensor(rowptr=rowptr, col=col, value=v, sparse_sizes=(M, N), is_sorted=True, trust_data=True)
-    for reduce in ("sum", "mean"):
+    for reduce in ("sum", "mean", "max"):
         def step():
             v.grad = Bt.grad = None
             a.matmul(Bt, reduce).backward(Gd)
