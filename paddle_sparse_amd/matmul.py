@@ -42,14 +42,15 @@ def _csc_weights(st: SparseStorage, value: Optional[torch.Tensor], csr2csc, row_
     return w
 
 
-def _streamed_values(st: SparseStorage, value: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+def _streamed_values(st: SparseStorage, value: Optional[torch.Tensor], plan="ask") -> Optional[torch.Tensor]:
     """value[csr2csc] through the storage's planned route (two streaming passes, 0.12 ms at 20 M
     entries), for the passes over the CSC view: they then read their weights as a stream instead
     of through nnz dependent 4-byte reads value[csr2csc[j]] (18 % of such a pass's memory
     requests).  None when there is no plan (small matrices) — the pass reads through csr2csc."""
     if value is None or value.dtype != torch.float32 or value.dim() != 1:
         return None
-    plan = st._permute_plan("to_csc")
+    if isinstance(plan, str):  # "ask": one request to the storage (it builds a plan on the second one)
+        plan = st._permute_plan("to_csc")
     return None if plan is None else ops.permute_apply(value.detach().contiguous(), plan)
 
 
@@ -190,13 +191,19 @@ class _SpMM(torch.autograd.Function):
             # column: matrices whose transpose takes the row-wave family; power-law ones widen as before)
             csr2csc = st.csr2csc()
             v32 = value.detach().float()
-            w = _streamed_values(st, v32)
+            mean = reduce == "mean"
+            back, forth = st._permute_plan("to_csr"), st._permute_plan("to_csc")
+            folded = mean and back is not None and forth is not None
+            # mean on the planned routes: 1 / deg(row) rides in the weights and is applied to grad_value after its
+            # way back (SparseStorage._mean_scale_per_entry) instead of a dependent read per CSC entry inside the pass
+            w = _streamed_values(st, v32 * st._mean_scale_per_entry() if folded else v32, plan=forth)
             if w is None:
                 w = ops.transpose_weights(v32, csr2csc, None, None, False)
-            scale = (1.0 / st.rowcount().clamp(min=1).to(torch.float32)) if reduce == "mean" else None
+            scale = (1.0 / st.rowcount().clamp(min=1).to(torch.float32)) if mean and not folded else None
             gv, gm = ops.spmm_half_sum_bw_csc(st.colptr(), st._row_in_csc_order(), w, mat, grad_out, True, row_scale=scale)
-            plan = st._permute_plan("to_csr")
-            gv = ops.permute_apply(gv, plan) if plan is not None else ops.gather_rows(gv, st.csc2csr())
+            gv = ops.permute_apply(gv, back) if back is not None else ops.gather_rows(gv, st.csc2csr())
+            if folded:
+                gv = gv * st._mean_scale_per_entry()
             return gv.to(value.dtype), gm, None, None, None
         if (ctx.half is not None and reduce in ("min", "max") and arg_bytes is not None and need_mat
                 and grad_out.dtype == ctx.half):
@@ -205,11 +212,8 @@ class _SpMM(torch.autograd.Function):
             csr2csc = st.csr2csc()
             width = arg_bytes.element_size()
             w = None
-            if value is not None:
-                v32 = value.detach().float()
-                w = _streamed_values(st, v32)
-                if w is None:
-                    w = _csc_weights(st, v32, csr2csc, st._row_in_csc_order(), False)
+            if value is not None:  # value[csr2csc]: the planned route when the storage has one (one request), else the gather
+                w = _csc_weights(st, value.detach().float(), csr2csc, st._row_in_csc_order(), False)
             gv, gm = ops.spmm_half_minmax_bw_csc(st.colptr(), st._row_in_csc_order(), st._csc_edge_tags(width), w, mat,
                                                  grad_out, arg_bytes, want_value=need_value)
             if gv is not None:
@@ -267,14 +271,20 @@ class _SpMM(torch.autograd.Function):
                 # the column's own mat row, grad_value (instead of a second full
                 # gather of mat rows in spmm_value_bw plus the weight gather).
                 csr2csc = st.csr2csc()
-                # mean: 1/deg(row) multiplies both gradients, per edge, inside the pass
-                scale = (1.0 / st.rowcount().clamp(min=1).to(torch.float32)) if mean else None
+                back, forth = st._permute_plan("to_csr"), st._permute_plan("to_csc")
+                folded = mean and back is not None and forth is not None and value.dtype == torch.float32
+                # mean: 1/deg(row) multiplies both gradients per edge — inside the pass (row_scale, a dependent read per
+                # CSC entry), or, on the planned routes, folded into the weights before their way to CSC order and into
+                # grad_value after its way back (two streaming multiplies; SparseStorage._mean_scale_per_entry)
+                scale = (1.0 / st.rowcount().clamp(min=1).to(torch.float32)) if mean and not folded else None
                 plan = st._csc_view()._hot_columns()  # hub rows: grad_out rows from a compact copy
+                streamed = _streamed_values(st, value.detach() * st._mean_scale_per_entry() if folded else value, plan=forth)
                 grad_value, grad_mat = ops.spmm_sum_bw_csc(st.colptr(), st._row_in_csc_order() if plan is None else plan[1],
                                                            csr2csc, value, mat, grad_out, True, csc2csr=st.csc2csr(),
                                                            row_scale=scale, hot_ids=None if plan is None else plan[0],
-                                                           to_csr_plan=st._permute_plan("to_csr"),
-                                                           value_csc=_streamed_values(st, value))
+                                                           to_csr_plan=back, value_csc=streamed)
+                if folded:
+                    grad_value = grad_value * st._mean_scale_per_entry()
                 return grad_value, grad_mat
             if need_value:
                 grad_value = ops.spmm_value_bw(None, st.rowptr(), st.col(), mat, grad_out,

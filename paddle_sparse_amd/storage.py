@@ -351,6 +351,16 @@ class SparseStorage(object):
             plans[direction] = ops.permute_plan(self.csc2csr() if direction == "to_csc" else self.csr2csc())
         return plans[direction]
 
+    def _mean_scale_per_entry(self) -> torch.Tensor:
+        """1 / max(deg(row), 1) of every entry, CSR order (fp32[nnz], structure only, memoised): with it the mean
+        backward folds the scale into the weights BEFORE their planned way to CSC order and into grad_value AFTER
+        its way back — two streaming multiplies instead of a dependent 4-byte read row_scale[r] per CSC entry
+        inside the pass (+0.18 ms at 20 M entries)."""
+        if getattr(self, "_mean_scale_memo", None) is None:
+            scale = 1.0 / self.rowcount().clamp(min=1).to(torch.float32)
+            self._mean_scale_memo = ops.gather_rows(scale, self.row())
+        return self._mean_scale_memo
+
     def _longest_row(self) -> int:
         """Entries of the longest row (memoised; the min/max forward asks whether
         the one-byte form of arg_out is complete, i.e. no row above 128)."""
@@ -475,6 +485,7 @@ class SparseStorage(object):
         self._hot_memo = None
         self._csc_view_memo = None
         self._perm_plans = {}
+        self._mean_scale_memo = None
         return self
 
     def cached_keys(self) -> List[str]:
@@ -497,6 +508,7 @@ class SparseStorage(object):
             out._hot_memo = self._hot_memo
             out._csc_view_memo = self._csc_view_memo
             out._perm_plans = self._perm_plans
+            out._mean_scale_memo = getattr(self, "_mean_scale_memo", None)
         return out
 
     def _map(self, fn: Callable[[torch.Tensor], torch.Tensor]):

@@ -568,3 +568,45 @@ def test_minmax_grad_mat_by_edge_ranges_over_the_csc_view(reduce, K, width, has_
     slot[hot] = torch.arange(hot.numel(), device="cuda")
     redirected = torch.where(slot[row_csc] >= 0, M + slot[row_csc], row_csc)
     assert torch.equal(got, ops.spmm_minmax_bw_eb(st.colptr(), view_row, redirected, tags, w, G, words, hot_ids=hot))
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean", "max"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_autograd_steps_agree_before_and_after_the_planned_routes_exist(reduce, dtype):
+    """A storage builds its planned CSR <-> CSC routes on the SECOND request (storage._permute_plan): the first
+    backward of a training loop gathers through csr2csc / csc2csr and reads row_scale inside the pass, later ones
+    stream the weights, fold the mean scale into them and bring grad_value back along the plan.  Same gradients:
+    grad_value bit for bit for sum / max in fp32 (same terms, same order), within 1e-5 * sum|terms| for mean (the
+    scale multiplies at another point) and for the half-width passes."""
+    from paddle_sparse_amd import SparseTensor, ops
+
+    M, N, nnz, K = 250_000, 200_000, 1_300_000, 32
+    row, rowptr, col, val = random_csr(M, N, nnz, seed=11, sort_cols=True)
+    keep = np.concatenate([[True], (row[1:] != row[:-1]) | (col[1:] != col[:-1])])
+    row, col, val = row[keep], col[keep], val[keep]
+    assert col.size >= ops.PERMUTE_PLAN_FROM
+    v = dev(val).requires_grad_()
+    B = torch.randn(N, K, device="cuda").to(dtype).requires_grad_()
+    G = torch.randn(M, K, device="cuda").to(dtype)
+    a = SparseTensor(row=dev(row), col=dev(col), value=v, sparse_sizes=(M, N), is_sorted=True)
+    grads = []
+    for step in range(3):
+        v.grad = B.grad = None
+        a.matmul(B, reduce).backward(G)
+        grads.append((v.grad.clone(), B.grad.clone()))
+        if step == 0:
+            assert not any(isinstance(k, str) for k in a.storage._perm_plans)  # asked once, not built yet
+    built = set(k for k in a.storage._perm_plans if isinstance(k, str))
+    assert "to_csr" in built and built <= {"to_csr", "to_csc"}  # (to_csc is not asked for again while value[csr2csc] is memoised)
+    (gv0, gm0), (gv2, gm2) = grads[0], grads[2]
+    assert torch.equal(grads[1][0], gv2) and torch.equal(grads[1][1], gm2)  # steps 2 and 3 run the same code
+    if dtype == torch.float32 and reduce != "mean":
+        assert torch.equal(gv0, gv2) and torch.equal(gm0, gm2)
+    else:
+        Bf, Gf = B.detach().float(), G.float()
+        scale_v = ops.spmm_value_bw(None, a.storage.rowptr(), a.storage.col(), Bf.abs(), Gf.abs(), "sum") + 1e-30
+        assert bool(((gv0 - gv2).abs() <= 1e-5 * scale_v).all())
+        eps = 2.0 ** -8 if dtype == torch.bfloat16 else 0.0
+        scale_m = SparseTensor(row=dev(row), col=dev(col), value=dev(np.abs(val)), sparse_sizes=(M, N),
+                               is_sorted=True).t().matmul(Gf.abs()) + 1e-30
+        assert bool(((gm0.float() - gm2.float()).abs() <= 1e-5 * scale_m + 2 * eps * gm2.float().abs()).all())
