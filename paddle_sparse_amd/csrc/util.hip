@@ -46,15 +46,24 @@ split_keys_kernel(const int64_t* __restrict__ keys, int64_t n, int64_t div,
 }
 
 // out[i, :] = src[perm[i], :], rows of `chunks` pieces of sizeof(T) bytes.
+// shift >= 0: chunks == 1 << shift (the usual case: 2^k-byte rows) — the row of a piece is a shift, not a
+// 64-bit division (~40 VALU instructions at 4 issue cycles each: the pack of 1.4 M 512-byte rows of the halo
+// exchange ran at 1.4 TB/s with it).
 template <typename T>
 __global__ void __launch_bounds__(kThreads)
 gather_rows_kernel(const T* __restrict__ src, const int64_t* __restrict__ perm,
-                   int64_t n, int64_t chunks, int64_t stride, int64_t first, T* __restrict__ out) {
+                   int64_t n, int64_t chunks, int64_t stride, int64_t first, T* __restrict__ out, int shift) {
   // rows of `stride` pieces in src, of which the window [first, first + chunks) is taken
   const int64_t g = static_cast<int64_t>(blockIdx.x) * kThreads + threadIdx.x;
   if (g >= n * chunks) return;
-  const int64_t i = chunks == 1 ? g : g / chunks;
-  const int64_t c = chunks == 1 ? 0 : g - i * chunks;
+  int64_t i, c;
+  if (shift >= 0) {
+    i = g >> shift;
+    c = g & (chunks - 1);
+  } else {
+    i = g / chunks;
+    c = g - i * chunks;
+  }
   out[g] = src[perm[i] * stride + first + c];
 }
 
@@ -169,9 +178,14 @@ int launch_gather(const void* src, const int64_t* perm, int64_t n,
   const int64_t first = offset_bytes / static_cast<int64_t>(sizeof(T));
   const int64_t blocks = psa::ceil_div(n * chunks, kThreads);
   PSA_REQUIRE(blocks <= 0x7fffffff, "too many elements for one launch");
+  int shift = -1;
+  if ((chunks & (chunks - 1)) == 0) {
+    shift = 0;
+    while ((int64_t{1} << shift) < chunks) ++shift;
+  }
   hipLaunchKernelGGL((gather_rows_kernel<T>), dim3(static_cast<unsigned>(blocks)),
                      dim3(kThreads), 0, s, static_cast<const T*>(src), perm, n,
-                     chunks, stride, first, static_cast<T*>(out));
+                     chunks, stride, first, static_cast<T*>(out), shift);
   PSA_LAUNCH_CHECK();
   return PSA_OK;
 }
