@@ -245,6 +245,29 @@ def breadth(rowptr, col, val, B, reps: int):
     return out
 
 
+def config2(device):
+    """BASELINE config 2: spmm_sum forward, CSR 100k x 100k, nnz 1 M, F = 64 — a 45 us problem, timed over 200 calls
+    through the tensor surface (which knows the longest row and skips the long-row launches) and as the raw op."""
+    from paddle_sparse_amd import SparseTensor, ops
+
+    M = N = 100_000
+    nnz, F = 1_000_000, 64
+    rowptr, col, val = make_workload(M, N, nnz, F, 1, device)
+    B = torch.randn(N, F, device=device)
+    a = SparseTensor(rowptr=rowptr, col=col, value=val, sparse_sizes=(M, N), is_sorted=True, trust_data=True)
+    nb = algorithmic_bytes(nnz, M, F)
+    out = {}
+    with torch.no_grad():
+        for name, fn in (("tensor_surface", lambda: a.matmul(B)), ("raw_op", lambda: ops.spmm_sum(rowptr, col, val, B))):
+            for _ in range(50):
+                fn()
+            ms = event_ms(fn, 200)
+            out[name] = {"us": round(ms * 1e3, 2), "gedges_per_s": round(nnz / ms / 1e6, 3),
+                         "frac_of_hbm_peak": round(nb / ms / 1e6 / HBM_PEAK_GBS, 4)}
+    out["algorithmic_gb"] = round(nb / 1e9, 4)
+    return out
+
+
 def power_law(device, F: int, reps: int):
     """The forward on a power-law graph (R-MAT scale 21, 19.5 M entries), both kernel families,
     as generated and with relabelled columns."""
@@ -608,6 +631,7 @@ def main() -> None:
             # after the timed region: the rest of BASELINE config 3 (mean / max forward, sum / max
             # forward + backward) and the forward on a power-law graph; headline fields unchanged
             line["c3_other_ops"] = breadth(rowptr, col, val, B_full, max(5, args.steps // 5))
+            line["c2_spmm_sum_fwd"] = config2(device)
             del out
             line["power_law"] = power_law(device, F, max(5, args.steps // 5))
         if stdout_fd is not None:

@@ -80,7 +80,7 @@ def spmm_planned(st: SparseStorage, weights: Optional[torch.Tensor], mat: torch.
     else:
         algo = "auto"
     return ops._spmm(reduce, st.rowptr(), col, weights, mat, want_arg=False, row=row, algo=algo, hot_rows=hot_rows,
-                     out=out)[0]
+                     out=out, no_long_rows=st._longest_row() <= ops.LONG_ROW)[0]
 
 
 def _spmm_sum_planned(st: SparseStorage, weights: Optional[torch.Tensor], mat: torch.Tensor) -> torch.Tensor:
@@ -159,10 +159,12 @@ class _SpMM(torch.autograd.Function):
             bytes_only = csc_bw and longest <= ops.ARG_WORDS_EXACT_ROW
             want_arg = (need_value or need_mat) and not bytes_only
             res = ops._spmm(reduce, rowptr, col, value, mat, want_arg_bytes=width if csc_bw else False,
-                            want_arg=want_arg, row=row, algo=algo, hot_rows=hot_rows)
+                            want_arg=want_arg, row=row, algo=algo, hot_rows=hot_rows,
+                            no_long_rows=storage._longest_row() <= ops.LONG_ROW)
             out, arg, arg_bytes = res if csc_bw else (*res, None)
         else:
-            out = ops._spmm(reduce, rowptr, col, value, mat, row=row, algo=algo, hot_rows=hot_rows)[0]
+            out = ops._spmm(reduce, rowptr, col, value, mat, row=row, algo=algo, hot_rows=hot_rows,
+                            no_long_rows=storage._longest_row() <= ops.LONG_ROW)[0]
         ctx.storage, ctx.reduce = storage, reduce
         ctx.save_for_backward(value, mat, arg, arg_bytes)
         return out

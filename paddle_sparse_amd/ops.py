@@ -106,7 +106,8 @@ def ptr2ind(ptr: torch.Tensor, E: int) -> torch.Tensor:
 def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
           value: Optional[torch.Tensor], mat: torch.Tensor, want_arg_bytes: bool = False,
           want_arg: bool = True, row: Optional[torch.Tensor] = None, algo: str = "auto",
-          out: Optional[torch.Tensor] = None, hot_rows: Optional[torch.Tensor] = None):
+          out: Optional[torch.Tensor] = None, hot_rows: Optional[torch.Tensor] = None,
+          no_long_rows: bool = False):
     """(out, arg_out | None) — and, with want_arg_bytes (min/max, K % 4 == 0), a
     third result: arg_out as row-local byte indices for spmm_minmax_bw_csc.
     want_arg=False (min/max) skips the int64 arg_out altogether: the kernel then
@@ -120,7 +121,10 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
     fp32 [M, K] tensor, which may be a column slice of a wider contiguous
     matrix (row stride = the wider matrix's width).  `hot_rows` (edge_ranges
     only): float32 [h, K] compact copy of rows of mat; column ids in [N, N + h)
-    name its rows (SparseStorage._hot_columns builds the redirected col)."""
+    name its rows (SparseStorage._hot_columns builds the redirected col).  `no_long_rows`: the
+    caller knows that no row has more than 128 entries (SparseStorage._longest_row); for K <= 64 the
+    call then brings no long-row workspace, which saves the three near-empty launches of the long-row
+    machinery — 5 us of a 45 us problem such as BASELINE config 2."""
     rowptr = _index(rowptr, "rowptr")
     col = _index(col, "col")
     if row is not None:
@@ -168,6 +172,8 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
     minmax = rid in (_lib.MIN, _lib.MAX)
     lib = _lib.load()
     ws_bytes = lib.psa_spmm_workspace_bytes(rid, K, nnz)  # long-row scratch (0 if no row can be long)
+    if no_long_rows and K <= 64 and algo != "edge_ranges":
+        ws_bytes = 0  # every row on its own lane group: same results, no list / chunk / combine launches
     ws = _workspace(ws_bytes, mat.device) if ws_bytes else None
     # the kernels that write the byte form themselves: K <= 64 (multirow) and, for
     # 64 < K <= 256, the fused-roles kernel — which spmm_dispatch takes only when a row
