@@ -122,7 +122,7 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
     matrix (row stride = the wider matrix's width).  `hot_rows` (edge_ranges
     only): float32 [h, K] compact copy of rows of mat; column ids in [N, N + h)
     name its rows (SparseStorage._hot_columns builds the redirected col).  `no_long_rows`: the
-    caller knows that no row has more than 128 entries (SparseStorage._longest_row); for K <= 64 the
+    caller knows that no row has more than 128 entries (SparseStorage._longest_row); for K <= 128 the
     call then brings no long-row workspace, which saves the three near-empty launches of the long-row
     machinery — 5 us of a 45 us problem such as BASELINE config 2."""
     rowptr = _index(rowptr, "rowptr")
@@ -172,8 +172,12 @@ def _spmm(reduce: str, rowptr: torch.Tensor, col: torch.Tensor,
     minmax = rid in (_lib.MIN, _lib.MAX)
     lib = _lib.load()
     ws_bytes = lib.psa_spmm_workspace_bytes(rid, K, nnz)  # long-row scratch (0 if no row can be long)
-    if no_long_rows and K <= 64 and algo != "edge_ranges":
-        ws_bytes = 0  # every row on its own lane group: same results, no list / chunk / combine launches
+    if no_long_rows and algo != "edge_ranges" and (K <= 64 or (K <= 128 and not want_arg_bytes and N * K * 4 < (6 << 30))):
+        # every row on its own wave / lane group: same results, no list / chunk / combine launches (K <= 64: the
+        # multirow kernel; 64 < K <= 128: the row kernel, as fast as the fused-roles one on rows this short —
+        # 100k x 100k, F = 128: 83.5 -> 76.0 us, config 3: 1608 -> 1603 us; from K = 192 the fused kernel's
+        # 128-wide tiles win, and only it gathers non-temporally for operands beyond 6 GiB)
+        ws_bytes = 0
     ws = _workspace(ws_bytes, mat.device) if ws_bytes else None
     # the kernels that write the byte form themselves: K <= 64 (multirow) and, for
     # 64 < K <= 256, the fused-roles kernel — which spmm_dispatch takes only when a row
