@@ -610,3 +610,30 @@ def test_autograd_steps_agree_before_and_after_the_planned_routes_exist(reduce, 
         scale_m = SparseTensor(row=dev(row), col=dev(col), value=dev(np.abs(val)), sparse_sizes=(M, N),
                                is_sorted=True).t().matmul(Gf.abs()) + 1e-30
         assert bool(((gm0.float() - gm2.float()).abs() <= 1e-5 * scale_m + 2 * eps * gm2.float().abs()).all())
+
+
+@pytest.mark.parametrize("reduce", ["sum", "mean", "max"])
+@pytest.mark.parametrize("K", [16, 64, 96, 128, 192])
+@pytest.mark.parametrize("long_deg", [20, 300])
+def test_tensor_surface_skips_the_long_row_launches_only_when_no_row_is_long(reduce, K, long_deg):
+    """SparseTensor.matmul hands `no_long_rows` to the op when its storage knows that no row has more than 128
+    entries: for K <= 128 the call then brings no long-row workspace (no list / chunk / combine launches).  Same
+    bits as the raw op, which always brings it; with a long row present the hint is off and nothing changes."""
+    from paddle_sparse_amd import SparseTensor, ops
+
+    row, rowptr, col, val = skewed_csr(3000, 2000, seed=K + long_deg, long_rows=(5, 1500), long_deg=long_deg)
+    B = torch.randn(2000, K, device="cuda")
+    a = SparseTensor(rowptr=dev(rowptr), col=dev(col), value=dev(val), sparse_sizes=(3000, 2000), is_sorted=True)
+    a.storage._spmm_algo_memo = "row_waves"  # (skewed_csr has many empty rows: keep the family fixed for the comparison)
+    a.storage._longest_row()
+    seen = []
+    real = ops._spmm
+    ops._spmm = lambda *x, **k: seen.append(k.get("no_long_rows", False)) or real(*x, **k)
+    try:
+        with torch.no_grad():
+            got = a.matmul(B, reduce)
+    finally:
+        ops._spmm = real
+    assert seen == [long_deg <= 128]
+    want = real(reduce, dev(rowptr), dev(col), dev(val), B, want_arg=False, algo="row_waves")[0]
+    assert torch.equal(got, want)
