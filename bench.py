@@ -568,7 +568,7 @@ def main() -> None:
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
-            "scaling": scaling if use_dist else "weak",
+            "scaling": scaling,  # N = 1 is the base of the series the flags select (strong for config 3: total work fixed as N grows)
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
