@@ -339,6 +339,73 @@ def test_row_partitioned_spmm_world1_on_the_device():
         dist.destroy_process_group()
 
 
+def _worker_device_gloo(rank, world, port, reduce):
+    """Several ranks SHARING cuda:0 over gloo (it moves device tensors): the multi-rank logic with the real HIP
+    kernels underneath — nnz-balanced blocks, the per-block plan, the HIP pack of the halo exchange, in-place
+    feature slices, the backward through the step.  RCCL itself needs one GPU per rank and is not in this test."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from paddle_sparse_amd import SparseTensor, ops
+        from paddle_sparse_amd import distributed as pd
+
+        rng = np.random.default_rng(23)
+        M, N, F = 30_000, 20_011, 64  # N not a multiple of the world: the last block of B is padded
+        deg = np.where(rng.random(M) < 0.5, 0, rng.integers(1, 9, M))
+        deg[::700] = 900  # hub rows: some blocks take the edge-range family, rows above 128 entries
+        rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+        nnz = int(rowptr[-1])
+        hubs = rng.integers(0, N, 300)
+        col = np.where(rng.random(nnz) < 0.4, hubs[rng.integers(0, 300, nnz)], rng.integers(0, N, nnz)).astype(np.int64)
+        val = rng.standard_normal(nnz).astype(np.float32)
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+        t_rowptr, t_col, t_val = d(rowptr), d(col), d(val)
+        B = d(rng.standard_normal((N, F)).astype(np.float32))
+        G = d(rng.standard_normal((M, F)).astype(np.float32))
+        whole = SparseTensor(rowptr=t_rowptr, col=t_col, value=t_val, sparse_sizes=(M, N), is_sorted=True, trust_data=True)
+        Bg = B.clone().requires_grad_(True)
+        ref = whole.matmul(Bg, reduce)
+        S = ops._spmm("sum", t_rowptr, t_col, t_val.abs(), B.abs())[0] + 1e-30
+        if reduce in ("sum", "mean"):
+            ref.backward(G)
+            Sg = SparseTensor(rowptr=t_rowptr, col=t_col, value=t_val.abs(), sparse_sizes=(M, N), is_sorted=True,
+                              trust_data=True).t().matmul(G.abs()) + 1e-30
+        bounds = pd.partition_rows_by_nnz(t_rowptr, world)
+        r0, r1 = bounds[rank], bounds[rank + 1]
+        nb = pd.dense_block_rows(N, world)
+        for exchange in pd.EXCHANGES:
+            op = pd.RowPartitionedSpMM.from_global(t_rowptr, t_col, t_val, N, reduce=reduce, exchange=exchange)
+            assert (op.shard.row_begin, op.shard.row_end) == (r0, r1)
+            b_local = op.local_dense_block(B)
+            for chunks in (1, 4):
+                out = op(b_local, feature_chunks=chunks)
+                if reduce == "max":
+                    assert torch.equal(out, ref.detach()[r0:r1]), (exchange, chunks)
+                else:
+                    # a block may take another kernel family than the whole matrix: 1e-5 of the sum of |terms| (for mean: an over-estimate)
+                    assert bool(((out - ref.detach()[r0:r1]).abs() <= 1e-5 * S[r0:r1]).all()), (exchange, chunks)
+            held = op.buffer_bytes()
+            op(b_local, feature_chunks=4)
+            assert op.buffer_bytes() == held  # steady state: nothing new is allocated for the collectives
+            if reduce in ("sum", "mean"):
+                bl = b_local.clone().requires_grad_(True)
+                op.apply(bl).backward(G[r0:r1])
+                rows = min(nb, N - rank * nb)
+                got, want = bl.grad[:rows], Bg.grad[rank * nb:rank * nb + rows]
+                assert bool(((got - want).abs() <= 1e-5 * Sg[rank * nb:rank * nb + rows]).all()), exchange
+                assert bool((bl.grad[rows:] == 0).all())  # the padding rows of the last block receive nothing
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,reduce", [(2, "sum"), (3, "mean"), (2, "max")])
+def test_row_partitioned_spmm_more_ranks_on_one_device_over_gloo(world, reduce):
+    mp.spawn(_worker_device_gloo, args=(world, _free_port(), reduce), nprocs=world, join=True)
+
+
 def test_partition_helpers():
     from paddle_sparse_amd import distributed as pd
 
