@@ -363,6 +363,11 @@ def main() -> None:
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
+    # Rehearsal hook (functional only): PSA_BENCH_REHEARSE_ON_ONE_GPU=1 lets N ranks SHARE cuda:0 and talk over gloo
+    # (which moves device tensors) — the N > 1 code path of this file on a one-GPU box.  Its times say nothing.
+    rehearse = os.environ.get("PSA_BENCH_REHEARSE_ON_ONE_GPU") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
 
@@ -384,8 +389,14 @@ def main() -> None:
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
+    global M_PER_GPU, NNZ_PER_GPU
+    if rehearse:  # gloo stages device tensors through the host (~1 GB/s): a tenth of the problem keeps the run in minutes
+        M_PER_GPU, NNZ_PER_GPU = M_PER_GPU // 10, NNZ_PER_GPU // 10
     scaling = args.scaling if args.scaling != "auto" else ("strong" if args.config == "c3" else "weak")
     F = 256 if args.config == "c4" else FEAT
     reduce = args.op.split("_", 1)[1]
@@ -460,6 +471,8 @@ def main() -> None:
             for _ in range(3):
                 o(B_local, feature_chunks=c)
             spent.append(wall(lambda: o(B_local, feature_chunks=c), TUNE_STEPS))
+            if rank == 0:
+                print(f"[bench] tuned {e}/chunks{c}: {spent[-1] * 1e3:.3f} ms per step", file=sys.stderr, flush=True)
         spent_t = torch.tensor(spent, dtype=torch.float64, device=device)
         dist.all_reduce(spent_t, op=dist.ReduceOp.MAX)
         spent = [float(x) for x in spent_t]
@@ -550,7 +563,8 @@ def main() -> None:
             traffic_note = (f"read from profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round "
                             f"{rec.get('round', '?')}, {rec.get('source', '?')}); not measured in this run")
         if use_dist and scaling == "strong":
-            what = (f"{args.op} fwd, the ONE uniform random CSR {M_PER_GPU}x{N} with nnz={total_nnz} (BASELINE config 3), "
+            what = (f"{args.op} fwd, the ONE uniform random CSR {M_PER_GPU}x{N} with nnz={total_nnz} "
+                    f"({'a tenth of BASELINE config 3: rehearsal' if rehearse else 'BASELINE config 3'}), "
                     f"dense F={F} fp32, rows split by nnz over {world} GPU(s)")
         else:
             cfg_name = "BASELINE config 3 per GPU" if args.config == "c3" else "BASELINE config 4's per-GPU share (F = 256)"
@@ -591,6 +605,9 @@ def main() -> None:
                 "kernel_gedges_per_s": round(nnz / (kern_ms * 1e-3) / 1e9, 4),
             },
         }
+        if rehearse:
+            line["rehearsal"] = (f"{world} ranks sharing ONE GPU over gloo (PSA_BENCH_REHEARSE_ON_ONE_GPU=1): a functional run of "
+                                 "the N > 1 path; none of its times is a measurement")
         if use_dist:
             rate = lambda s_: round(total_nnz / s_ / 1e9, 4)  # noqa: E731
             serial = {e: rate(form_s[(e, 1)]) for e in ops_by_exchange if (e, 1) in form_s}
