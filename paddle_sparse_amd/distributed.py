@@ -189,6 +189,11 @@ def peer_copy_dense(buf: torch.Tensor, part: torch.Tensor, group=None, async_op:
 def _hip_spmm_planned(reduce: str, st, value, mat, out=None):
     from .matmul import spmm_planned  # the HIP core; loads (or fails loudly) on first use
 
+    if out is not None and mat.dtype in (torch.float16, torch.bfloat16):
+        # a half-width B travels as it is (half the bytes on the fabric) and runs the half-width kernels, which
+        # allocate their result: one copy into the caller's buffer / column slice
+        out.copy_(spmm_planned(st, value, mat, reduce))
+        return out
     return spmm_planned(st, value, mat, reduce, out=out)
 
 

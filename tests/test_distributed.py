@@ -389,6 +389,13 @@ def _worker_device_gloo(rank, world, port, reduce):
             held = op.buffer_bytes()
             op(b_local, feature_chunks=4)
             assert op.buffer_bytes() == held  # steady state: nothing new is allocated for the collectives
+            # a bf16 B is exchanged as bf16 (half the bytes) and multiplied by the half-width kernels
+            bh = b_local.to(torch.bfloat16)
+            want_h = whole.matmul(B.to(torch.bfloat16), reduce)[r0:r1].float()
+            for chunks in (1, 2):
+                got_h = op(bh, feature_chunks=chunks)
+                assert got_h.dtype == torch.bfloat16
+                assert bool(((got_h.float() - want_h).abs() <= 1e-5 * S[r0:r1] + 2.0 ** -7 * want_h.abs()).all()), (exchange, chunks)
             if reduce in ("sum", "mean"):
                 bl = b_local.clone().requires_grad_(True)
                 op.apply(bl).backward(G[r0:r1])
