@@ -349,6 +349,9 @@ def main() -> None:
                     help="N > 1: exchange B in this many column slices and run the SpMM of a slice under the "
                          "exchange of the next ones (1: one exchange, then the SpMM; default 0: time 1 and 4 "
                          "before the warmup and keep the faster)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="dense operand and output: f32 (the metric's dtype, default) or bf16 (fp32 sums; half the bytes of B "
+                         "per gathered row and, at N > 1, on the fabric) — an optional run, never the headline")
     ap.add_argument("--no-plan", action="store_true", help="N > 1: rank-local kernel on the raw arrays (algo auto) "
                                                            "instead of the block's per-matrix plan")
     args = ap.parse_args()
@@ -450,6 +453,9 @@ def main() -> None:
             from paddle_sparse_amd.distributed import RowPartitionedSpMM, RowShard
 
             shard = RowShard(rowptr, col, val, rank * M, (rank + 1) * M, N)
+    half = args.dtype == "bf16"
+    if half:
+        B_local = B_local.to(torch.bfloat16)
     torch.cuda.empty_cache()
 
     forms = {}  # (exchange, chunks) -> RowPartitionedSpMM
@@ -554,10 +560,12 @@ def main() -> None:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_nnz / (elapsed / args.steps) / 1e9
         alg = algorithmic_bytes(nnz, M, F, True, args.op in ("spmm_max", "spmm_min"))
+        if half:  # 2-byte dense rows: 2 F of every (12 + 2 F) bytes per edge, 8 + 2 F per row
+            alg = nnz * (8 + 4 + 2 * F) + M * (8 + 2 * F) + (M * F * 8 if args.op in ("spmm_max", "spmm_min") else 0)
         achieved = alg / (kern_ms * 1e-3) / 1e9
         traffic, traffic_note = None, "not collected for this configuration"
         tfile = ROOT / "profiles" / "traffic.json"
-        if tfile.exists() and world == 1 and args.config == "c3":
+        if tfile.exists() and world == 1 and args.config == "c3" and not half:
             rec = json.loads(tfile.read_text()).get(f"{args.op}_c3", {})
             traffic = rec.get("hbm_bytes_per_launch")
             traffic_note = (f"read from profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of round "
@@ -565,11 +573,11 @@ def main() -> None:
         if use_dist and scaling == "strong":
             what = (f"{args.op} fwd, the ONE uniform random CSR {M_PER_GPU}x{N} with nnz={total_nnz} "
                     f"({'a tenth of BASELINE config 3: rehearsal' if rehearse else 'BASELINE config 3'}), "
-                    f"dense F={F} fp32, rows split by nnz over {world} GPU(s)")
+                    f"dense F={F} {args.dtype}, rows split by nnz over {world} GPU(s)")
         else:
             cfg_name = "BASELINE config 3 per GPU" if args.config == "c3" else "BASELINE config 4's per-GPU share (F = 256)"
             what = (f"{args.op} fwd, uniform random CSR {M}x{N} per GPU, nnz={nnz} per GPU, "
-                    f"dense F={F} fp32 ({cfg_name})")
+                    f"dense F={F} {args.dtype} ({cfg_name})")
         if use_dist:
             what += (f"; + exchange of B ({N}x{F}, row-sharded) every step: {chosen[0]}"
                      + (f", in {chosen[1]} column slices overlapped with the SpMM" if chosen[1] > 1 else ""))
@@ -584,7 +592,7 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": scaling,  # N = 1 is the base of the series the flags select (strong for config 3: total work fixed as N grows)
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {
                 "workload": what,
@@ -593,7 +601,7 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "spmm_fused_kernel",
+                "kernel": "spmm_half_row_kernel" if half else "spmm_fused_kernel",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -638,13 +646,14 @@ def main() -> None:
                 "note": "value counts the exchange of B inside every step, in the form named by form_timed_as_value; "
                         "spmm_only_* is the local-kernel rate with B already assembled (slowest rank)",
             }
-        if not args.no_cpu and args.op == "spmm_sum" and world == 1 and isinstance(B_full, torch.Tensor) and not (use_dist and chosen[0] == "halo"):  # CPU leg: N = 1 only
+        if (not args.no_cpu and args.op == "spmm_sum" and world == 1 and isinstance(B_full, torch.Tensor) and not half
+                and not (use_dist and chosen[0] == "halo")):  # CPU leg: N = 1 only
             info, ref, rows = cpu_baseline(rowptr, col, val, B_full)
             got = out[:rows].cpu().numpy()
             scale = np.abs(ref).max()
             line["cpu_baseline"] = info
             line["check_max_abs_err_vs_oracle"] = float(np.abs(got - ref).max() / scale)
-        if not args.no_extra and world == 1 and not use_dist and args.config == "c3":
+        if not args.no_extra and world == 1 and not use_dist and args.config == "c3" and not half:
             # after the timed region: the rest of BASELINE config 3 (mean / max forward, sum / max
             # forward + backward) and the forward on a power-law graph; headline fields unchanged
             line["c3_other_ops"] = breadth(rowptr, col, val, B_full, max(5, args.steps // 5))
