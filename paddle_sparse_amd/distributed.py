@@ -29,11 +29,13 @@ back to the caching allocator before that stream's event completes, and a host
 that runs ahead of the GPU then falls through to hipMalloc every step (round
 2's committed rehearsal: 2.08 ms per step over 3 steps, 6.92 ms over 25).
 
-Backward (`RowPartitionedSpMM.apply`, sum / mean): grad of the local block of B
-= this rank's rows of sum_r A_r^T grad_out_r — every rank runs the SpMM over its
-block's CSC view (fixed adjacency: the planned forward of the transpose) and
-ONE `reduce_scatter_tensor` (full) or the halo's all_to_all run backwards
-followed by a segmented add (halo) brings the partial sums to their owners.
+Backward (`RowPartitionedSpMM.apply`): a differentiable exchange composed with the
+ordinary differentiable local product.  grad of the local block of B = this rank's
+rows of sum_r A_r^T grad_out_r: every rank runs its block's backward (the one-pass
+kernels over the block's CSC view: every reduction, trained values, half width) and
+ONE `reduce_scatter_tensor` (full) or the halo's all_to_all run backwards followed
+by an add by `send_idx` (halo) brings the partial sums to their owners; the gradient
+of a block's edge values stays on its rank.
 
 xGMI arithmetic that decides what this can reach (8-GPU full mesh, 7 links x
 ~153 GB/s per GPU): every rank must receive (world-1)/world of B every step;
@@ -439,16 +441,65 @@ class RowPartitionedSpMM:
                 for c in range(feature_chunks)]
 
     # ---- autograd ------------------------------------------------------------------------
-    def apply(self, b_local: torch.Tensor) -> torch.Tensor:
-        """The step as a differentiable function of this rank's block of B (sum / mean, fixed
-        adjacency).  Forward = __call__; backward: every rank forms its block's contribution
-        A_r^T grad_out_r over the CSC view of its block (the planned forward of the transpose),
-        then the contributions go to the owners of the rows — ONE reduce_scatter_tensor of the
-        [world * nb, F] partial sums (full exchanges), or the halo exchange run backwards (rows go
-        back to the ranks they came from, which add them into their block by `send_idx`)."""
-        if self.reduce not in ("sum", "mean"):
-            raise NotImplementedError("RowPartitionedSpMM.apply differentiates sum / mean")
-        return _PartitionedSpMM.apply(b_local, self)
+    def apply(self, b_local: torch.Tensor, value: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The step as a differentiable function of this rank's block of B — and, on the device, of the block's
+        edge values.  Two autograd functions composed: a differentiable EXCHANGE (forward: the operand the rank's
+        columns need; backward: the contributions to the rows of B go back to their owners — ONE
+        reduce_scatter_tensor of the [world * nb, F] partial sums for the full exchanges, the halo's all-to-all
+        run backwards plus an add by `send_idx` for the halo), then the ordinary differentiable local product
+        (`SparseTensor.matmul` of the block: every reduction incl. min / max, trained values — their gradient
+        stays on the rank that owns the rows —, half-width operands, the one-pass backward over the block's CSC
+        view).  `value`: the block's edge values as a tensor that may require grad (default: the shard's own).
+        With the CPU test hook (`local_spmm`) only sum / mean with fixed values differentiate."""
+        if self._custom_spmm is not None or not b_local.is_cuda:
+            if self.reduce not in ("sum", "mean"):
+                raise NotImplementedError("RowPartitionedSpMM.apply with a local_spmm hook differentiates sum / mean")
+            return _PartitionedSpMM.apply(b_local, self)
+        from .matmul import spmm_sparse
+        from .tensor import SparseTensor
+
+        operand = _ExchangeB.apply(b_local, self)
+        value = self.shard.value if value is None else value
+        st = self.local_storage()  # ONE storage per block: the CSC view, tags and routes built by a backward stay for the next
+        st.set_value_(value, layout="coo")
+        return spmm_sparse(SparseTensor.from_storage(st), operand, self.reduce)
+
+    def _exchange_fresh(self, b_local: torch.Tensor) -> torch.Tensor:
+        """The exchange into buffers of its own (autograd keeps the operand until the backward: a second forward
+        through the same object must not overwrite it)."""
+        s, F = self.shard, b_local.shape[1]
+        b_local = b_local.contiguous()
+        if self.halo is None:
+            buf = torch.empty((self.world * self.block_rows, F), dtype=b_local.dtype, device=b_local.device)
+            if self.exchange == "full_p2p":
+                peer_copy_dense(buf, b_local, self.group)
+            else:
+                dist.all_gather_into_tensor(buf, b_local, group=self.group)
+            return buf[:s.num_cols]
+        h = self.halo
+        send = self._pack(b_local, h.send_idx, 0, F, None)
+        recv = torch.empty((h.num_needed, F), dtype=b_local.dtype, device=b_local.device)
+        dist.all_to_all_single(recv, send, output_split_sizes=h.need_counts, input_split_sizes=h.send_counts, group=self.group)
+        return recv
+
+    def _return_grad(self, part: torch.Tensor) -> torch.Tensor:
+        """grad of the assembled operand ([N, F], or [num_needed, F] for the halo) -> grad of this rank's block of B."""
+        F, nb = part.shape[1], self.block_rows
+        if self.halo is None:
+            if part.shape[0] != self.world * nb:  # pad to whole blocks
+                padded = torch.zeros((self.world * nb, F), dtype=part.dtype, device=part.device)
+                padded[:part.shape[0]] = part
+                part = padded
+            grad_local = torch.empty((nb, F), dtype=part.dtype, device=part.device)
+            dist.reduce_scatter_tensor(grad_local, part.contiguous(), group=self.group)
+            return grad_local
+        h = self.halo
+        back = torch.empty((h.send_idx.numel(), F), dtype=part.dtype, device=part.device)
+        dist.all_to_all_single(back, part.contiguous(), output_split_sizes=h.send_counts, input_split_sizes=h.need_counts,
+                               group=self.group)
+        grad_local = torch.zeros((nb, F), dtype=part.dtype, device=part.device)
+        grad_local.index_add_(0, h.send_idx, back)  # a row may be asked for by several ranks
+        return grad_local
 
     def _grad_operand(self, grad_out: torch.Tensor) -> torch.Tensor:
         """A_r^T grad_out_r as an [operand height, F] matrix (rank-local)."""
@@ -473,23 +524,21 @@ class RowPartitionedSpMM:
         return spmm_transposed_planned(self.local_storage(), s.value, grad_out.contiguous(), self.reduce == "mean")
 
     def _backward(self, grad_out: torch.Tensor) -> torch.Tensor:
-        F, nb = grad_out.shape[1], self.block_rows
-        part = self._grad_operand(grad_out)  # [N, F] (full) or [num_needed, F] (halo)
-        if self.halo is None:
-            if part.shape[0] != self.world * nb:  # pad to whole blocks
-                padded = torch.zeros((self.world * nb, F), dtype=part.dtype, device=part.device)
-                padded[:part.shape[0]] = part
-                part = padded
-            grad_local = torch.empty((nb, F), dtype=part.dtype, device=part.device)
-            dist.reduce_scatter_tensor(grad_local, part.contiguous(), group=self.group)
-            return grad_local
-        h = self.halo
-        back = torch.empty((h.send_idx.numel(), F), dtype=part.dtype, device=part.device)
-        dist.all_to_all_single(back, part.contiguous(), output_split_sizes=h.send_counts, input_split_sizes=h.need_counts,
-                               group=self.group)
-        grad_local = torch.zeros((nb, F), dtype=part.dtype, device=part.device)
-        grad_local.index_add_(0, h.send_idx, back)  # a row may be asked for by several ranks
-        return grad_local
+        return self._return_grad(self._grad_operand(grad_out))  # [N, F] (full) or [num_needed, F] (halo) -> the block's rows
+
+
+class _ExchangeB(torch.autograd.Function):
+    """The exchange of B as a differentiable function: forward = the assembled operand, backward = its gradient's
+    rows brought to (and summed at) the ranks that own them."""
+
+    @staticmethod
+    def forward(ctx, b_local, op: RowPartitionedSpMM):
+        ctx.op = op
+        return op._exchange_fresh(b_local)
+
+    @staticmethod
+    def backward(ctx, grad_operand):
+        return ctx.op._return_grad(grad_operand.contiguous()), None
 
 
 class _PartitionedSpMM(torch.autograd.Function):

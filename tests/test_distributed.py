@@ -366,12 +366,15 @@ def _worker_device_gloo(rank, world, port, reduce):
         G = d(rng.standard_normal((M, F)).astype(np.float32))
         whole = SparseTensor(rowptr=t_rowptr, col=t_col, value=t_val, sparse_sizes=(M, N), is_sorted=True, trust_data=True)
         Bg = B.clone().requires_grad_(True)
+        vg = t_val.clone().requires_grad_(True)
+        whole = SparseTensor(rowptr=t_rowptr, col=t_col, value=vg, sparse_sizes=(M, N), is_sorted=True, trust_data=True)
         ref = whole.matmul(Bg, reduce)
         S = ops._spmm("sum", t_rowptr, t_col, t_val.abs(), B.abs())[0] + 1e-30
-        if reduce in ("sum", "mean"):
-            ref.backward(G)
-            Sg = SparseTensor(rowptr=t_rowptr, col=t_col, value=t_val.abs(), sparse_sizes=(M, N), is_sorted=True,
-                              trust_data=True).t().matmul(G.abs()) + 1e-30
+        ref.backward(G)
+        whole = SparseTensor(rowptr=t_rowptr, col=t_col, value=t_val, sparse_sizes=(M, N), is_sorted=True, trust_data=True)
+        Sg = SparseTensor(rowptr=t_rowptr, col=t_col, value=t_val.abs(), sparse_sizes=(M, N), is_sorted=True,
+                          trust_data=True).t().matmul(G.abs()) + 1e-30  # sum |terms| of either gradient's sums
+        Sv = ops.spmm_value_bw(None, t_rowptr, t_col, B.abs(), G.abs(), "sum") + 1e-30
         bounds = pd.partition_rows_by_nnz(t_rowptr, world)
         r0, r1 = bounds[rank], bounds[rank + 1]
         nb = pd.dense_block_rows(N, world)
@@ -396,13 +399,17 @@ def _worker_device_gloo(rank, world, port, reduce):
                 got_h = op(bh, feature_chunks=chunks)
                 assert got_h.dtype == torch.bfloat16
                 assert bool(((got_h.float() - want_h).abs() <= 1e-5 * S[r0:r1] + 2.0 ** -7 * want_h.abs()).all()), (exchange, chunks)
-            if reduce in ("sum", "mean"):
-                bl = b_local.clone().requires_grad_(True)
-                op.apply(bl).backward(G[r0:r1])
-                rows = min(nb, N - rank * nb)
-                got, want = bl.grad[:rows], Bg.grad[rank * nb:rank * nb + rows]
-                assert bool(((got - want).abs() <= 1e-5 * Sg[rank * nb:rank * nb + rows]).all()), exchange
-                assert bool((bl.grad[rows:] == 0).all())  # the padding rows of the last block receive nothing
+            # backward through the step: a differentiable exchange + the block's own autograd — every reduction,
+            # and trained edge values (their gradient stays on the rank that owns the rows)
+            bl = b_local.clone().requires_grad_(True)
+            vl = op.shard.value.clone().requires_grad_(True)
+            op.apply(bl, value=vl).backward(G[r0:r1])
+            rows = min(nb, N - rank * nb)
+            got, want = bl.grad[:rows], Bg.grad[rank * nb:rank * nb + rows]
+            assert bool(((got - want).abs() <= 1e-5 * Sg[rank * nb:rank * nb + rows]).all()), exchange
+            assert bool((bl.grad[rows:] == 0).all())  # the padding rows of the last block receive nothing
+            e0, e1 = int(rowptr[r0]), int(rowptr[r1])
+            assert bool(((vl.grad - vg.grad[e0:e1]).abs() <= 1e-5 * Sv[e0:e1]).all()), exchange
     finally:
         dist.destroy_process_group()
 
