@@ -79,7 +79,11 @@ __device__ __forceinline__ int64_t shfl_i64(int64_t x, int src) {
 }
 
 // value: fp32[nnz] (VAL32) or the same 2-byte type as mat, or NULL (weights 1)
-template <typename T, int LPR, int RED, int U, bool TRACK, bool VAL32>
+// SMALL: the dense operand is below 4 GiB, so a row's byte offset fits 32 bits (and the column ids 31): the gather
+// address is one 32-bit multiply-add on a uniform base instead of a 64-bit multiply built from three 32-bit ones, and
+// only the low word of the column id crosses lanes — 4 VALU + 1 LDS instruction less per gathered row in a kernel
+// that spends 80 % of its cycles issuing VALU instructions (profiles/r03_pmc_half.json).
+template <typename T, int LPR, int RED, int U, bool TRACK, bool VAL32, bool SMALL = false>
 __global__ void __launch_bounds__(kThreads)
 spmm_half_row_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restrict__ col,
                      const void* __restrict__ val, const uint16_t* __restrict__ mat,
@@ -125,11 +129,17 @@ spmm_half_row_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restri
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int idx = j + u * G + g;  // < 64
-        const int64_t c = shfl_i64(c_l, idx);
         w[u] = __shfl(v_l, idx);
         ok[u] = (idx < n) && kact;
         raw[u] = make_uint4(0u, 0u, 0u, 0u);
-        if (ok[u]) raw[u] = *reinterpret_cast<const uint4*>(matk + c * K);
+        if constexpr (SMALL) {
+          const uint32_t c = static_cast<uint32_t>(__shfl(static_cast<int>(c_l), idx));
+          const uint32_t off = c * (static_cast<uint32_t>(K) * 2u) + static_cast<uint32_t>(k0) * 2u;
+          if (ok[u]) raw[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(mat) + off);
+        } else {
+          const int64_t c = shfl_i64(c_l, idx);
+          if (ok[u]) raw[u] = *reinterpret_cast<const uint4*>(matk + c * K);
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -324,7 +334,7 @@ spmm_half_multirow_kernel(const int64_t* __restrict__ rowptr, const int64_t* __r
 // `tags` [nnz] (CSC order); an entry's term counts for column k only where words[r, k] == its tag — the
 // masked form of the fp32 pass (spmm.hip, M_MASK) in its exact forms (1 byte: no row above 128 entries;
 // 2 bytes: none above 65 535).  MW = 0: sum / mean, every term counts.
-template <typename T, int LPR, int U, bool GV, int MW = 0>
+template <typename T, int LPR, int U, bool GV, int MW = 0, bool SMALL = false>
 __global__ void __launch_bounds__(kThreads, (MW != 0 && GV) ? 5 : 6)  // sum: 78 VGPRs without spilling at 6 waves per SIMD (81 / 5 unconstrained); masked + grad_value: 5
 spmm_half_csc_bw_kernel(const int64_t* __restrict__ colptr, const int64_t* __restrict__ row_csc,
                         const float* __restrict__ w_csc, const float* __restrict__ row_scale,
@@ -382,13 +392,22 @@ spmm_half_csc_bw_kernel(const int64_t* __restrict__ colptr, const int64_t* __res
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int idx = j + u * G + g;  // < 64
-        const int64_t r = shfl_i64(r_l, idx);
         ok[u] = (idx < n) && kact;
         raw[u] = make_uint4(0u, 0u, 0u, 0u);
-        if (ok[u]) raw[u] = *reinterpret_cast<const uint4*>(gk + r * K);
-        if constexpr (MW != 0) {
-          wd[u] = {};
-          if (ok[u]) wd[u] = *reinterpret_cast<const Words*>(words + (r * K + k0) * MW);
+        if constexpr (MW != 0) wd[u] = {};
+        if constexpr (SMALL) {  // (see spmm_half_row_kernel)
+          const uint32_t r = static_cast<uint32_t>(__shfl(static_cast<int>(r_l), idx));
+          const uint32_t e = r * static_cast<uint32_t>(K) + static_cast<uint32_t>(k0);
+          if (ok[u]) raw[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(grad) + e * 2u);
+          if constexpr (MW != 0) {
+            if (ok[u]) wd[u] = *reinterpret_cast<const Words*>(words + e * static_cast<uint32_t>(MW));
+          }
+        } else {
+          const int64_t r = shfl_i64(r_l, idx);
+          if (ok[u]) raw[u] = *reinterpret_cast<const uint4*>(gk + r * K);
+          if constexpr (MW != 0) {
+            if (ok[u]) wd[u] = *reinterpret_cast<const Words*>(words + (r * K + k0) * MW);
+          }
         }
       }
       float dot[U];
@@ -506,14 +525,19 @@ int launch_half_multirow(int red, bool track, bool val32, const int64_t* rowptr,
 template <typename T, int LPR, int U>
 int launch_half(int red, bool track, bool val32, const int64_t* rowptr, const int64_t* col, const void* val,
                 const uint16_t* mat, uint16_t* out, int64_t* arg_out, int64_t M, int64_t K, int64_t nnz, int mean,
-                hipStream_t s, uint8_t* arg_bytes = nullptr, int arg_width = 1) {
+                hipStream_t s, uint8_t* arg_bytes = nullptr, int arg_width = 1, bool small = false) {
   const int64_t gx = psa::ceil_div(psa::ceil_div(M, kWaves), 8) * 8;  // whole groups of 8 row blocks (XCD mixing)
   const int64_t gy = psa::ceil_div(K, static_cast<int64_t>(LPR) * 8);
   PSA_REQUIRE(gx <= 0x7fffffff && gy <= 65535, "problem too large for one launch");
   const dim3 grid(static_cast<unsigned>(gx), static_cast<unsigned>(gy)), block(kThreads);
-#define PSA_H(R, TR, V32)                                                                              \
-  hipLaunchKernelGGL((spmm_half_row_kernel<T, LPR, R, U, TR, V32>), grid, block, 0, s, rowptr, col, val, mat, out, \
+#define PSA_H1(R, TR, V32, SM)                                                                                        \
+  hipLaunchKernelGGL((spmm_half_row_kernel<T, LPR, R, U, TR, V32, SM>), grid, block, 0, s, rowptr, col, val, mat, out, \
                      arg_out, M, K, nnz, mean, g_half_variant == 3 ? 0 : 1, arg_bytes, arg_width)
+#define PSA_H(R, TR, V32)              \
+  do {                                 \
+    if (small) PSA_H1(R, TR, V32, true); \
+    else PSA_H1(R, TR, V32, false);    \
+  } while (0)
 #define PSA_HV(R, TR)        \
   do {                       \
     if (val32) PSA_H(R, TR, true); \
@@ -529,6 +553,7 @@ int launch_half(int red, bool track, bool val32, const int64_t* rowptr, const in
   }
 #undef PSA_HV
 #undef PSA_H
+#undef PSA_H1
   PSA_LAUNCH_CHECK();
   return PSA_OK;
 }
@@ -536,7 +561,7 @@ int launch_half(int red, bool track, bool val32, const int64_t* rowptr, const in
 template <typename T>
 int dispatch_half(int red, bool track, bool val32, const int64_t* rowptr, const int64_t* col, const void* val,
                   const uint16_t* mat, uint16_t* out, int64_t* arg_out, int64_t M, int64_t K, int64_t nnz, int mean,
-                  hipStream_t s, uint8_t* arg_bytes = nullptr, int arg_width = 1) {
+                  hipStream_t s, uint8_t* arg_bytes = nullptr, int arg_width = 1, bool small = false) {
   const int64_t q = K / 8;  // 16-byte pieces per dense row
 #define PSA_MULTI(LPR, U) return launch_half_multirow<T, LPR, U>(red, track, val32, rowptr, col, val, mat, out, arg_out, M, K, nnz, mean, s)
   if (g_half_variant == 1 && arg_bytes == nullptr) {
@@ -547,7 +572,7 @@ int dispatch_half(int red, bool track, bool val32, const int64_t* rowptr, const 
     if (q <= 16) PSA_MULTI(16, 8);
   }
 #undef PSA_MULTI
-#define PSA_GO(LPR, U) return launch_half<T, LPR, U>(red, track, val32, rowptr, col, val, mat, out, arg_out, M, K, nnz, mean, s, arg_bytes, arg_width)
+#define PSA_GO(LPR, U) return launch_half<T, LPR, U>(red, track, val32, rowptr, col, val, mat, out, arg_out, M, K, nnz, mean, s, arg_bytes, arg_width, small)
   if (q <= 1) PSA_GO(1, 1);
   if (q <= 2) PSA_GO(2, 2);
   if (q <= 4) PSA_GO(4, 4);
@@ -563,19 +588,26 @@ int dispatch_half(int red, bool track, bool val32, const int64_t* rowptr, const 
 template <typename T, int MW = 0>
 int dispatch_half_csc_bw(const int64_t* colptr, const int64_t* row_csc, const float* w_csc, const float* row_scale,
                          const uint16_t* mat, const uint16_t* grad, uint16_t* grad_mat, float* grad_value, int64_t N,
-                         int64_t K, hipStream_t s, const uint8_t* words = nullptr, const uint8_t* tags = nullptr) {
+                         int64_t K, hipStream_t s, const uint8_t* words = nullptr, const uint8_t* tags = nullptr,
+                         bool small = false) {
   const int64_t gx = psa::ceil_div(psa::ceil_div(N, kWaves), 8) * 8;
   PSA_REQUIRE(gx <= 0x7fffffff, "problem too large for one launch");
   const dim3 grid(static_cast<unsigned>(gx)), block(kThreads);
   const int64_t q = K / 8;
 #define PSA_GO(LPR, U)                                                                                              \
   do {                                                                                                              \
-    if (grad_value != nullptr)                                                                                      \
-      hipLaunchKernelGGL((spmm_half_csc_bw_kernel<T, LPR, U, true, MW>), grid, block, 0, s, colptr, row_csc, w_csc, \
-                         row_scale, mat, grad, grad_mat, grad_value, N, K, 1, words, tags);                         \
+    if (grad_value != nullptr && small)                                                                             \
+      hipLaunchKernelGGL((spmm_half_csc_bw_kernel<T, LPR, U, true, MW, true>), grid, block, 0, s, colptr, row_csc,  \
+                         w_csc, row_scale, mat, grad, grad_mat, grad_value, N, K, 1, words, tags);                  \
+    else if (grad_value != nullptr)                                                                                 \
+      hipLaunchKernelGGL((spmm_half_csc_bw_kernel<T, LPR, U, true, MW, false>), grid, block, 0, s, colptr, row_csc, \
+                         w_csc, row_scale, mat, grad, grad_mat, grad_value, N, K, 1, words, tags);                  \
+    else if (small)                                                                                                 \
+      hipLaunchKernelGGL((spmm_half_csc_bw_kernel<T, LPR, U, false, MW, true>), grid, block, 0, s, colptr, row_csc, \
+                         w_csc, row_scale, mat, grad, grad_mat, grad_value, N, K, 1, words, tags);                  \
     else                                                                                                            \
-      hipLaunchKernelGGL((spmm_half_csc_bw_kernel<T, LPR, U, false, MW>), grid, block, 0, s, colptr, row_csc, w_csc, \
-                         row_scale, mat, grad, grad_mat, grad_value, N, K, 1, words, tags);                         \
+      hipLaunchKernelGGL((spmm_half_csc_bw_kernel<T, LPR, U, false, MW, false>), grid, block, 0, s, colptr, row_csc, \
+                         w_csc, row_scale, mat, grad, grad_mat, grad_value, N, K, 1, words, tags);                  \
     PSA_LAUNCH_CHECK();                                                                                             \
     return PSA_OK;                                                                                                  \
   } while (0)
@@ -613,8 +645,10 @@ extern "C" int psa_spmm_half_sum_bw_csc(int dtype, const int64_t* colptr, const 
   const uint16_t* g = static_cast<const uint16_t*>(grad);
   uint16_t* gm = static_cast<uint16_t*>(grad_mat);
   if (dtype == PSA_BF16)
-    return dispatch_half_csc_bw<BF16>(colptr, row_csc, weight_csc, row_scale, m, g, gm, grad_value_csc, N, K, s);
-  return dispatch_half_csc_bw<F16>(colptr, row_csc, weight_csc, row_scale, m, g, gm, grad_value_csc, N, K, s);
+    return dispatch_half_csc_bw<BF16>(colptr, row_csc, weight_csc, row_scale, m, g, gm, grad_value_csc, N, K, s, nullptr, nullptr,
+                                      M * K * 2 < (1ll << 32));
+  return dispatch_half_csc_bw<F16>(colptr, row_csc, weight_csc, row_scale, m, g, gm, grad_value_csc, N, K, s, nullptr, nullptr,
+                                   M * K * 2 < (1ll << 32));
 }
 
 extern "C" int psa_spmm_half_set_variant(int v) {
@@ -626,7 +660,7 @@ extern "C" int psa_spmm_half_set_variant(int v) {
 extern "C" int psa_spmm_half_arg(int reduce, int dtype, const int64_t* rowptr, const int64_t* col, const void* value,
                                  int value_dtype, const void* mat, int64_t M, int64_t N, int64_t K, int64_t nnz,
                                  void* out, int64_t* arg_out, void* arg_bytes, int arg_width, psa_stream_t stream) {
-  (void)N;
+  const bool small = N > 0 && N * K * 2 < (1ll << 32);  // a row's byte offset fits 32 bits (N is the caller's bound on col)
   PSA_REQUIRE(reduce >= PSA_SUM && reduce <= PSA_MAX, "bad reduce");
   PSA_REQUIRE(M >= 0 && K >= 0 && nnz >= 0, "negative size");
   if (dtype != PSA_F16 && dtype != PSA_BF16) {
@@ -653,9 +687,9 @@ extern "C" int psa_spmm_half_arg(int reduce, int dtype, const int64_t* rowptr, c
   uint16_t* o = static_cast<uint16_t*>(out);
   if (dtype == PSA_BF16)
     return dispatch_half<BF16>(red, track, val32, rowptr, col, value, m, o, arg_out, M, K, nnz, reduce == PSA_MEAN, s, ab,
-                               arg_width);
+                               arg_width, small);
   return dispatch_half<F16>(red, track, val32, rowptr, col, value, m, o, arg_out, M, K, nnz, reduce == PSA_MEAN, s, ab,
-                            arg_width);
+                            arg_width, small);
 }
 
 extern "C" int psa_spmm_half(int reduce, int dtype, const int64_t* rowptr, const int64_t* col, const void* value,
@@ -690,7 +724,7 @@ extern "C" int psa_spmm_half_minmax_bw_csc(int dtype, const int64_t* colptr, con
   uint16_t* gm = static_cast<uint16_t*>(grad_mat);
   const uint8_t* words = static_cast<const uint8_t*>(arg_bytes);
   const uint8_t* tags = static_cast<const uint8_t*>(tag);
-#define PSA_MM(T, MW) return dispatch_half_csc_bw<T, MW>(colptr, row_csc, weight_csc, nullptr, m, g, gm, grad_value_csc, N, K, s, words, tags)
+#define PSA_MM(T, MW) return dispatch_half_csc_bw<T, MW>(colptr, row_csc, weight_csc, nullptr, m, g, gm, grad_value_csc, N, K, s, words, tags, M * K * 2 < (1ll << 32))
   if (dtype == PSA_BF16) {
     if (arg_width == 2) PSA_MM(BF16, 2);
     PSA_MM(BF16, 1);
