@@ -266,7 +266,10 @@ for reduce in ("sum", "mean", "min", "max"):
     else:
         report("a13", f"spmm_{reduce} forward (+ arg_out)", ms, fw_bytes + M * F * 8)
 ms = gpu_ms(lambda: ops.spmm_value_bw(row_s, rowptr_d, col_s, B_d, g_d, "sum"), reps=20)
-report("a13", "spmm_value_bw (grad of value, sum)", ms, E * (8 + 8 + 8 * F + 4))
+# bytes the pass moves: col + the gathered mat row + grad_value per entry, rowptr + the row's own grad row per row.
+# (SURVEY.md 8(d)'s SDDMM model — 8 + 8 + 8 F + 4 per entry, 20.9 GB — reads the grad row per ENTRY; this kernel holds
+# it in registers per row, so against that model it would read as 122 % of the HBM peak.)
+report("a13", "spmm_value_bw (grad of value, sum; survey model 20.9 GB)", ms, E * (8 + 4 * F + 4) + M * (8 + 4 * F))
 csr2csc, colptr_d = A.storage.csr2csc(), A.storage.colptr()
 row_csc = A.storage._row_in_csc_order()
 ms = gpu_ms(lambda: ops.transpose_weights(val_c, csr2csc, None, None, False), reps=20)
