@@ -31,11 +31,19 @@ import sys
 import time
 from pathlib import Path
 
-import numpy as np
-import torch
-
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+
+# numpy / torch are imported by load_compute_modules() — a launcher process (self_launch below) never needs them
+np = torch = None
+
+
+def load_compute_modules() -> None:
+    global np, torch
+    import numpy
+    import torch as torch_mod
+
+    np, torch = numpy, torch_mod
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec peak
 
@@ -326,7 +334,70 @@ def power_law(device, F: int, reps: int):
     return res
 
 
-def main() -> None:
+def visible_gpus() -> int:
+    """GPUs this process could use, counted WITHOUT initialising the HIP runtime (torch.cuda.device_count() reads the
+    driver's device list on this image; nothing here creates a context — the launcher must stay exec- and fork-safe)."""
+    import torch as t
+
+    return t.cuda.device_count()
+
+
+def self_launch(args, argv) -> int:
+    """`python bench.py --gpus N` typed as it stands (no launcher, WORLD_SIZE unset): start ONE fresh child
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <the same flags>` — one rank per GPU —
+    pass rank 0's single JSON line through to stdout and everything else to stderr, and return the child's exit code.
+    The parent never touches the GPU, never imports paddle_sparse_amd and never exec()s; a child that fails or runs past
+    PSA_BENCH_LAUNCH_TIMEOUT seconds (default 3000) makes the parent exit non-zero.  No retry."""
+    import signal
+    import socket
+    import subprocess
+
+    rehearse = os.environ.get("PSA_BENCH_REHEARSE_ON_ONE_GPU") == "1"
+    have = visible_gpus()
+    need = 1 if rehearse else args.gpus
+    if have < need:
+        print(f"bench.py: --gpus {args.gpus} needs {need} visible GPU(s), this node shows {have}", file=sys.stderr)
+        return 2
+    with socket.socket() as s_:  # a free rendezvous port on the loopback (the container hostname may not resolve)
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *argv]
+    print("[bench] launching: " + " ".join(cmd), file=sys.stderr, flush=True)
+    limit = float(os.environ.get("PSA_BENCH_LAUNCH_TIMEOUT", "3000"))
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        stdout, _ = child.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        print(f"bench.py: the {args.gpus}-rank child ran past {limit:.0f} s; stopping its process group", file=sys.stderr)
+        os.killpg(child.pid, signal.SIGTERM)  # exactly the group this call started (start_new_session)
+        try:
+            child.communicate(timeout=30)
+        except subprocess.TimeoutExpired:
+            os.killpg(child.pid, signal.SIGKILL)
+            child.communicate()
+        return 124
+    lines, rest = [], []
+    for ln in stdout.splitlines():
+        try:
+            ok = isinstance(json.loads(ln), dict) and "metric" in json.loads(ln)
+        except ValueError:
+            ok = False
+        (lines if ok else rest).append(ln)
+    if rest:
+        print("\n".join(rest), file=sys.stderr)
+    if child.returncode != 0:
+        print(f"bench.py: the {args.gpus}-rank child exited with {child.returncode}", file=sys.stderr)
+        return child.returncode
+    if len(lines) != 1:
+        print(f"bench.py: expected ONE JSON line from rank 0, got {len(lines)}", file=sys.stderr)
+        return 3
+    print(lines[0], flush=True)
+    return 0
+
+
+def main(argv=None) -> None:
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -344,7 +415,8 @@ def main() -> None:
     ap.add_argument("--no-extra", action="store_true", help="skip the breadth / power-law legs after the timed region")
     ap.add_argument("--exchange", default="auto", choices=["auto", "full", "full_p2p", "halo"],
                     help="N > 1: all of B by all-gather, the same by direct peer copies, or only the rows this rank's "
-                         "columns touch (all_to_all_single); auto times all of them before the warmup")
+                         "columns touch (all_to_all_single); auto times full and halo before the warmup "
+                         "(full_p2p only by name)")
     ap.add_argument("--feature-chunks", type=int, default=0,
                     help="N > 1: exchange B in this many column slices and run the SpMM of a slice under the "
                          "exchange of the next ones (1: one exchange, then the SpMM; default 0: time 1 and 4 "
@@ -354,16 +426,18 @@ def main() -> None:
                          "per gathered row and, at N > 1, on the fabric) — an optional run, never the headline")
     ap.add_argument("--no-plan", action="store_true", help="N > 1: rank-local kernel on the raw arrays (algo auto) "
                                                            "instead of the block's per-matrix plan")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # typed without a launcher: become the launcher (before anything initialises the GPU in this process)
+        raise SystemExit(self_launch(args, argv))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
+    load_compute_modules()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (there is no CPU fallback)")
     # Rehearsal hook (functional only): PSA_BENCH_REHEARSE_ON_ONE_GPU=1 lets N ranks SHARE cuda:0 and talk over gloo
@@ -463,7 +537,9 @@ def main() -> None:
     tune_ms = {}
     TUNE_STEPS = 10
     if use_dist:
-        exchanges = ["full", "full_p2p", "halo"] if args.exchange == "auto" else [args.exchange]
+        # full_p2p (batch_isend_irecv) has never run on more than one GPU: it is timed only when asked for by name,
+        # so that a first multi-GPU run cannot lose its headline to it
+        exchanges = ["full", "halo"] if args.exchange == "auto" else [args.exchange]
         chunk_opts = [1, 4] if args.feature_chunks == 0 and F % 16 == 0 else [max(args.feature_chunks, 1)]
         # exchange / send buffers and the output live on the objects: a step allocates nothing (distributed.py)
         ops_by_exchange = {e: RowPartitionedSpMM(shard, reduce=reduce, exchange=e, plan=not args.no_plan, keep_output=True)
@@ -536,6 +612,7 @@ def main() -> None:
             o.spmm_only(operand)
             kern_by_exchange[(e, c)] = event_ms(lambda: o.spmm_only(operand), other_steps)
 
+    kern_ms_own = kern_ms  # this rank's own kernel time (kern_ms becomes the slowest rank's below)
     vec = [elapsed, kern_ms] + [form_s[k] for k in forms] + [exch_ms[e] for e in exch_ms] + [kern_by_exchange[e] for e in kern_by_exchange]
     t = torch.tensor(vec, dtype=torch.float64, device=device)
     if use_dist:
@@ -547,7 +624,20 @@ def main() -> None:
     kern_by_exchange = dict(zip(kern_by_exchange, vec[2 + len(forms) + len(exch_ms):]))
     recv_rows = {}
     shard_sizes = None
+    esz = B_local.element_size()
+    minmax = args.op in ("spmm_max", "spmm_min")
+    if half:  # 2-byte dense rows: 2 F of every (12 + 2 F) bytes per edge, 8 + 2 F per row
+        my_alg = nnz * (8 + 4 + 2 * F) + M * (8 + 2 * F) + (M * F * 8 if minmax else 0)
+    else:
+        my_alg = algorithmic_bytes(nnz, M, F, True, minmax)
+    roof_rank, roof_ms, roof_alg, roof_nnz = 0, kern_ms_own, my_alg, nnz
     if use_dist:
+        # the roofline pairs ONE rank's kernel time with that same rank's bytes: the slowest rank's
+        kr = torch.zeros(world, 3, dtype=torch.float64, device=device)
+        kr[rank, 0], kr[rank, 1], kr[rank, 2] = kern_ms_own, float(my_alg), float(nnz)
+        dist.all_reduce(kr)
+        roof_rank = int(kr[:, 0].argmax())
+        roof_ms, roof_alg, roof_nnz = float(kr[roof_rank, 0]), int(kr[roof_rank, 1]), int(kr[roof_rank, 2])
         rr = torch.tensor([o.rows_received_per_step() for o in ops_by_exchange.values()], dtype=torch.int64, device=device)
         dist.all_reduce(rr, op=dist.ReduceOp.MAX)
         recv_rows = dict(zip(ops_by_exchange, rr.tolist()))
@@ -559,10 +649,8 @@ def main() -> None:
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_nnz / (elapsed / args.steps) / 1e9
-        alg = algorithmic_bytes(nnz, M, F, True, args.op in ("spmm_max", "spmm_min"))
-        if half:  # 2-byte dense rows: 2 F of every (12 + 2 F) bytes per edge, 8 + 2 F per row
-            alg = nnz * (8 + 4 + 2 * F) + M * (8 + 2 * F) + (M * F * 8 if args.op in ("spmm_max", "spmm_min") else 0)
-        achieved = alg / (kern_ms * 1e-3) / 1e9
+        alg = roof_alg
+        achieved = alg / (roof_ms * 1e-3) / 1e9
         traffic, traffic_note = None, "not collected for this configuration"
         tfile = ROOT / "profiles" / "traffic.json"
         if tfile.exists() and world == 1 and args.config == "c3" and not half:
@@ -575,9 +663,13 @@ def main() -> None:
                     f"({'a tenth of BASELINE config 3: rehearsal' if rehearse else 'BASELINE config 3'}), "
                     f"dense F={F} {args.dtype}, rows split by nnz over {world} GPU(s)")
         else:
-            cfg_name = "BASELINE config 3 per GPU" if args.config == "c3" else "BASELINE config 4's per-GPU share (F = 256)"
-            what = (f"{args.op} fwd, uniform random CSR {M}x{N} per GPU, nnz={nnz} per GPU, "
-                    f"dense F={F} {args.dtype} ({cfg_name})")
+            if world == 1 and args.config == "c3":  # the base of the strong series: the ONE config-3 matrix on one GPU
+                what = (f"{args.op} fwd, uniform random CSR {M}x{N}, nnz={nnz}, dense F={F} {args.dtype} "
+                        f"(BASELINE config 3, whole on one GPU)")
+            else:
+                cfg_name = "BASELINE config 3 per GPU" if args.config == "c3" else "BASELINE config 4's per-GPU share (F = 256)"
+                what = (f"{args.op} fwd, uniform random CSR {M}x{N} per GPU, nnz={nnz} per GPU, "
+                        f"dense F={F} {args.dtype} ({cfg_name})")
         if use_dist:
             what += (f"; + exchange of B ({N}x{F}, row-sharded) every step: {chosen[0]}"
                      + (f", in {chosen[1]} column slices overlapped with the SpMM" if chosen[1] > 1 else ""))
@@ -609,8 +701,8 @@ def main() -> None:
                 "traffic": traffic,
                 "traffic_source": traffic_note,
                 "algorithmic_bytes_per_launch": alg,
-                "kernel_ms": round(kern_ms, 4),
-                "kernel_gedges_per_s": round(nnz / (kern_ms * 1e-3) / 1e9, 4),
+                "kernel_ms": round(roof_ms, 4),
+                "kernel_gedges_per_s": round(roof_nnz / (roof_ms * 1e-3) / 1e9, 4),
             },
         }
         if rehearse:
@@ -621,8 +713,8 @@ def main() -> None:
             serial = {e: rate(form_s[(e, 1)]) for e in ops_by_exchange if (e, 1) in form_s}
             overl = {e: rate(form_s[(e, c)]) for (e, c) in form_s if c > 1}
             line["config"]["rows_nnz_by_rank"] = shard_sizes
-            line["roofline"]["note"] = ("rank 0's block: its kernel time over its own algorithmic bytes; kernel_ms is the "
-                                        "slowest rank's")
+            line["roofline"]["note"] = (f"rank {roof_rank}'s block (the slowest rank's kernel): its own algorithmic bytes "
+                                        "over its own HIP-event kernel time")
             line["multi_gpu"] = {
                 "form_timed_as_value": f"{chosen[0]}/chunks{chosen[1]}",
                 "form_chosen_by": "flags" if len(forms) == 1 else f"{TUNE_STEPS} steady-state steps per form before the warmup (ms per step by form)",
@@ -640,8 +732,8 @@ def main() -> None:
                                                     for (e, c) in exch_ms},
                 "step_over_parts_by_form": {f"{e}/chunks{c}": round(form_s[(e, c)] * 1e3 / (exch_ms[(e, c)] + kern_by_exchange[(e, c)]), 4)
                                             for (e, c) in exch_ms},
-                "allgather_bytes_received_per_rank": recv_rows.get("full", 0) * F * 4,
-                "bytes_received_per_rank_by_exchange": {e: r * F * 4 for e, r in recv_rows.items()},
+                "allgather_bytes_received_per_rank": recv_rows.get("full", 0) * F * esz,
+                "bytes_received_per_rank_by_exchange": {e: r * F * esz for e, r in recv_rows.items()},
                 "buffer_bytes_held_by_form_objects": {e: o.buffer_bytes() for e, o in ops_by_exchange.items()},
                 "note": "value counts the exchange of B inside every step, in the form named by form_timed_as_value; "
                         "spmm_only_* is the local-kernel rate with B already assembled (slowest rank)",
@@ -653,6 +745,10 @@ def main() -> None:
             scale = np.abs(ref).max()
             line["cpu_baseline"] = info
             line["check_max_abs_err_vs_oracle"] = float(np.abs(got - ref).max() / scale)
+        if "cpu_baseline" not in line:
+            line["cpu_baseline"] = None
+            line["cpu_baseline_note"] = ("the CPU leg runs on rank 0 at N = 1 with --op spmm_sum --dtype f32 only (here: "
+                                         f"n_gpus={world}, op={args.op}, dtype={args.dtype}, no_cpu={args.no_cpu})")
         if not args.no_extra and world == 1 and not use_dist and args.config == "c3" and not half:
             # after the timed region: the rest of BASELINE config 3 (mean / max forward, sum / max
             # forward + backward) and the forward on a power-law graph; headline fields unchanged

@@ -34,7 +34,7 @@ ordinary differentiable local product.  grad of the local block of B = this rank
 rows of sum_r A_r^T grad_out_r: every rank runs its block's backward (the one-pass
 kernels over the block's CSC view: every reduction, trained values, half width) and
 ONE `reduce_scatter_tensor` (full) or the halo's all_to_all run backwards followed
-by an add by `send_idx` (halo) brings the partial sums to their owners; the gradient
+by a segmented sum along the plan's return route (halo) brings the partial sums to their owners; the gradient
 of a block's edge values stays on its rank.
 
 xGMI arithmetic that decides what this can reach (8-GPU full mesh, 7 links x
@@ -177,8 +177,10 @@ def peer_copy_dense(buf: torch.Tensor, part: torch.Tensor, group=None, async_op:
     ops = []
     for d in range(1, world):  # peer order rotated by rank: at every position of the batch the pairs are disjoint
         dst, src = (rank + d) % world, (rank - d) % world
-        ops.append(dist.P2POp(dist.isend, part, dst, group))
-        ops.append(dist.P2POp(dist.irecv, buf[src * nb:(src + 1) * nb], src, group))
+        # dst / src are ranks OF `group`: the positional `peer` of P2POp is a GLOBAL rank (they differ in any
+        # group other than WORLD), `group_peer` is the group's own numbering
+        ops.append(dist.P2POp(dist.isend, part, group=group, group_peer=dst))
+        ops.append(dist.P2POp(dist.irecv, buf[src * nb:(src + 1) * nb], group=group, group_peer=src))
     if not ops:
         return None
     works = _Works(dist.batch_isend_irecv(ops))
@@ -222,6 +224,26 @@ class HaloPlan:
     send_idx: torch.Tensor        # int64[sum(send_counts)]: LOCAL row ids of b_local, grouped by destination
     col_local: torch.Tensor       # int64[nnz_local]: col remapped into the received (compacted) B
     num_needed: int               # rows of the compacted B = distinct columns of the local block
+    # the backward's way home, built at the first backward (`return_route`): the returned rows grouped by the local
+    # row they belong to — a stable order of send_idx (requesters stay in rank order) and its CSR pointer
+    back_order: Optional[torch.Tensor] = None   # int64[sum(send_counts)]
+    back_ptr: Optional[torch.Tensor] = None     # int64[block_rows + 1]
+
+    def return_route(self, block_rows: int) -> Tuple[torch.Tensor, torch.Tensor]:
+        if self.back_order is None:
+            idx = self.send_idx
+            if idx.is_cuda:
+                from . import ops
+
+                srt, order = ops.index_sort(idx, max_value=max(block_rows, 1), with_sorted_inputs=True, check=True)
+                self.back_ptr = ops.ind2ptr(srt, block_rows)
+            else:  # CPU / gloo tests
+                srt, order = torch.sort(idx, stable=True)
+                ptr = torch.zeros(block_rows + 1, dtype=torch.int64)
+                ptr[1:] = torch.cumsum(torch.bincount(srt, minlength=block_rows)[:block_rows], 0)
+                self.back_ptr = ptr
+            self.back_order = order.contiguous()
+        return self.back_order, self.back_ptr
 
 
 def plan_halo(shard: RowShard, block_rows: int, group=None) -> HaloPlan:
@@ -329,6 +351,10 @@ class RowPartitionedSpMM:
             return _hip_spmm_planned(self.reduce, self.local_storage(), s.value, operand, out)
         from . import ops
 
+        if out is not None and operand.dtype in (torch.float16, torch.bfloat16):
+            # as in _hip_spmm_planned: the half-width kernels allocate their result, one copy into the caller's slice
+            out.copy_(ops._spmm(self.reduce, s.rowptr, col, s.value, operand, want_arg=False)[0])
+            return out
         return ops._spmm(self.reduce, s.rowptr, col, s.value, operand, want_arg=False, out=out)[0]
 
     # ---- buffers that live as long as the object ---------------------------------------
@@ -497,9 +523,17 @@ class RowPartitionedSpMM:
         back = torch.empty((h.send_idx.numel(), F), dtype=part.dtype, device=part.device)
         dist.all_to_all_single(back, part.contiguous(), output_split_sizes=h.send_counts, input_split_sizes=h.need_counts,
                                group=self.group)
-        grad_local = torch.zeros((nb, F), dtype=part.dtype, device=part.device)
-        grad_local.index_add_(0, h.send_idx, back)  # a row may be asked for by several ranks
-        return grad_local
+        # a row may be asked for by several ranks: its copies are summed in requester order by a segmented
+        # reduction over the route built once per plan (no atomics: two runs give the same bits, like every
+        # single-GPU backward of the path)
+        order, ptr = h.return_route(nb)
+        if back.is_cuda:
+            from . import ops
+
+            acc = back if back.dtype == torch.float32 else back.float()
+            return ops.segment_csr(acc, ptr, "sum", perm=order).to(part.dtype)
+        acc = back[order].to(torch.float32)
+        return torch.segment_reduce(acc, "sum", offsets=ptr, axis=0, initial=0.0).to(part.dtype)
 
     def _grad_operand(self, grad_out: torch.Tensor) -> torch.Tensor:
         """A_r^T grad_out_r as an [operand height, F] matrix (rank-local)."""

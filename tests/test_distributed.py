@@ -216,6 +216,92 @@ def test_strong_split_every_exchange_more_ranks_gloo(world, M, N):
     mp.spawn(_worker_strong_split, args=(world, _free_port(), M, N, 12), nprocs=world, join=True)
 
 
+def _worker_halo_backward_bits(rank, world, port):
+    """The halo form's backward sums the copies of a row of B that several ranks asked for along a route built once
+    per plan (stable order of send_idx + its CSR pointer, a segmented sum) — no atomics: two runs give the same bits,
+    the route is built once, and the gradient equals the full form's within 1e-5 * sum |terms|."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from paddle_sparse_amd import distributed as pd
+
+        rng = np.random.default_rng(23)
+        M, N, F = 240, 90, 20
+        deg = rng.integers(2, 9, M)
+        rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+        row = np.repeat(np.arange(M), deg)
+        col = rng.integers(0, N, rowptr[-1]).astype(np.int64)
+        col[rng.random(col.size) < 0.3] = rng.integers(0, 5, 1)  # hub columns: asked for by every rank
+        val = rng.standard_normal(col.size).astype(np.float32)
+        B = rng.standard_normal((N, F)).astype(np.float32)
+        G = rng.standard_normal((M, F)).astype(np.float32)
+        args = (torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val), N)
+        full = pd.RowPartitionedSpMM.from_global(*args, local_spmm=_oracle_local_spmm)
+        halo = pd.RowPartitionedSpMM.from_global(*args, local_spmm=_oracle_local_spmm, exchange="halo")
+        s = halo.shard
+        g_local = torch.from_numpy(G[s.row_begin:s.row_end])
+        b_local = full.local_dense_block(torch.from_numpy(B))
+        grads = []
+        for o in (halo, halo, full):
+            bl = b_local.clone().requires_grad_(True)
+            o.apply(bl).backward(g_local)
+            grads.append(bl.grad.numpy().copy())
+        assert np.array_equal(grads[0], grads[1])  # bit-identical run to run
+        order, ptr = halo.halo.return_route(halo.block_rows)
+        assert halo.halo.return_route(halo.block_rows)[0] is order  # built once
+        sent = halo.halo.send_idx.numpy()
+        assert np.array_equal(sent[order.numpy()], np.sort(sent, kind="stable"))
+        assert np.array_equal(ptr.numpy(), np.searchsorted(np.sort(sent), np.arange(halo.block_rows + 1)))
+        nb = halo.block_rows
+        abs_terms = np.zeros((world * nb, F), np.float64)
+        np.add.at(abs_terms, col, np.abs(val[:, None].astype(np.float64) * G[row].astype(np.float64)))
+        tol = 1e-5 * abs_terms[rank * nb:(rank + 1) * nb] + 1e-30
+        assert np.all(np.abs(grads[0].astype(np.float64) - grads[2].astype(np.float64)) <= tol)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_halo_backward_is_bitwise_reproducible_world3_gloo():
+    import oracle
+
+    oracle.build()
+    mp.spawn(_worker_halo_backward_bits, args=(3, _free_port()), nprocs=3, join=True)
+
+
+def _worker_subgroup_p2p(rank, world, port):
+    """peer_copy_dense inside a group whose ranks are NOT the global ranks (global 1, 2 -> group 0, 1): the P2P
+    ops must name their peers in the group's numbering (the positional `peer` is a global rank)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from paddle_sparse_amd import distributed as pd
+
+        members = [1, 2]
+        grp = dist.new_group(members)  # every rank takes part in the creation
+        if rank in members:
+            g_rank = dist.get_rank(grp)
+            assert g_rank == members.index(rank) and g_rank != rank
+            nb, w = 5, 3
+            part = torch.full((nb, w), float(10 + rank))
+            buf = torch.zeros(2 * nb, w)
+            pd.peer_copy_dense(buf, part, grp)
+            want = torch.cat([torch.full((nb, w), float(10 + m)) for m in members])
+            assert torch.equal(buf, want)
+            buf2 = torch.zeros(2 * nb, w)
+            work = pd.peer_copy_dense(buf2, part, grp, async_op=True)
+            work.wait()
+            assert torch.equal(buf2, want)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_peer_copies_inside_a_subgroup_use_group_ranks_gloo():
+    mp.spawn(_worker_subgroup_p2p, args=(3, _free_port()), nprocs=3, join=True)
+
+
 def _worker_skewed_halo(rank, world, port, result_path):
     """Banded graph with a few hub columns: most of a rank's columns are its own
     rows' neighbours, so the halo is a small fraction of B; results identical."""
