@@ -217,10 +217,14 @@ int psa_spmm_half_coo(int reduce, int dtype, const int64_t* rowptr,
  * operand), grad f16/bf16 [M, K], grad_mat f16/bf16 [N, K] out (fp32 sums, one rounding),
  * grad_value_csc f32[nnz] out in CSC order or NULL.  weight_csc: f32[nnz] = value[csr2csc] (CSC
  * order: psa_permute_apply_u32 / psa_transpose_weights) or NULL (weights 1); row_scale f32[M] or
- * NULL multiplies both gradients per entry (mean: 1 / max(deg(r), 1)).  One wave per column, no
- * long-column path: for matrices whose CSC view takes the row-wave family.  K % 8 == 0, K <= 512
- * (the dot <mat[c, :], grad[r, :]> needs the whole row in one tile), else PSA_ERR_UNSUPPORTED.
- * The dtype list the reference parametrises over: paddle_sparse/testing.py:12-21. */
+ * NULL multiplies both gradients per entry (mean: 1 / max(deg(r), 1)).  One wave per column; with a
+ * workspace of psa_spmm_half_bw_csc_workspace_bytes(K, nnz) bytes, columns above 128 entries (the hub
+ * rows of a power-law matrix) are cut into 128-entry chunks with a wave each, whose fp32 partials are
+ * added in chunk order (workspace NULL: every column on its one wave, whatever its length).
+ * K % 8 == 0, K <= 512 (the dot <mat[c, :], grad[r, :]> needs the whole row in one tile), else
+ * PSA_ERR_UNSUPPORTED.  The dtype list the reference parametrises over: paddle_sparse/testing.py:12-21. */
+size_t psa_spmm_half_bw_csc_workspace_bytes(int64_t K, int64_t nnz);
+
 /* psa_spmm_half that also leaves the row-local form of arg_out behind (min / max; arg_bytes: [M, K]
  * entries of arg_width bytes as in psa_spmm_coo, or NULL; arg_out and arg_bytes are both optional). */
 int psa_spmm_half_arg(int reduce, int dtype, const int64_t* rowptr, const int64_t* col, const void* value,
@@ -231,15 +235,17 @@ int psa_spmm_half_arg(int reduce, int dtype, const int64_t* rowptr, const int64_
  * fp32 form is psa_spmm_minmax_bw_csc in its exact arg_bytes forms): an entry's term counts for column k
  * only where arg_bytes[r, k] equals the entry's tag (psa_csc_edge_tags, same width).  arg_bytes must be
  * exact (one byte: no row above 128 entries; two: none above 65 535).  weight_csc: f32[nnz] value[csr2csc]
- * or NULL; grad_value_csc f32[nnz] in CSC order or NULL; grad_mat in grad's dtype.  K % 8 == 0, K <= 512. */
+ * or NULL; grad_value_csc f32[nnz] in CSC order or NULL; grad_mat in grad's dtype.  K % 8 == 0, K <= 512.
+ * workspace: as for psa_spmm_half_sum_bw_csc (long columns in chunks), or NULL. */
 int psa_spmm_half_minmax_bw_csc(int dtype, const int64_t* colptr, const int64_t* row_csc, const void* tag,
                                 const float* weight_csc, const void* mat, const void* grad, const void* arg_bytes,
                                 int arg_width, int64_t M, int64_t N, int64_t K, int64_t nnz, float* grad_value_csc,
-                                void* grad_mat, psa_stream_t stream);
+                                void* grad_mat, void* workspace, size_t workspace_bytes, psa_stream_t stream);
 
 int psa_spmm_half_sum_bw_csc(int dtype, const int64_t* colptr, const int64_t* row_csc, const float* weight_csc,
                              const float* row_scale, const void* mat, const void* grad, int64_t M, int64_t N,
-                             int64_t K, int64_t nnz, float* grad_value_csc, void* grad_mat, psa_stream_t stream);
+                             int64_t K, int64_t nnz, float* grad_value_csc, void* grad_mat, void* workspace,
+                             size_t workspace_bytes, psa_stream_t stream);
 
 /* Test/bench hook: 0 = default (one row per wave), 1 = several rows per wave for
  * K <= 128, 2 = one row per wave with 8 gather steps in flight, 3 = default

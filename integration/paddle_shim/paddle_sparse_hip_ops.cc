@@ -439,9 +439,12 @@ std::vector<paddle::Tensor> spmm_half_sum_bw_csc(paddle::Tensor& colptr, paddle:
   const auto place = grad.place();
   auto gv_csc = paddle::empty({want_value ? nnz : 0}, paddle::DataType::FLOAT32, place);
   auto gm = paddle::empty({N, K}, grad.dtype(), place);
+  const size_t ws_bytes = psa_spmm_half_bw_csc_workspace_bytes(K, nnz);  // long columns in chunks (power-law transposes)
+  auto ws = paddle::empty({static_cast<int64_t>(ws_bytes)}, paddle::DataType::UINT8, place);
   PSA_CALL(psa_spmm_half_sum_bw_csc(dtype_id_of(grad), i64(colptr), i64(row_csc), f32_or_null(weight_csc),
                                     f32_or_null(row_scale), want_value ? mat.data() : nullptr, grad.data(), M, N, K, nnz,
-                                    want_value ? gv_csc.data<float>() : nullptr, gm.data(), stream_of(grad)));
+                                    want_value ? gv_csc.data<float>() : nullptr, gm.data(), ws_bytes ? ws.data() : nullptr,
+                                    ws_bytes, stream_of(grad)));
   return {gv_csc, gm};
 }
 PD_BUILD_OP(spmm_half_sum_bw_csc)
@@ -479,9 +482,12 @@ std::vector<paddle::Tensor> spmm_half_minmax_bw_csc(paddle::Tensor& colptr, padd
   const int width = tag.dtype() == paddle::DataType::INT16 ? 2 : 1;
   auto gv_csc = paddle::empty({want_value ? nnz : 0}, paddle::DataType::FLOAT32, place);
   auto gm = paddle::empty({N, K}, grad.dtype(), place);
+  const size_t ws_bytes = psa_spmm_half_bw_csc_workspace_bytes(K, nnz);
+  auto ws = paddle::empty({static_cast<int64_t>(ws_bytes)}, paddle::DataType::UINT8, place);
   PSA_CALL(psa_spmm_half_minmax_bw_csc(dtype_id_of(grad), i64(colptr), i64(row_csc), tag.data(), f32_or_null(weight_csc),
                                        want_value ? mat.data() : nullptr, grad.data(), arg_bytes.data(), width, M, N, K, nnz,
-                                       want_value ? gv_csc.data<float>() : nullptr, gm.data(), stream_of(grad)));
+                                       want_value ? gv_csc.data<float>() : nullptr, gm.data(),
+                                       ws_bytes ? ws.data() : nullptr, ws_bytes, stream_of(grad)));
   return {gv_csc, gm};
 }
 PD_BUILD_OP(spmm_half_minmax_bw_csc)

@@ -43,11 +43,13 @@ SIGNATURES = {
     "psa_spmm_half": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64,
                               c_int64, c_void_p, c_void_p, c_void_p]),
     "psa_spmm_half_sum_bw_csc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,
-                                         c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+                                         c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "psa_spmm_half_bw_csc_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "psa_spmm_half_arg": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64,
                                   c_int64, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "psa_spmm_half_minmax_bw_csc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                            c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+                                            c_int, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                            c_size_t, c_void_p]),
     "psa_spmm_half_set_variant": (c_int, [c_int]),
     "psa_csr_row_stats": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "psa_spmm_set_variant": (c_int, [c_int]),

@@ -12,6 +12,7 @@
 //                          plain psa_spmm over (colptr, row[csr2csc], w').
 //   psa_spmm_minmax_bw     scatter through arg_out with float atomics.
 #include "common.h"
+#include "lane_fold.h"
 #include "long_rows.h"
 
 namespace {
@@ -63,6 +64,7 @@ __device__ __forceinline__ void value_bw_range(const int64_t* __restrict__ col,
   for (int64_t base = s; base < e; base += 64) {
     const int n = (e - base) < 64 ? static_cast<int>(e - base) : 64;
     int64_t c_l = 0;
+    float keep = 0.f;  // the dot of this lane's edge, collected step by step
     if (lane < n) c_l = col[base + lane];
     for (int j = 0; j < n; j += G * U) {
       float dot[U];
@@ -99,31 +101,17 @@ __device__ __forceinline__ void value_bw_range(const int64_t* __restrict__ col,
           for (int i = 0; i < VEC; ++i) dot[u] += b[u][i] * gt[i];
         }
       }
-      // Fold the U partial dots of this lane group together: each halving
-      // step sends the half a lane does not keep to its partner (xor bit), so
-      // U-1 + log2(LPR/U) shuffles replace U*log2(LPR).  Lane l ends up with
-      // the full dot of edge slot u = l % U.
-      static_assert((U & (U - 1)) == 0 && U <= LPR, "U must be a power of two <= LPR");
-      {
-        int cnt = U;
-#pragma unroll
-        for (int bit = 1; bit < U; bit <<= 1, cnt >>= 1) {
-          const bool up = (l & bit) != 0;
-#pragma unroll
-          for (int i = 0; i < cnt / 2; ++i) {
-            const float keep = up ? dot[2 * i + 1] : dot[2 * i];
-            const float send = up ? dot[2 * i] : dot[2 * i + 1];
-            dot[i] = keep + __shfl_xor(send, bit);
-          }
-        }
-#pragma unroll
-        for (int bit = U; bit < LPR; bit <<= 1) dot[0] += __shfl_xor(dot[0], bit);
-      }
-      if (l < U) {
-        const int idx = j + l * G + g;
-        if (idx < n) __builtin_nontemporal_store(dot[0] / denom, out + base + idx);  // written once: keep it out of the caches
-      }
+      // Fold the U partial dots of this lane group together (lane_fold.h: DPP / permlane moves in the
+      // VALU, no ds_bpermute): lane l < U of group g ends up with the whole dot of edge slot j + l * G + g.
+      psa::fold_group_dots<LPR, U>(dot, l);
+      // It is handed to the lane that loaded that edge (lane == slot) and stored once per 64-edge batch —
+      // 256 contiguous bytes instead of G * U floats per step (partial-line writes: 199 MB written for 80 MB
+      // of grad_value at config 3, profiles/r03_pmc_backward.json).
+      const unsigned rel = static_cast<unsigned>(lane - j);  // this lane's edge belongs to the step iff rel < G * U
+      const float got = __shfl(dot[0], static_cast<int>(((rel % G) * LPR + rel / G) & 63u));
+      if (rel < static_cast<unsigned>(G * U)) keep = got;
     }
+    if (lane < n) __builtin_nontemporal_store(keep / denom, out + base + lane);  // written once: keep it out of the caches
   }
 }
 

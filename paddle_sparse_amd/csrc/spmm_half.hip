@@ -19,6 +19,8 @@
 #include <hip/hip_fp16.h>
 
 #include "common.h"
+#include "lane_fold.h"
+#include "long_rows.h"
 #include "spmm_eb.h"
 #include "vec_io.h"
 
@@ -163,9 +165,10 @@ spmm_half_row_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restri
       }
     }
   }
-  // fold the G edge slots
+  // fold the G edge slots (sums: in the VALU, lane_fold.h)
+  if constexpr (RED == R_SUM) psa::fold_lane_groups<LPR, 8>(acc);
 #pragma unroll
-  for (int off = LPR; off < 64; off <<= 1) {
+  for (int off = LPR; off < 64 && RED != R_SUM; off <<= 1) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const float o = __shfl_xor(acc[i], off);
@@ -334,44 +337,22 @@ spmm_half_multirow_kernel(const int64_t* __restrict__ rowptr, const int64_t* __r
 // `tags` [nnz] (CSC order); an entry's term counts for column k only where words[r, k] == its tag — the
 // masked form of the fp32 pass (spmm.hip, M_MASK) in its exact forms (1 byte: no row above 128 entries;
 // 2 bytes: none above 65 535).  MW = 0: sum / mean, every term counts.
-template <typename T, int LPR, int U, bool GV, int MW = 0, bool SMALL = false>
-__global__ void __launch_bounds__(kThreads, (MW != 0 && GV) ? 5 : 6)  // sum: 78 VGPRs without spilling at 6 waves per SIMD (81 / 5 unconstrained); masked + grad_value: 5
-spmm_half_csc_bw_kernel(const int64_t* __restrict__ colptr, const int64_t* __restrict__ row_csc,
-                        const float* __restrict__ w_csc, const float* __restrict__ row_scale,
-                        const uint16_t* __restrict__ mat, const uint16_t* __restrict__ grad,
-                        uint16_t* __restrict__ grad_mat, float* __restrict__ grad_value, int64_t N, int64_t K,
-                        int mix_xcds, const uint8_t* __restrict__ words = nullptr,
-                        const uint8_t* __restrict__ tags = nullptr) {
+typedef float F2 __attribute__((ext_vector_type(2)));
+
+// Entries [s, e) of ONE column of the CSC view (all of it for a row wave, a 128-entry chunk for a chunk wave):
+// acc += w * grad[r, k0 .. k0 + 7] (masked for MW != 0), grad_value[j] = <mat[c, :], grad[r, :]> stored per
+// 64-entry batch.  mr: the lane's slice of mat[c, :] (GV only).
+template <typename T, int LPR, int U, bool GV, int MW, bool SMALL>
+__device__ __forceinline__ void half_csc_bw_range(const int64_t* __restrict__ row_csc, const float* __restrict__ w_csc,
+                                                  const float* __restrict__ row_scale, const uint16_t* __restrict__ grad,
+                                                  float* __restrict__ grad_value, int64_t K, int64_t k0, bool kact,
+                                                  int lane, int64_t s, int64_t e, const uint8_t* __restrict__ words,
+                                                  const uint8_t* __restrict__ tags, const F2 (&mr)[4], F2 (&acc)[4]) {
   constexpr int G = 64 / LPR;
   static_assert(64 % (G * U) == 0, "edge batch must divide the wave");
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  int64_t rb = blockIdx.x;
-  if (mix_xcds) rb ^= static_cast<int64_t>((static_cast<uint32_t>(rb >> 3) * 0x9E3779B1u) >> 29);
-  const int64_t c = rb * kWaves + wave;
-  if (c >= N) return;
   const int g = lane / LPR;
   const int l = lane % LPR;
-  const int64_t k0 = static_cast<int64_t>(l) * 8;
-  const bool kact = k0 < K;
   const uint16_t* gk = grad + k0;
-  const int64_t s = colptr[c], e = colptr[c + 1];
-
-  // sums and products as pairs: v_pk_fma_f32 does two fp32 FMAs per issue slot, and a wave64 VALU
-  // instruction takes 4 issue cycles on this chip — with ~10 entries per column the pass is bound by
-  // instruction issue, not by bytes (profiles/r03_half_train_step.txt)
-  typedef float F2 __attribute__((ext_vector_type(2)));
-  F2 acc[4], mr[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) acc[i] = F2{0.f, 0.f};
-  if constexpr (GV) {
-    uint4 raw = make_uint4(0u, 0u, 0u, 0u);
-    if (kact) raw = *reinterpret_cast<const uint4*>(mat + c * K + k0);
-    float m8[8];
-    widen8<T>(raw, m8);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) mr[i] = F2{m8[2 * i], m8[2 * i + 1]};
-  }
   for (int64_t base = s; base < e; base += 64) {
     const int n = (e - base) < 64 ? static_cast<int>(e - base) : 64;
     int64_t r_l = 0;
@@ -397,10 +378,10 @@ spmm_half_csc_bw_kernel(const int64_t* __restrict__ colptr, const int64_t* __res
         if constexpr (MW != 0) wd[u] = {};
         if constexpr (SMALL) {  // (see spmm_half_row_kernel)
           const uint32_t r = static_cast<uint32_t>(__shfl(static_cast<int>(r_l), idx));
-          const uint32_t e = r * static_cast<uint32_t>(K) + static_cast<uint32_t>(k0);
-          if (ok[u]) raw[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(grad) + e * 2u);
+          const uint32_t eo = r * static_cast<uint32_t>(K) + static_cast<uint32_t>(k0);
+          if (ok[u]) raw[u] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(grad) + eo * 2u);
           if constexpr (MW != 0) {
-            if (ok[u]) wd[u] = *reinterpret_cast<const Words*>(words + e * static_cast<uint32_t>(MW));
+            if (ok[u]) wd[u] = *reinterpret_cast<const Words*>(words + eo * static_cast<uint32_t>(MW));
           }
         } else {
           const int64_t r = shfl_i64(r_l, idx);
@@ -443,24 +424,10 @@ spmm_half_csc_bw_kernel(const int64_t* __restrict__ colptr, const int64_t* __res
         dot[u] = d2[0] + d2[1];
       }
       if constexpr (GV) {
-        static_assert((U & (U - 1)) == 0 && U <= LPR, "U must be a power of two <= LPR");
-        // fold the U partial dots of the lane group transposing as it goes (spmm.hip, value_bw_range): after
-        // log2(U) exchange steps lane l holds the partial of edge slot u = l % U, the remaining bits add up
-        int cnt = U;
-#pragma unroll
-        for (int bit = 1; bit < U; bit <<= 1, cnt >>= 1) {
-          const bool up = (l & bit) != 0;
-#pragma unroll
-          for (int i = 0; i < cnt / 2; ++i) {
-            const float keep = up ? dot[2 * i + 1] : dot[2 * i];
-            const float send = up ? dot[2 * i] : dot[2 * i + 1];
-            dot[i] = keep + __shfl_xor(send, bit);
-          }
-        }
-#pragma unroll
-        for (int bit = U; bit < LPR; bit <<= 1) dot[0] += __shfl_xor(dot[0], bit);
-        // lane l < U of group g now holds the dot of edge slot j + l * G + g; the lane that loaded that
-        // edge (lane == slot) keeps it for one 256-byte store per 64-edge batch
+        // fold the U partial dots of the lane group transposing as it goes (lane_fold.h: DPP / permlane moves
+        // in the VALU): lane l < U of group g then holds the dot of edge slot j + l * G + g; the lane that
+        // loaded that edge (lane == slot) keeps it for one 256-byte store per 64-edge batch
+        psa::fold_group_dots<LPR, U>(dot, l);
         const unsigned rel = static_cast<unsigned>(lane - j);
         const float got = __shfl(dot[0], static_cast<int>(((rel % G) * LPR + rel / G) & 63u));
         if (rel < static_cast<unsigned>(G * U)) gv_keep = got;
@@ -468,17 +435,66 @@ spmm_half_csc_bw_kernel(const int64_t* __restrict__ colptr, const int64_t* __res
     }
     if (GV && lane < n) __builtin_nontemporal_store(gv_keep * s_l, grad_value + base + lane);
   }
+}
+
+template <typename T, bool GV>
+__device__ __forceinline__ void half_load_mat_row(const uint16_t* __restrict__ mat, int64_t c, int64_t K, int64_t k0,
+                                                  bool kact, F2 (&mr)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) mr[i] = F2{0.f, 0.f};
+  if constexpr (GV) {
+    uint4 raw = make_uint4(0u, 0u, 0u, 0u);
+    if (kact) raw = *reinterpret_cast<const uint4*>(mat + c * K + k0);
+    float m8[8];
+    widen8<T>(raw, m8);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) mr[i] = F2{m8[2 * i], m8[2 * i + 1]};
+  }
+}
+
+// One wave per column.  long_list != NULL: columns above psa::kLongRow entries are handed to chunk waves
+// (long_rows.h) instead — a hub row of a power-law graph is a 40 000-entry column of the CSC view, which one wave
+// would walk for milliseconds.
+template <typename T, int LPR, int U, bool GV, int MW = 0, bool SMALL = false>
+__global__ void __launch_bounds__(kThreads, (MW != 0 && GV) ? 5 : 6)  // sum: 78 VGPRs without spilling at 6 waves per SIMD (81 / 5 unconstrained); masked + grad_value: 5
+spmm_half_csc_bw_kernel(const int64_t* __restrict__ colptr, const int64_t* __restrict__ row_csc,
+                        const float* __restrict__ w_csc, const float* __restrict__ row_scale,
+                        const uint16_t* __restrict__ mat, const uint16_t* __restrict__ grad,
+                        uint16_t* __restrict__ grad_mat, float* __restrict__ grad_value, int64_t N, int64_t K,
+                        int mix_xcds, const uint8_t* __restrict__ words = nullptr,
+                        const uint8_t* __restrict__ tags = nullptr, unsigned long long* __restrict__ long_ctr = nullptr,
+                        psa::LongEntry* __restrict__ long_list = nullptr) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int64_t rb = blockIdx.x;
+  if (mix_xcds) rb ^= static_cast<int64_t>((static_cast<uint32_t>(rb >> 3) * 0x9E3779B1u) >> 29);
+  const int64_t c = rb * kWaves + wave;
+  if (c >= N) return;
+  const int g = lane / LPR;
+  const int l = lane % LPR;
+  const int64_t k0 = static_cast<int64_t>(l) * 8;
+  const bool kact = k0 < K;
+  const int64_t s = colptr[c], e = colptr[c + 1];
+  if (long_list != nullptr && e - s > psa::kLongRow) {  // wave-uniform
+    if (lane == 0) psa::push_long_row(long_ctr, long_list, c, e - s);
+    return;
+  }
+  // sums and products as pairs: v_pk_fma_f32 does two fp32 FMAs per issue slot, and a wave64 VALU
+  // instruction takes 4 issue cycles on this chip — with ~10 entries per column the pass is bound by
+  // instruction issue, not by bytes (profiles/r03_half_train_step.txt)
+  F2 acc[4], mr[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = F2{0.f, 0.f};
+  half_load_mat_row<T, GV>(mat, c, K, k0, kact, mr);
+  half_csc_bw_range<T, LPR, U, GV, MW, SMALL>(row_csc, w_csc, row_scale, grad, grad_value, K, k0, kact, lane, s, e, words,
+                                               tags, mr, acc);
   float a8[8];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     a8[2 * i] = acc[i][0];
     a8[2 * i + 1] = acc[i][1];
   }
-#pragma unroll
-  for (int off = LPR; off < 64; off <<= 1) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) a8[i] += __shfl_xor(a8[i], off);
-  }
+  psa::fold_lane_groups<LPR, 8>(a8);  // the lane groups' sums: permlane swaps / DPP, the bits of the xor shuffles
   if (g == 0 && kact) {
     const uint4 packed = narrow8<T>(a8);
     typedef unsigned int U4 __attribute__((ext_vector_type(4)));
@@ -488,6 +504,89 @@ spmm_half_csc_bw_kernel(const int64_t* __restrict__ colptr, const int64_t* __res
     st[2] = packed.z;
     st[3] = packed.w;
     __builtin_nontemporal_store(st, reinterpret_cast<U4*>(grad_mat + c * K + k0));
+  }
+}
+
+// One wave per 128-entry chunk of a long column (grid-stride over the chunk list): its fp32 partial of
+// grad_mat[c, :] goes to part[chunk, :]; its grad_value entries are final (chunks own disjoint entries).
+template <typename T, int LPR, int U, bool GV, int MW, bool SMALL>
+__global__ void __launch_bounds__(psa::kLongThreads)
+spmm_half_csc_bw_chunk_kernel(const int64_t* __restrict__ colptr, const int64_t* __restrict__ row_csc,
+                              const float* __restrict__ w_csc, const float* __restrict__ row_scale,
+                              const uint16_t* __restrict__ mat, const uint16_t* __restrict__ grad,
+                              float* __restrict__ grad_value, int64_t K, const uint8_t* __restrict__ words,
+                              const uint8_t* __restrict__ tags, const unsigned long long* __restrict__ long_ctr,
+                              const psa::LongEntry* __restrict__ long_list, float* __restrict__ part) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long ctr = *long_ctr;
+  const uint32_t total = static_cast<uint32_t>(ctr & 0xffffffffull);
+  const int ncols = static_cast<int>(ctr >> 32);
+  const int g = lane / LPR;
+  const int l = lane % LPR;
+  const int64_t k0 = static_cast<int64_t>(l) * 8;
+  const bool kact = k0 < K;
+  const uint32_t num_waves = gridDim.x * (blockDim.x >> 6);
+  for (uint32_t ch = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); ch < total; ch += num_waves) {
+    const psa::LongEntry ent = psa::find_long_entry(long_list, ncols, ch);
+    const int64_t cs = colptr[ent.row], ce = colptr[ent.row + 1];
+    const int64_t s = cs + static_cast<int64_t>(ch - ent.first_chunk) * psa::kLongChunk;
+    const int64_t e = s + psa::kLongChunk < ce ? s + psa::kLongChunk : ce;
+    F2 acc[4], mr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = F2{0.f, 0.f};
+    half_load_mat_row<T, GV>(mat, ent.row, K, k0, kact, mr);
+    half_csc_bw_range<T, LPR, U, GV, MW, SMALL>(row_csc, w_csc, row_scale, grad, grad_value, K, k0, kact, lane, s, e,
+                                                 words, tags, mr, acc);
+    float a8[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      a8[2 * i] = acc[i][0];
+      a8[2 * i + 1] = acc[i][1];
+    }
+    psa::fold_lane_groups<LPR, 8>(a8);
+    if (g == 0 && kact) {
+      float* dst = part + static_cast<int64_t>(ch) * K + k0;
+      *reinterpret_cast<float4*>(dst) = make_float4(a8[0], a8[1], a8[2], a8[3]);
+      *reinterpret_cast<float4*>(dst + 4) = make_float4(a8[4], a8[5], a8[6], a8[7]);
+    }
+  }
+}
+
+// One wave per long column: its chunks' partials summed in chunk order (fp32), one rounding on store.
+template <typename T>
+__global__ void __launch_bounds__(psa::kLongThreads)
+spmm_half_csc_bw_combine_kernel(int64_t K, const unsigned long long* __restrict__ long_ctr,
+                                const psa::LongEntry* __restrict__ long_list, const float* __restrict__ part,
+                                uint16_t* __restrict__ grad_mat) {
+  const int lane = threadIdx.x & 63;
+  const int ncols = static_cast<int>(*long_ctr >> 32);
+  const int num_waves = gridDim.x * (blockDim.x >> 6);
+  for (int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); r < ncols; r += num_waves) {
+    const psa::LongEntry ent = long_list[r];
+    for (int64_t k0 = static_cast<int64_t>(lane) * 8; k0 < K; k0 += 512) {
+      const float* src = part + static_cast<int64_t>(ent.first_chunk) * K + k0;
+      float a8[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a8[i] = 0.f;
+      for (uint32_t ch = 0; ch < ent.num_chunks; ch += 4) {  // four partials requested per step, added in chunk order
+        float4 x[4][2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const bool on = ch + t < ent.num_chunks;
+          const float* p = src + static_cast<int64_t>(ch + t) * K;
+          x[t][0] = on ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+          x[t][1] = on ? *reinterpret_cast<const float4*>(p + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (ch + t >= ent.num_chunks) break;
+          a8[0] += x[t][0].x; a8[1] += x[t][0].y; a8[2] += x[t][0].z; a8[3] += x[t][0].w;
+          a8[4] += x[t][1].x; a8[5] += x[t][1].y; a8[6] += x[t][1].z; a8[7] += x[t][1].w;
+        }
+      }
+      const uint4 packed = narrow8<T>(a8);
+      *reinterpret_cast<uint4*>(grad_mat + ent.row * K + k0) = packed;
+    }
   }
 }
 
@@ -585,31 +684,68 @@ int dispatch_half(int red, bool track, bool val32, const int64_t* rowptr, const 
 }
 
 
+// scratch of the long-column path: {counter, list of long columns, fp32 partials [chunks, K]}
+struct HalfLong {
+  unsigned long long* ctr = nullptr;
+  psa::LongEntry* list = nullptr;
+  float* part = nullptr;
+};
+
+size_t half_long_bytes(int64_t K, int64_t nnz) {
+  if (K <= 0 || nnz <= psa::kLongRow) return 0;
+  return psa::long_list_bytes(nnz) + psa::align256(sizeof(float) * static_cast<size_t>(psa::max_long_chunks(nnz)) * K);
+}
+
+template <typename T, int LPR, int U, bool GV, int MW, bool SMALL>
+int launch_half_csc_bw(const int64_t* colptr, const int64_t* row_csc, const float* w_csc, const float* row_scale,
+                       const uint16_t* mat, const uint16_t* grad, uint16_t* grad_mat, float* grad_value, int64_t N,
+                       int64_t K, hipStream_t s, const uint8_t* words, const uint8_t* tags, const HalfLong& w) {
+  const int64_t gx = psa::ceil_div(psa::ceil_div(N, kWaves), 8) * 8;
+  PSA_REQUIRE(gx <= 0x7fffffff, "problem too large for one launch");
+  hipLaunchKernelGGL((spmm_half_csc_bw_kernel<T, LPR, U, GV, MW, SMALL>), dim3(static_cast<unsigned>(gx)), dim3(kThreads), 0, s,
+                     colptr, row_csc, w_csc, row_scale, mat, grad, grad_mat, grad_value, N, K, 1, words, tags, w.ctr, w.list);
+  if (w.list != nullptr) {  // columns above 128 entries: chunk waves, then their partials in chunk order
+    hipLaunchKernelGGL((spmm_half_csc_bw_chunk_kernel<T, LPR, U, GV, MW, SMALL>), dim3(psa::kLongBlocks),
+                       dim3(psa::kLongThreads), 0, s, colptr, row_csc, w_csc, row_scale, mat, grad, grad_value, K, words,
+                       tags, w.ctr, w.list, w.part);
+    hipLaunchKernelGGL((spmm_half_csc_bw_combine_kernel<T>), dim3(psa::kLongBlocks), dim3(psa::kLongThreads), 0, s, K,
+                       w.ctr, w.list, w.part, grad_mat);
+  }
+  PSA_LAUNCH_CHECK();
+  return PSA_OK;
+}
+
 template <typename T, int MW = 0>
 int dispatch_half_csc_bw(const int64_t* colptr, const int64_t* row_csc, const float* w_csc, const float* row_scale,
                          const uint16_t* mat, const uint16_t* grad, uint16_t* grad_mat, float* grad_value, int64_t N,
-                         int64_t K, hipStream_t s, const uint8_t* words = nullptr, const uint8_t* tags = nullptr,
-                         bool small = false) {
-  const int64_t gx = psa::ceil_div(psa::ceil_div(N, kWaves), 8) * 8;
-  PSA_REQUIRE(gx <= 0x7fffffff, "problem too large for one launch");
-  const dim3 grid(static_cast<unsigned>(gx)), block(kThreads);
+                         int64_t K, int64_t nnz, hipStream_t s, const uint8_t* words, const uint8_t* tags, bool small,
+                         void* workspace, size_t workspace_bytes) {
+  HalfLong w;
+  if (workspace != nullptr && nnz > psa::kLongRow) {
+    if (workspace_bytes < half_long_bytes(K, nnz)) {
+      psa::set_error("half-width pass over the CSC view: workspace too small");
+      return PSA_ERR_WORKSPACE;
+    }
+    PSA_REQUIRE(psa::aligned(workspace, 16), "workspace must be 16-byte aligned");
+    w.ctr = static_cast<unsigned long long*>(workspace);
+    w.list = reinterpret_cast<psa::LongEntry*>(static_cast<char*>(workspace) + 256);
+    w.part = reinterpret_cast<float*>(static_cast<char*>(workspace) + psa::long_list_bytes(nnz));
+    PSA_ZERO(w.ctr, 8, s);
+  }
   const int64_t q = K / 8;
-#define PSA_GO(LPR, U)                                                                                              \
-  do {                                                                                                              \
-    if (grad_value != nullptr && small)                                                                             \
-      hipLaunchKernelGGL((spmm_half_csc_bw_kernel<T, LPR, U, true, MW, true>), grid, block, 0, s, colptr, row_csc,  \
-                         w_csc, row_scale, mat, grad, grad_mat, grad_value, N, K, 1, words, tags);                  \
-    else if (grad_value != nullptr)                                                                                 \
-      hipLaunchKernelGGL((spmm_half_csc_bw_kernel<T, LPR, U, true, MW, false>), grid, block, 0, s, colptr, row_csc, \
-                         w_csc, row_scale, mat, grad, grad_mat, grad_value, N, K, 1, words, tags);                  \
-    else if (small)                                                                                                 \
-      hipLaunchKernelGGL((spmm_half_csc_bw_kernel<T, LPR, U, false, MW, true>), grid, block, 0, s, colptr, row_csc, \
-                         w_csc, row_scale, mat, grad, grad_mat, grad_value, N, K, 1, words, tags);                  \
-    else                                                                                                            \
-      hipLaunchKernelGGL((spmm_half_csc_bw_kernel<T, LPR, U, false, MW, false>), grid, block, 0, s, colptr, row_csc, \
-                         w_csc, row_scale, mat, grad, grad_mat, grad_value, N, K, 1, words, tags);                  \
-    PSA_LAUNCH_CHECK();                                                                                             \
-    return PSA_OK;                                                                                                  \
+#define PSA_GO(LPR, U)                                                                                                   \
+  do {                                                                                                                   \
+    if (grad_value != nullptr && small)                                                                                  \
+      return launch_half_csc_bw<T, LPR, U, true, MW, true>(colptr, row_csc, w_csc, row_scale, mat, grad, grad_mat,       \
+                                                            grad_value, N, K, s, words, tags, w);                        \
+    if (grad_value != nullptr)                                                                                           \
+      return launch_half_csc_bw<T, LPR, U, true, MW, false>(colptr, row_csc, w_csc, row_scale, mat, grad, grad_mat,      \
+                                                             grad_value, N, K, s, words, tags, w);                       \
+    if (small)                                                                                                           \
+      return launch_half_csc_bw<T, LPR, U, false, MW, true>(colptr, row_csc, w_csc, row_scale, mat, grad, grad_mat,      \
+                                                             grad_value, N, K, s, words, tags, w);                       \
+    return launch_half_csc_bw<T, LPR, U, false, MW, false>(colptr, row_csc, w_csc, row_scale, mat, grad, grad_mat,       \
+                                                            grad_value, N, K, s, words, tags, w);                        \
   } while (0)
   if (q <= 1) PSA_GO(1, 1);
   if (q <= 2) PSA_GO(2, 2);
@@ -626,7 +762,7 @@ int dispatch_half_csc_bw(const int64_t* colptr, const int64_t* row_csc, const fl
 extern "C" int psa_spmm_half_sum_bw_csc(int dtype, const int64_t* colptr, const int64_t* row_csc, const float* weight_csc,
                                         const float* row_scale, const void* mat, const void* grad, int64_t M, int64_t N,
                                         int64_t K, int64_t nnz, float* grad_value_csc, void* grad_mat,
-                                        psa_stream_t stream) {
+                                        void* workspace, size_t workspace_bytes, psa_stream_t stream) {
   PSA_REQUIRE(M >= 0 && N >= 0 && K >= 0 && nnz >= 0, "negative size");
   if (dtype != PSA_F16 && dtype != PSA_BF16) {
     psa::set_error("psa_spmm_half_sum_bw_csc: dtype must be PSA_F16 or PSA_BF16");
@@ -645,11 +781,13 @@ extern "C" int psa_spmm_half_sum_bw_csc(int dtype, const int64_t* colptr, const 
   const uint16_t* g = static_cast<const uint16_t*>(grad);
   uint16_t* gm = static_cast<uint16_t*>(grad_mat);
   if (dtype == PSA_BF16)
-    return dispatch_half_csc_bw<BF16>(colptr, row_csc, weight_csc, row_scale, m, g, gm, grad_value_csc, N, K, s, nullptr, nullptr,
-                                      M * K * 2 < (1ll << 32));
-  return dispatch_half_csc_bw<F16>(colptr, row_csc, weight_csc, row_scale, m, g, gm, grad_value_csc, N, K, s, nullptr, nullptr,
-                                   M * K * 2 < (1ll << 32));
+    return dispatch_half_csc_bw<BF16>(colptr, row_csc, weight_csc, row_scale, m, g, gm, grad_value_csc, N, K, nnz, s, nullptr,
+                                      nullptr, M * K * 2 < (1ll << 32), workspace, workspace_bytes);
+  return dispatch_half_csc_bw<F16>(colptr, row_csc, weight_csc, row_scale, m, g, gm, grad_value_csc, N, K, nnz, s, nullptr,
+                                   nullptr, M * K * 2 < (1ll << 32), workspace, workspace_bytes);
 }
+
+extern "C" size_t psa_spmm_half_bw_csc_workspace_bytes(int64_t K, int64_t nnz) { return half_long_bytes(K, nnz); }
 
 extern "C" int psa_spmm_half_set_variant(int v) {
   const int prev = g_half_variant;
@@ -702,7 +840,8 @@ extern "C" int psa_spmm_half(int reduce, int dtype, const int64_t* rowptr, const
 extern "C" int psa_spmm_half_minmax_bw_csc(int dtype, const int64_t* colptr, const int64_t* row_csc, const void* tag,
                                            const float* weight_csc, const void* mat, const void* grad,
                                            const void* arg_bytes, int arg_width, int64_t M, int64_t N, int64_t K,
-                                           int64_t nnz, float* grad_value_csc, void* grad_mat, psa_stream_t stream) {
+                                           int64_t nnz, float* grad_value_csc, void* grad_mat, void* workspace,
+                                           size_t workspace_bytes, psa_stream_t stream) {
   PSA_REQUIRE(M >= 0 && N >= 0 && K >= 0 && nnz >= 0, "negative size");
   if (dtype != PSA_F16 && dtype != PSA_BF16) {
     psa::set_error("psa_spmm_half_minmax_bw_csc: dtype must be PSA_F16 or PSA_BF16");
@@ -724,7 +863,9 @@ extern "C" int psa_spmm_half_minmax_bw_csc(int dtype, const int64_t* colptr, con
   uint16_t* gm = static_cast<uint16_t*>(grad_mat);
   const uint8_t* words = static_cast<const uint8_t*>(arg_bytes);
   const uint8_t* tags = static_cast<const uint8_t*>(tag);
-#define PSA_MM(T, MW) return dispatch_half_csc_bw<T, MW>(colptr, row_csc, weight_csc, nullptr, m, g, gm, grad_value_csc, N, K, s, words, tags, M * K * 2 < (1ll << 32))
+#define PSA_MM(T, MW)                                                                                                  \
+  return dispatch_half_csc_bw<T, MW>(colptr, row_csc, weight_csc, nullptr, m, g, gm, grad_value_csc, N, K, nnz, s, words, \
+                                     tags, M * K * 2 < (1ll << 32), workspace, workspace_bytes)
   if (dtype == PSA_BF16) {
     if (arg_width == 2) PSA_MM(BF16, 2);
     PSA_MM(BF16, 1);

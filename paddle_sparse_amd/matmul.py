@@ -21,6 +21,10 @@ from .storage import SparseStorage
 from .tensor import SparseTensor
 
 
+HUGE_IDS = 1 << 20  # room kept below 2^31 for the ids of hub rows and pieces in the compact copies
+HUGE_ROW_PIECES = True  # test hook: False sends matrices with rows above 65 535 entries back to the int64 arg_out
+
+
 def _csc_weights(st: SparseStorage, value: Optional[torch.Tensor], csr2csc, row_csc, mean: bool):
     """Edge weights in CSC order for grad_mat = A^T grad_out (value[csr2csc],
     over deg(row) for mean).  A fixed adjacency — the usual GNN case — asks for
@@ -56,10 +60,31 @@ def _streamed_values(st: SparseStorage, value: Optional[torch.Tensor], plan="ask
 
 def _half_minmax_bw_ok(st: SparseStorage, K: int) -> bool:
     """Will the half-width masked pass over the CSC view serve the min / max backward of this matrix?  K in one
-    tile, an exact row-local form (no row above 65 535 entries), and a transpose that takes the row-wave family
-    (one wave per column; power-law transposes keep the fp32 route with its long-column and hub-row machinery)."""
+    tile, an exact row-local form (no row above 65 535 entries) and a forward of the row-wave family (the one that
+    leaves that form behind in half width).  The transpose may be anything: long columns run in chunks."""
     return (ops.half_sum_bw_csc_supported(K) and st._longest_row() <= ops.ARG_WORDS_EXACT_ROW
-            and st._spmm_algo() == "row_waves" and st._csc_view()._spmm_algo() == "row_waves")
+            and st._spmm_algo() == "row_waves")
+
+
+def _huge_piece_winners(st: SparseStorage, reduce: str, value: Optional[torch.Tensor], mat: torch.Tensor) -> torch.Tensor:
+    """min / max on a matrix with rows above 65 535 entries, without an int64 arg_out: the rows in question are
+    reduced once more as PIECES of at most 65 535 entries (`SparseStorage._huge_rows`: a small CSR of its own, the
+    same kernels), each piece leaving its exact two-byte row-local winners; per (row, k) the first piece that
+    reaches the row's extreme keeps its winner, every other piece says "no winner" (0xffff) — ties go to the
+    earlier edge, as everywhere.  Returns int16[P, K]: what the pass over the CSC view reads for the entries of
+    those rows (`_huge_backward_plan` points them at their pieces).  The extra work is one more gather of the
+    entries of the rows concerned; everything else is a few launches on [P, K] arrays.  (A row whose extreme is
+    NaN gets no winner here; the int64 route would name one.)"""
+    hr = st._huge_rows()
+    v = None if value is None else ops.gather_rows(value.detach(), hr["ids"])
+    out_h, _, bytes_h = ops._spmm(reduce, hr["rowptr"], hr["col"], v, mat.detach(), want_arg=False, want_arg_bytes=2)
+    piece_row, first_piece = hr["piece_row"], hr["piece_ptr"][:-1]
+    best = ops.segment_csr(out_h, hr["piece_ptr"], reduce)  # [H, K]: the rows' extremes (== out[rows])
+    eq = out_h == best[piece_row]
+    run = torch.cumsum(eq.to(torch.int32), 0)
+    before = run[first_piece] - eq[first_piece].to(torch.int32)
+    first = eq & ((run - before[piece_row]) == 1)
+    return torch.where(first, bytes_h, torch.full_like(bytes_h, -1)).contiguous()
 
 
 def spmm_planned(st: SparseStorage, weights: Optional[torch.Tensor], mat: torch.Tensor, reduce: str = "sum",
@@ -128,7 +153,7 @@ class _SpMM(torch.autograd.Function):
                 out, arg = ops._spmm(reduce, rowptr, col, value, mat, want_arg=need and reduce in ("min", "max"), row=row,
                                      algo=algo, hot_rows=hot_rows)
             ctx.storage, ctx.reduce, ctx.half = storage, reduce, mat.dtype
-            ctx.save_for_backward(value, mat, arg, arg_bytes)
+            ctx.save_for_backward(value, mat, arg, arg_bytes, None)
             return out
         ctx.half = None
         algo = storage._spmm_algo()  # per-matrix choice, read once
@@ -141,7 +166,7 @@ class _SpMM(torch.autograd.Function):
             # resident, instead of rows that may share a few memory channels
             hot_rows = ops.gather_rows(mat.detach(), plan[0])
             col = plan[1]
-        arg = arg_bytes = None
+        arg = arg_bytes = piece_bytes = None
         if reduce in ("min", "max"):
             # What the backward will read decides what the forward stores.  The
             # int64 arg_out is two thirds of the forward's output traffic (2 GB of
@@ -155,23 +180,29 @@ class _SpMM(torch.autograd.Function):
             need_mat = track and ctx.needs_input_grad[1]
             csc_bw = need_mat and ops.minmax_bw_csc_supported(mat.shape[1])
             longest = storage._longest_row() if csc_bw else 0
-            width = 2 if ops.ARG_BYTES_EXACT_ROW < longest <= ops.ARG_WORDS_EXACT_ROW else 1
-            bytes_only = csc_bw and longest <= ops.ARG_WORDS_EXACT_ROW
+            # rows above 65 535 entries (hubs of a large power-law graph): the two-byte form stays the whole answer
+            # when those rows are cut into pieces that each keep an exact one (_huge_piece_winners)
+            huge = (HUGE_ROW_PIECES and csc_bw and longest > ops.ARG_WORDS_EXACT_ROW
+                    and storage._sparse_sizes[0] + 2 * HUGE_IDS < (1 << 31))
+            width = 2 if (ops.ARG_BYTES_EXACT_ROW < longest <= ops.ARG_WORDS_EXACT_ROW or huge) else 1
+            bytes_only = csc_bw and (longest <= ops.ARG_WORDS_EXACT_ROW or huge)
             want_arg = (need_value or need_mat) and not bytes_only
             res = ops._spmm(reduce, rowptr, col, value, mat, want_arg_bytes=width if csc_bw else False,
                             want_arg=want_arg, row=row, algo=algo, hot_rows=hot_rows,
                             no_long_rows=storage._longest_row() <= ops.LONG_ROW)
             out, arg, arg_bytes = res if csc_bw else (*res, None)
+            if huge:
+                piece_bytes = _huge_piece_winners(storage, reduce, value, mat)
         else:
             out = ops._spmm(reduce, rowptr, col, value, mat, row=row, algo=algo, hot_rows=hot_rows,
                             no_long_rows=storage._longest_row() <= ops.LONG_ROW)[0]
         ctx.storage, ctx.reduce = storage, reduce
-        ctx.save_for_backward(value, mat, arg, arg_bytes)
+        ctx.save_for_backward(value, mat, arg, arg_bytes, piece_bytes)
         return out
 
     @staticmethod
     def backward(ctx, grad_out: torch.Tensor):
-        value, mat, arg, arg_bytes = ctx.saved_tensors
+        value, mat, arg, arg_bytes, piece_bytes = ctx.saved_tensors
         st, reduce = ctx.storage, ctx.reduce
         need_value = value is not None and ctx.needs_input_grad[0]
         need_mat = ctx.needs_input_grad[1]
@@ -187,10 +218,10 @@ class _SpMM(torch.autograd.Function):
                 w = _csc_weights(st, None if value is None else value.detach().float(), csr2csc, st._row_in_csc_order(), mean)
             return None, _spmm_sum_planned(st._csc_view(), w, grad_out), None, None, None
         if (ctx.half is not None and reduce in ("sum", "mean") and need_value and need_mat and grad_out.dtype == ctx.half
-                and ops.half_sum_bw_csc_supported(grad_out.shape[1]) and st._csc_view()._spmm_algo() == "row_waves"):
+                and ops.half_sum_bw_csc_supported(grad_out.shape[1])):
             # trained values, half-width operands: both gradients in one pass over the CSC view that gathers
             # 2-byte rows of grad_out and keeps fp32 sums — no fp32 copies of mat / grad_out (one wave per
-            # column: matrices whose transpose takes the row-wave family; power-law ones widen as before)
+            # column, columns above 128 entries — hub rows of a power-law matrix — in chunks of 128)
             csr2csc = st.csr2csc()
             v32 = value.detach().float()
             mean = reduce == "mean"
@@ -202,7 +233,8 @@ class _SpMM(torch.autograd.Function):
             if w is None:
                 w = ops.transpose_weights(v32, csr2csc, None, None, False)
             scale = (1.0 / st.rowcount().clamp(min=1).to(torch.float32)) if mean and not folded else None
-            gv, gm = ops.spmm_half_sum_bw_csc(st.colptr(), st._row_in_csc_order(), w, mat, grad_out, True, row_scale=scale)
+            gv, gm = ops.spmm_half_sum_bw_csc(st.colptr(), st._row_in_csc_order(), w, mat, grad_out, True, row_scale=scale,
+                                              long_columns=st._csc_view()._longest_row() > ops.LONG_ROW)
             gv = ops.permute_apply(gv, back) if back is not None else ops.gather_rows(gv, st.csc2csr())
             if folded:
                 gv = gv * st._mean_scale_per_entry()
@@ -217,7 +249,8 @@ class _SpMM(torch.autograd.Function):
             if value is not None:  # value[csr2csc]: the planned route when the storage has one (one request), else the gather
                 w = _csc_weights(st, value.detach().float(), csr2csc, st._row_in_csc_order(), False)
             gv, gm = ops.spmm_half_minmax_bw_csc(st.colptr(), st._row_in_csc_order(), st._csc_edge_tags(width), w, mat,
-                                                 grad_out, arg_bytes, want_value=need_value)
+                                                 grad_out, arg_bytes, want_value=need_value,
+                                                 long_columns=st._csc_view()._longest_row() > ops.LONG_ROW)
             if gv is not None:
                 plan = st._permute_plan("to_csr")
                 gv = (ops.permute_apply(gv, plan) if plan is not None else ops.gather_rows(gv, st.csc2csr())).to(value.dtype)
@@ -227,11 +260,11 @@ class _SpMM(torch.autograd.Function):
                                           grad_out.float(), arg, None, need_value, need_mat)
             return (None if gv is None else gv.to(value.dtype), None if gm is None else gm.to(ctx.half),
                     None, None, None)
-        gv, gm = _SpMM._backward_fp32(st, reduce, value, mat, grad_out, arg, arg_bytes, need_value, need_mat)
+        gv, gm = _SpMM._backward_fp32(st, reduce, value, mat, grad_out, arg, arg_bytes, need_value, need_mat, piece_bytes)
         return gv, gm, None, None, None
 
     @staticmethod
-    def _backward_fp32(st, reduce, value, mat, grad_out, arg, arg_bytes, need_value, need_mat):
+    def _backward_fp32(st, reduce, value, mat, grad_out, arg, arg_bytes, need_value, need_mat, piece_bytes=None):
         grad_value = grad_mat = None
         if reduce in ("min", "max"):
             # With grad_mat wanted and a K tile the kernel takes, both gradients
@@ -242,6 +275,19 @@ class _SpMM(torch.autograd.Function):
                 csr2csc = st.csr2csc()  # first: it leaves colptr and row[csr2csc] behind
                 width = arg_bytes.element_size() if arg_bytes is not None else 1
                 view = st._csc_view()
+                if piece_bytes is not None:
+                    # rows above 65 535 entries: their CSC entries go to the pieces' rows of the compact copies
+                    # (behind the view's own hub rows), tagged with their position inside the piece
+                    ids_ext, row_ext, tags_ext, _ = st._huge_backward_plan()
+                    if not need_value and view._spmm_algo() == "edge_ranges":
+                        w = None if value is None else _csc_weights(st, value, csr2csc, st._row_in_csc_order(), False)
+                        return None, ops.spmm_minmax_bw_eb(st.colptr(), view.row(), row_ext, tags_ext, w, grad_out, arg_bytes,
+                                                           hot_ids=ids_ext, hot_bytes_tail=piece_bytes)
+                    return ops.spmm_minmax_bw_csc(
+                        st.rowptr(), st.colptr(), row_ext, csr2csc, tags_ext, value, mat, grad_out, None,
+                        want_value=need_value, csc2csr=st.csc2csr() if need_value else None, arg_bytes=arg_bytes,
+                        hot_ids=ids_ext, to_csr_plan=st._permute_plan("to_csr") if need_value else None,
+                        value_csc=_streamed_values(st, value), hot_bytes_tail=piece_bytes)
                 if not need_value and arg is None and arg_bytes is not None and view._spmm_algo() == "edge_ranges":
                     # fixed adjacency on a power-law matrix: the edge-range kernels over the CSC view, masked by
                     # the row-local arg_out (two gathers per entry), hub rows from compact copies

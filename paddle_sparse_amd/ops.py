@@ -931,14 +931,17 @@ def minmax_bw_csc_supported(K: int) -> bool:
 def spmm_minmax_bw_csc(rowptr, colptr, row_csc, csr2csc, tag, value, mat, grad, arg_out,
                        want_value: bool = True, csc2csr: Optional[torch.Tensor] = None,
                        arg_bytes: Optional[torch.Tensor] = None, hot_ids: Optional[torch.Tensor] = None,
-                       to_csr_plan: Optional["PermutePlan"] = None, value_csc: Optional[torch.Tensor] = None):
+                       to_csr_plan: Optional["PermutePlan"] = None, value_csc: Optional[torch.Tensor] = None,
+                       hot_bytes_tail: Optional[torch.Tensor] = None):
     """Backward of spmm_min / spmm_max in one pass over the CSC view, no atomics
     (see include/paddle_sparse_hip.h).  Returns (grad_value f32[nnz] | None,
     grad_mat f32[N, K]); grad_value is in CSR order (the pass writes it in CSC
     order, `csc2csr` — computed here when not given — brings it back).
     tag / arg_bytes: uint8 (one byte per entry) or int16 (two).  hot_ids: int64[h]
     rows of grad / arg_bytes that row_csc refers to as M + position (compact copies
-    of them are gathered here; needs arg_bytes exact, arg_out None)."""
+    of them are gathered here; needs arg_bytes exact, arg_out None).  hot_bytes_tail: int16[t, K], the
+    row-local winners of the LAST t rows hot_ids names, given instead of gathered (the pieces of rows above
+    65 535 entries, SparseStorage._huge_backward_plan)."""
     rowptr, colptr = _index(rowptr, "rowptr"), _index(colptr, "colptr")
     row_csc, csr2csc = _index(row_csc, "row_csc"), _index(csr2csc, "csr2csc")
     grad = _f32(grad, "grad")
@@ -972,7 +975,7 @@ def spmm_minmax_bw_csc(rowptr, colptr, row_csc, csr2csc, tag, value, mat, grad, 
             raise ValueError("hot_ids need an exact arg_bytes in the two-byte form and no arg_out")
         hot_ids = _index(hot_ids, "hot_ids")
         num_hot = hot_ids.numel()
-        hot_grad, hot_bytes = _gather_rows_raw(grad, hot_ids), _gather_rows_raw(arg_bytes, hot_ids)
+        hot_grad, hot_bytes = _gather_rows_raw(grad, hot_ids), _hot_bytes(arg_bytes, hot_ids, hot_bytes_tail)
     gv = None
     if want_value:
         mat = _f32(mat, "mat")
@@ -996,7 +999,24 @@ def spmm_minmax_bw_csc(rowptr, colptr, row_csc, csr2csc, tag, value, mat, grad, 
     return gv, gm
 
 
-def spmm_minmax_bw_eb(colptr, col_csc, row_csc, tag, weight_csc, grad, arg_bytes, hot_ids=None) -> torch.Tensor:
+def _hot_bytes(arg_bytes: torch.Tensor, hot_ids: torch.Tensor, tail: Optional[torch.Tensor]) -> torch.Tensor:
+    """Compact copy of the rows `hot_ids` of arg_bytes; the last len(tail) rows are `tail` itself."""
+    if tail is None or tail.shape[0] == 0:
+        return _gather_rows_raw(arg_bytes, hot_ids)
+    _gpu(tail, "hot_bytes_tail")
+    t = tail.shape[0]
+    if tail.dtype != arg_bytes.dtype or tail.dim() != 2 or tail.shape[1] != arg_bytes.shape[1] or t > hot_ids.numel():
+        raise ValueError("hot_bytes_tail must be [t <= len(hot_ids), K] of arg_bytes' dtype")
+    out = torch.empty((hot_ids.numel(), arg_bytes.shape[1]), dtype=arg_bytes.dtype, device=arg_bytes.device)
+    head = hot_ids.numel() - t
+    if head:
+        out[:head] = _gather_rows_raw(arg_bytes, hot_ids[:head])
+    out[head:] = tail
+    return out
+
+
+def spmm_minmax_bw_eb(colptr, col_csc, row_csc, tag, weight_csc, grad, arg_bytes, hot_ids=None,
+                      hot_bytes_tail: Optional[torch.Tensor] = None) -> torch.Tensor:
     """grad_mat f32[N, K] of spmm_min / spmm_max for a fixed adjacency, by the edge-range kernels over
     the CSC view (psa_spmm_minmax_bw_eb): power-law matrices.  col_csc: column of every CSC-ordered
     entry or None; tag / arg_bytes: uint8 or int16 (exact form); weight_csc: value[csr2csc] or None;
@@ -1018,7 +1038,7 @@ def spmm_minmax_bw_eb(colptr, col_csc, row_csc, tag, weight_csc, grad, arg_bytes
     if hot_ids is not None and hot_ids.numel():
         hot_ids = _index(hot_ids, "hot_ids")
         num_hot = hot_ids.numel()
-        hot_grad, hot_bytes = _gather_rows_raw(grad, hot_ids), _gather_rows_raw(arg_bytes, hot_ids)
+        hot_grad, hot_bytes = _gather_rows_raw(grad, hot_ids), _hot_bytes(arg_bytes, hot_ids, hot_bytes_tail)
     gm = torch.empty((N, K), dtype=torch.float32, device=grad.device)
     lib = _lib.load()
     ws = _workspace(lib.psa_spmm_minmax_bw_eb_workspace_bytes(K, nnz), grad.device)
@@ -1084,12 +1104,21 @@ def half_sum_bw_csc_supported(K: int) -> bool:
     return K % 8 == 0 and 0 < K <= 512
 
 
+def _half_long_workspace(K: int, nnz: int, device, long_columns: bool):
+    """Scratch of the long-column path of the half-width passes over the CSC view (chunk list + fp32 partials)."""
+    if not long_columns:
+        return None
+    nbytes = _lib.load().psa_spmm_half_bw_csc_workspace_bytes(K, nnz)
+    return _workspace(nbytes, device) if nbytes else None
+
+
 def spmm_half_sum_bw_csc(colptr, row_csc, weight_csc, mat, grad, want_value: bool = True,
-                         row_scale: Optional[torch.Tensor] = None):
+                         row_scale: Optional[torch.Tensor] = None, long_columns: bool = True):
     """sum / mean backward over the CSC view with fp16 / bf16 dense operands (psa_spmm_half_sum_bw_csc):
     returns (grad_value f32[nnz] IN CSC ORDER | None, grad_mat [N, K] in grad's dtype).  weight_csc:
     f32[nnz] = value[csr2csc] or None; row_scale f32[M] (mean) or None.  The caller brings
-    grad_value to CSR order (SparseStorage._permute_plan("to_csr") / csc2csr)."""
+    grad_value to CSR order (SparseStorage._permute_plan("to_csr") / csc2csr).  long_columns=False: the caller
+    knows that no column has more than 128 entries (the view's _longest_row()) and saves the two near-empty launches."""
     colptr, row_csc = _index(colptr, "colptr"), _index(row_csc, "row_csc")
     _gpu(grad, "grad")
     if grad.dtype not in (torch.float16, torch.bfloat16) or grad.dim() != 2:
@@ -1110,14 +1139,17 @@ def spmm_half_sum_bw_csc(colptr, row_csc, weight_csc, mat, grad, want_value: boo
         mat = mat.contiguous()
         gv = torch.empty(nnz, dtype=torch.float32, device=grad.device)
     gm = torch.empty((N, K), dtype=grad.dtype, device=grad.device)
+    ws = _half_long_workspace(K, nnz, grad.device, long_columns)
     with _on(grad.device):
         check(_lib.load().psa_spmm_half_sum_bw_csc(_DTYPE_ID[grad.dtype], _ptr(colptr), _ptr(row_csc), _ptr(weight_csc),
                                                    _ptr(row_scale), _ptr(mat) if want_value else None, _ptr(grad), M, N, K,
-                                                   nnz, _ptr(gv), _ptr(gm), _stream()))
+                                                   nnz, _ptr(gv), _ptr(gm), _ptr(ws), ws.numel() if ws is not None else 0,
+                                                   _stream()))
     return gv, gm
 
 
-def spmm_half_minmax_bw_csc(colptr, row_csc, tag, weight_csc, mat, grad, arg_bytes, want_value: bool = True):
+def spmm_half_minmax_bw_csc(colptr, row_csc, tag, weight_csc, mat, grad, arg_bytes, want_value: bool = True,
+                            long_columns: bool = True):
     """min / max backward over the CSC view with fp16 / bf16 dense operands (psa_spmm_half_minmax_bw_csc):
     returns (grad_value f32[nnz] IN CSC ORDER | None, grad_mat [N, K] in grad's dtype).  tag / arg_bytes:
     uint8 or int16, the exact row-local forms (ops.csc_edge_tags / the third result of ops._spmm)."""
@@ -1142,11 +1174,12 @@ def spmm_half_minmax_bw_csc(colptr, row_csc, tag, weight_csc, mat, grad, arg_byt
         mat = mat.contiguous()
         gv = torch.empty(nnz, dtype=torch.float32, device=grad.device)
     gm = torch.empty((N, K), dtype=grad.dtype, device=grad.device)
+    ws = _half_long_workspace(K, nnz, grad.device, long_columns)
     with _on(grad.device):
         check(_lib.load().psa_spmm_half_minmax_bw_csc(_DTYPE_ID[grad.dtype], _ptr(colptr), _ptr(row_csc), _ptr(tag),
                                                       _ptr(weight_csc), _ptr(mat) if want_value else None, _ptr(grad),
                                                       _ptr(arg_bytes), tag.element_size(), M, N, K, nnz, _ptr(gv), _ptr(gm),
-                                                      _stream()))
+                                                      _ptr(ws), ws.numel() if ws is not None else 0, _stream()))
     return gv, gm
 
 

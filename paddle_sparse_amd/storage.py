@@ -416,6 +416,72 @@ class SparseStorage(object):
                     self._hot_memo = (hot, torch.where(s >= 0, s + N, self._col).contiguous())
         return self._hot_memo or None
 
+    def _huge_rows(self):
+        """Rows above ops.ARG_WORDS_EXACT_ROW (65 535) entries, cut into PIECES of at most that many — the form in
+        which the min / max training step keeps the row-local arg_out exact on such rows without an int64 arg_out
+        (matmul.py): every piece is a row of a small CSR matrix of its own (`rowptr`, `col`, entry ids `ids` into this
+        storage's arrays), reduced beside the main product; the piece that wins a (row, k) keeps its two-byte
+        winner, the others say "no winner".  None when no row is that long.  Structure only, memoised.
+        Fields: rows int64[H] (ids, ascending), start int64[H] (rowptr of each), piece_ptr int64[H + 1] (pieces of
+        each), piece_row int64[P] (position in `rows` of each piece), rowptr int64[P + 1], col int64[E], ids
+        int64[E]."""
+        memo = getattr(self, "_huge_memo", None)
+        if memo is None:
+            memo = False
+            if self._longest_row() > ops.ARG_WORDS_EXACT_ROW:
+                cut = ops.ARG_WORDS_EXACT_ROW
+                count, rowptr = self.rowcount(), self.rowptr()
+                rows = torch.nonzero(count > cut).flatten()
+                deg, start = count[rows], rowptr[rows]
+                dev = rows.device
+                H = rows.numel()
+                per = (deg + cut - 1) // cut
+                piece_ptr = torch.zeros(H + 1, dtype=torch.int64, device=dev)
+                piece_ptr[1:] = torch.cumsum(per, 0)
+                P = int(piece_ptr[-1].item())
+                piece_row = torch.repeat_interleave(torch.arange(H, device=dev), per, output_size=P)
+                piece_k = torch.arange(P, device=dev) - piece_ptr[piece_row]
+                piece_len = torch.clamp(deg[piece_row] - piece_k * cut, max=cut)
+                rp = torch.zeros(P + 1, dtype=torch.int64, device=dev)
+                rp[1:] = torch.cumsum(piece_len, 0)
+                E = int(rp[-1].item())
+                ent_slot = torch.repeat_interleave(torch.arange(H, device=dev), deg, output_size=E)
+                first = torch.cumsum(deg, 0) - deg
+                ids = (start[ent_slot] + (torch.arange(E, device=dev) - first[ent_slot])).contiguous()
+                memo = dict(rows=rows, start=start, piece_ptr=piece_ptr, piece_row=piece_row, rowptr=rp,
+                            col=ops.gather_rows(self._col, ids), ids=ids)
+            self._huge_memo = memo
+        return memo or None
+
+    def _huge_backward_plan(self):
+        """The pass over the CSC view for a matrix with rows above 65 535 entries (`_huge_rows`): every CSC entry
+        of such a row is pointed at its PIECE — a row of the compact copies the pass already reads hub rows from
+        (ids >= M name rows of `hot_grad` / `hot_bytes`; the pieces follow the view's own hub rows there) — and
+        tagged with its position inside the piece.  Returns (hot_ids int64[h + P]: the rows of grad_out to copy,
+        row_csc int64[nnz], tags int16[nnz], P).  Structure only, memoised."""
+        memo = getattr(self, "_huge_bw_memo", None)
+        if memo is None:
+            hr = self._huge_rows()
+            M = self._sparse_sizes[0]
+            cut = ops.ARG_WORDS_EXACT_ROW
+            base = self._csc_view()._hot_columns()
+            hot_ids = base[0] if base is not None else torch.empty(0, dtype=torch.int64, device=self._col.device)
+            row_true = self._row_in_csc_order()
+            row_eff = (base[1] if base is not None else row_true).clone()
+            tags = self._csc_edge_tags(2).clone()
+            slot_of_row = torch.full((M,), -1, dtype=torch.int64, device=row_true.device)
+            slot_of_row[hr["rows"]] = torch.arange(hr["rows"].numel(), device=row_true.device)
+            slot = ops.gather_rows(slot_of_row, row_true)
+            j = torch.nonzero(slot >= 0).flatten()  # CSC positions of the entries of huge rows
+            sj = slot[j]
+            local = self.csr2csc()[j] - hr["start"][sj]
+            row_eff[j] = M + hot_ids.numel() + hr["piece_ptr"][sj] + torch.div(local, cut, rounding_mode="floor")
+            within = local % cut  # 0 .. 65 534, stored as the two-byte pattern
+            tags[j] = torch.where(within >= 32768, within - 65536, within).to(torch.int16)
+            ids_ext = torch.cat([hot_ids, hr["rows"][hr["piece_row"]]]).contiguous()
+            memo = self._huge_bw_memo = (ids_ext, row_eff.contiguous(), tags.contiguous(), int(hr["piece_row"].numel()))
+        return memo
+
     def _spmm_algo(self) -> str:
         """Which SpMM forward suits this row structure (memoised; one 32-byte host
         read per matrix): "edge_ranges" once rows with at most two entries — the
@@ -486,6 +552,7 @@ class SparseStorage(object):
         self._csc_view_memo = None
         self._perm_plans = {}
         self._mean_scale_memo = None
+        self._huge_memo = self._huge_bw_memo = None
         return self
 
     def cached_keys(self) -> List[str]:
@@ -509,6 +576,7 @@ class SparseStorage(object):
             out._csc_view_memo = self._csc_view_memo
             out._perm_plans = self._perm_plans
             out._mean_scale_memo = getattr(self, "_mean_scale_memo", None)
+            out._huge_memo, out._huge_bw_memo = getattr(self, "_huge_memo", None), getattr(self, "_huge_bw_memo", None)
         return out
 
     def _map(self, fn: Callable[[torch.Tensor], torch.Tensor]):

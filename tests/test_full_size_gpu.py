@@ -242,3 +242,114 @@ def test_power_law_sum_training_step_properties(rmat, reduce):
         want = (ww[:, None] * rmat["G"][rr].double()).sum(0)
         mag = (ww.abs()[:, None] * rmat["G"][rr].double().abs()).sum(0)
         assert bool(((Bt.grad[c].double() - want).abs() <= 1e-5 * mag + 1e-30).all()), c
+
+
+# ---- BASELINE config 4 WHOLE on one GPU: 16 M x 16 M, 160 M entries, F = 256 (about 52 GB of HBM) ----
+
+def test_config4_whole_matrix_through_the_sharding_functions():
+    """The one matrix of BASELINE config 4 assembled on ONE MI355X and pushed through exactly what the 8 ranks of the
+    real job run: `partition_rows_by_nnz(rowptr, 8)` -> per block `shard_csr` + the block's planned local kernel
+    (`RowShard.storage()` + `spmm_planned`) into out[r0:r1].  The blocks together must give, bit for bit, the
+    unsharded `ops.spmm_sum`; a row sample is recomputed in float64; the nnz shares differ by under 1 %.  (What a
+    multi-GPU run adds to this is the exchange of B only — covered by the gloo tests and the RCCL world-1 test.)"""
+    from paddle_sparse_amd import ops
+    from paddle_sparse_amd.distributed import partition_rows_by_nnz, shard_csr
+    from paddle_sparse_amd.matmul import spmm_planned
+
+    Mg = Ng = 16_000_000
+    nnz, F, world = 160_000_000, 256, 8
+    g = torch.Generator(device="cuda").manual_seed(3)
+    row = torch.sort(torch.randint(0, Mg, (nnz,), generator=g, device="cuda"))[0]
+    rowptr = ops.ind2ptr(row, Mg)
+    del row
+    col = torch.randint(0, Ng, (nnz,), generator=g, device="cuda")
+    val = torch.randn(nnz, generator=g, device="cuda")
+    B = torch.randn(Ng, F, generator=g, device="cuda")
+    bounds = partition_rows_by_nnz(rowptr, world)
+    assert bounds[0] == 0 and bounds[-1] == Mg and len(bounds) == world + 1
+    shares = [int(rowptr[bounds[r + 1]] - rowptr[bounds[r]]) for r in range(world)]
+    assert sum(shares) == nnz and max(shares) - min(shares) <= 0.01 * (nnz / world)
+
+    out = torch.empty(Mg, F, device="cuda")
+    for r in range(world):
+        shard = shard_csr(rowptr, col, val, Ng, bounds, r)
+        assert shard.num_rows == bounds[r + 1] - bounds[r] and shard.nnz == shares[r]
+        spmm_planned(shard.storage(), shard.value, B, "sum", out=out[bounds[r]:bounds[r + 1]])
+        del shard
+    whole = ops.spmm_sum(rowptr, col, val, B)
+    assert torch.equal(out, whole)
+    del out
+    # float64 on a row sample: first / last rows of every block and random rows
+    edge_rows = torch.tensor([b for r in range(world) for b in (bounds[r], bounds[r + 1] - 1)], device="cuda")
+    rows = torch.unique(torch.cat([edge_rows, torch.randint(0, Mg, (4000,), generator=g, device="cuda")]))
+    lo, hi = rowptr[rows], rowptr[rows + 1]
+    deg = hi - lo
+    e = torch.repeat_interleave(lo, deg) + (torch.arange(int(deg.sum()), device="cuda")
+                                            - torch.repeat_interleave(torch.cumsum(deg, 0) - deg, deg))
+    slot = torch.repeat_interleave(torch.arange(rows.numel(), device="cuda"), deg)
+    terms = val[e, None].double() * B[col[e]].double()
+    ref = torch.zeros(rows.numel(), F, dtype=torch.float64, device="cuda").index_add_(0, slot, terms)
+    mag = torch.zeros(rows.numel(), F, dtype=torch.float64, device="cuda").index_add_(0, slot, terms.abs())
+    assert bool(((whole[rows].double() - ref).abs() <= 1e-5 * mag + 1e-30).all())
+
+
+# ---- R-MAT scale 24 (BASELINE config 5's graph): rows of up to ~140 k entries ----
+
+@pytest.mark.parametrize("reduce", ["max"])
+def test_rmat24_minmax_training_step_takes_the_bytes_only_route(reduce):
+    """R-MAT scale 24, 100 M generated entries (the graph of BASELINE config 5), F = 128: its hub rows exceed the
+    65 535 entries the two-byte row-local arg_out can name, and the training step still allocates no int64 arg_out
+    (they are reduced once more in pieces, matmul._huge_piece_winners) — with the bits of the int64 route."""
+    import sys
+
+    from paddle_sparse_amd import SparseTensor, coalesce, ops
+
+    mm_mod = sys.modules["paddle_sparse_amd.matmul"]
+    scale, n = 24, 100_000_000
+    size = 1 << scale
+    g = torch.Generator(device="cuda").manual_seed(4)
+    row = torch.zeros(n, dtype=torch.int64, device="cuda")
+    col = torch.zeros(n, dtype=torch.int64, device="cuda")
+    for bit in range(scale):
+        r = torch.rand(n, generator=g, device="cuda")
+        row |= (r >= 0.76).to(torch.int64) << bit
+        col |= (((r >= 0.57) & (r < 0.76)) | (r >= 0.95)).to(torch.int64) << bit
+    del r
+    index, val = coalesce(torch.stack([row, col]), torch.randn(n, generator=g, device="cuda"), size, size)
+    del row, col
+    row, col = index[0].contiguous(), index[1].contiguous()
+    del index
+    rowptr = ops.ind2ptr(row, size)
+    B = torch.randn(size, K, generator=g, device="cuda")
+    G = torch.randn(size, K, generator=g, device="cuda")
+
+    seen = []
+    real = ops._spmm
+
+    def spy(*a, **k):
+        seen.append((k.get("want_arg_bytes", False), k.get("want_arg", True)))
+        return real(*a, **k)
+
+    res = []
+    for pieces in (True, False):
+        v = val.clone().requires_grad_(True)
+        Bt = B.clone().requires_grad_(True)
+        a = SparseTensor(row=row, rowptr=rowptr, col=col, value=v, sparse_sizes=(size, size), is_sorted=True, trust_data=True)
+        mm_mod.HUGE_ROW_PIECES = pieces
+        ops._spmm = spy
+        try:
+            out = a.matmul(Bt, reduce)
+            out.backward(G)
+        finally:
+            ops._spmm = real
+            mm_mod.HUGE_ROW_PIECES = True
+        if pieces:
+            assert a.storage._longest_row() > 65_535 and a.storage._huge_rows()["rows"].numel() >= 1
+            assert all(s == (2, False) for s in seen), seen
+            seen.clear()
+        else:
+            assert (1, True) in seen
+        res.append((out.detach(), Bt.grad, v.grad))
+        del a, out, v, Bt
+    for x, y in zip(*res):
+        assert torch.equal(x, y)

@@ -388,8 +388,9 @@ def test_autograd_minmax_skips_arg_out_when_the_bytes_suffice(reduce):
         seen.append((k.get("want_arg_bytes", False), k.get("want_arg", True)))
         return real(*a, **k)
 
-    # rows up to 128 entries: one byte per element; up to 65 536: two; beyond: one byte + arg_out
-    for long_deg, expect in ((100, (1, False)), (200, (2, False)), (66_000, (1, True))):
+    # rows up to 128 entries: one byte per element; up to 65 535: two; beyond: two as well — the rows concerned are
+    # reduced once more in pieces of at most 65 535 entries (matmul._huge_piece_winners: the last _spmm call seen)
+    for long_deg, expect in ((100, (1, False)), (200, (2, False)), (66_000, (2, False)), (140_000, (2, False))):
         row, rowptr, col, val = skewed_csr(700, 300, seed=long_deg, long_rows=(5,), long_deg=long_deg)
         B = torch.randn(300, 64, device="cuda")
         grads = []
@@ -397,15 +398,17 @@ def test_autograd_minmax_skips_arg_out_when_the_bytes_suffice(reduce):
             A = SparseTensor(rowptr=dev(rowptr), col=dev(col), value=dev(val).requires_grad_(True),
                              sparse_sizes=(700, 300), is_sorted=True)
             Bg = B.clone().requires_grad_(True)
-            if patched:  # reference run: force the full arg_out
+            if patched:  # reference run: force the full arg_out (and the int64 route for rows above 65 535 entries)
                 ops._spmm = lambda *a, **k: real(*a, **{**k, "want_arg": True})
+                mm_mod.HUGE_ROW_PIECES = False
             else:
                 ops._spmm = spy
             try:
                 out = mm_mod.spmm_sparse(A, Bg, reduce)
-                out.backward(torch.ones_like(out))
+                out.backward(torch.randn(out.shape, generator=torch.Generator().manual_seed(long_deg)).cuda())
             finally:
                 ops._spmm = real
+                mm_mod.HUGE_ROW_PIECES = True
             grads.append((A.storage.value().grad.clone(), Bg.grad.clone(), out.detach()))
         assert seen[-1] == expect
         for x, y in zip(*grads):
@@ -637,3 +640,80 @@ def test_tensor_surface_skips_the_long_row_launches_only_when_no_row_is_long(red
     assert seen == [long_deg <= 128]
     want = real(reduce, dev(rowptr), dev(col), dev(val), B, want_arg=False, algo="row_waves")[0]
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("reduce", ["min", "max"])
+@pytest.mark.parametrize("case", ["trained_values", "fixed_adjacency", "no_values_ties", "trained_unit_values_ties"])
+def test_rows_above_65535_entries_keep_the_bytes_only_route(reduce, case):
+    """A 200 000-entry row, a 70 000-entry row (two pieces, the second short) and one of exactly 65 535 + 65 535
+    entries among tiny rows (a power-law shape: edge-range forward, edge-range CSC view): the training step
+    allocates no int64 arg_out — the long rows are reduced once more in pieces of at most 65 535 entries whose
+    two-byte winners are exact (matmul._huge_piece_winners, SparseStorage._huge_backward_plan) — and gives, bit
+    for bit, the gradients of the int64 route.  no_values_ties: value None and a dense operand of small integers,
+    so most products tie and the winner must be the FIRST edge reaching the extreme."""
+    import sys
+
+    from paddle_sparse_amd import SparseTensor, ops
+
+    mm_mod = sys.modules["paddle_sparse_amd.matmul"]
+    rng = np.random.default_rng(11)
+    M, N, K = 3000, 200_000, 64
+    deg = rng.integers(0, 3, M)
+    deg[7], deg[1500], deg[2999], deg[40] = 200_000, 70_000, 131_070, 30_000
+    rowptr = np.concatenate([[0], np.cumsum(deg)]).astype(np.int64)
+    nnz = int(rowptr[-1])
+    col = np.minimum((rng.random(nnz) ** 4 * N).astype(np.int64), N - 1)  # most columns hold at most two entries
+    ties = case.endswith("ties")
+    val = None if case == "no_values_ties" else (np.ones(nnz, np.float32) if ties else rng.standard_normal(nnz).astype(np.float32))
+    B = rng.integers(-3, 4, (N, K)).astype(np.float32) if ties else rng.standard_normal((N, K)).astype(np.float32)
+    G = torch.randn(M, K, generator=torch.Generator().manual_seed(3)).cuda()
+    train = case.startswith("trained")
+
+    seen = []
+    real = ops._spmm
+
+    def spy(*a, **k):
+        seen.append((k.get("want_arg_bytes", False), k.get("want_arg", True)))
+        return real(*a, **k)
+
+    res = []
+    for pieces in (True, False):
+        v = None if val is None else dev(val).requires_grad_(train)
+        A = SparseTensor(rowptr=dev(rowptr), col=dev(col), value=v, sparse_sizes=(M, N), is_sorted=True)
+        Bg = dev(B).requires_grad_(True)
+        mm_mod.HUGE_ROW_PIECES = pieces
+        ops._spmm = spy
+        try:
+            out = mm_mod.spmm_sparse(A, Bg, reduce)
+            out.backward(G)
+        finally:
+            ops._spmm = real
+            mm_mod.HUGE_ROW_PIECES = True
+        if pieces:
+            st = A.storage
+            assert st._spmm_algo() == "edge_ranges" and st._csc_view()._spmm_algo() == "edge_ranges"
+            hr = st._huge_rows()
+            assert hr["rows"].tolist() == [7, 1500, 2999] and hr["piece_ptr"].tolist() == [0, 4, 6, 8]
+            assert hr["rowptr"].tolist()[-1] == 200_000 + 70_000 + 131_070
+            assert all(s == (2, False) for s in seen)  # the product and the pieces: two-byte winners, no int64 arg_out
+            seen.clear()
+        else:
+            assert (1, True) in seen  # the reference run did take the int64 route
+        res.append((out.detach(), Bg.grad, None if not train else v.grad))
+    (o1, gm1, gv1), (o2, gm2, gv2) = res
+    assert torch.equal(o1, o2)
+    if not train:
+        # fixed adjacency on this shape: the edge-range kernels over the CSC view, which add a column's terms in
+        # another order than the row-wave pass of the int64 route — same terms (the same winners), fp32 rounding apart
+        terms = torch.zeros(N, K, dtype=torch.float64, device="cuda")
+        _, arg = real(reduce, dev(rowptr), dev(col), None if val is None else dev(val), dev(B))
+        live = arg < nnz
+        e = arg[live]
+        kk = torch.arange(K, device="cuda").expand_as(arg)[live]
+        w = torch.ones(e.numel(), dtype=torch.float64, device="cuda") if val is None else dev(val)[e].double()
+        terms.index_put_((dev(col)[e], kk), (w * G[live].double()).abs(), accumulate=True)
+        assert bool(((gm1.double() - gm2.double()).abs() <= 1e-6 * terms + 1e-30).all())
+    else:
+        assert torch.equal(gm1, gm2)
+    if train:
+        assert torch.equal(gv1, gv2)

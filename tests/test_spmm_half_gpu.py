@@ -384,3 +384,90 @@ def test_half_minmax_backward_stays_half_width(dtype, reduce, K, mode, long_row)
         assert v.grad.dtype == vd.dtype
         cast = eps * np.abs(gv_ref) + tiny if mode == "trained half values" else 0.0
         assert np.all(np.abs(v.grad.float().cpu().numpy() - gv_ref) <= 1e-5 * gv_S + cast + 1e-30)
+
+
+def _hub_column_matrix(M, N, seed):
+    """Random entries plus hub COLUMNS of 2 600, 700 and 129 entries and a 300-entry row: the CSC view has long columns
+    (chunks of 128 entries with a wave each, psa_spmm_half_*_bw_csc's workspace path) and a last chunk of one entry."""
+    rng = np.random.default_rng(seed)
+    row, _, col, val = random_csr(M, N, 20_000, seed=seed, sort_cols=True)
+    extra_r, extra_c = [np.full(300, 11)], [rng.choice(N, 300, replace=False)]
+    for c, n in ((5, 2600), (N - 1, 700), (N // 2, 129)):
+        extra_r.append(rng.choice(M, n, replace=False))
+        extra_c.append(np.full(n, c))
+    row = np.concatenate([row] + extra_r)
+    col = np.concatenate([col] + extra_c)
+    key = np.unique(row * N + col, return_index=True)[1]
+    row, col = row[key], col[key]
+    order = np.lexsort((col, row))
+    row, col = row[order], col[order]
+    val = rng.standard_normal(row.size).astype(np.float32)
+    return row, oracle.ind2ptr(row, M), col, val
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("reduce", ["sum", "mean", "max", "min"])
+@pytest.mark.parametrize("K", [64, 128, 512])
+def test_half_backward_with_hub_columns_stays_half_width(dtype, reduce, K):
+    """a transpose with long columns (the hub rows / columns of a power-law graph) no longer sends the
+    half-width training step to the fp32 kernels on widened operands: columns above 128 entries of the CSC view are
+    cut into chunks with a wave each, the chunks' fp32 partials are added in chunk order and rounded once.  Both
+    gradients against the oracle on the rounded inputs, and no fp32 pass is called."""
+    from paddle_sparse_amd import SparseTensor, ops
+
+    M, N = 3000, 2500
+    row, rowptr, col, val = _hub_column_matrix(M, N, seed=K)
+    rng = np.random.default_rng(K + 1)
+    d = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()  # noqa: E731
+    Bd, Bf = rounded(rng.standard_normal((N, K)).astype(np.float32), dtype)
+    Gd, Gf = rounded(rng.standard_normal((M, K)).astype(np.float32), dtype)
+    v = d(val).requires_grad_()
+    Bt = Bd.clone().requires_grad_()
+    a = SparseTensor(row=d(row), col=d(col), value=v, sparse_sizes=(M, N), is_sorted=True)
+    assert a.storage._csc_view()._longest_row() >= 2600
+    called = []
+    names = ("spmm_sum_bw_csc", "spmm_value_bw", "spmm_minmax_bw_csc", "spmm_minmax_bw", "spmm_minmax_bw_eb")
+    real = {n: getattr(ops, n) for n in names}
+    for n in names:
+        setattr(ops, n, (lambda n_: lambda *x, **k: called.append(n_) or real[n_](*x, **k))(n))
+    try:
+        out = a.matmul(Bt, reduce)
+        out.backward(Gd)
+    finally:
+        for n in names:
+            setattr(ops, n, real[n])
+    assert called == [], called
+    eps, tiny = EPS[dtype], TINY[dtype]
+    if reduce in ("sum", "mean"):
+        gm_ref = oracle.spmm_mat_bw(reduce, row, rowptr, col, val, Gf, N)
+        gm_S = oracle.spmm_mat_bw(reduce, row, rowptr, col, np.abs(val), np.abs(Gf), N)
+        gv_ref = oracle.spmm_value_bw(reduce, row, rowptr, col, Bf, Gf)
+        gv_S = oracle.spmm_value_bw(reduce, row, rowptr, col, np.abs(Bf), np.abs(Gf))
+    else:
+        _, ref_arg = oracle.spmm(reduce, rowptr, col, val, Bf)
+        gv_ref, gm_ref = oracle.spmm_minmax_bw(col, val, Bf, Gf, ref_arg)
+        gv_S, gm_S = oracle.spmm_minmax_bw(col, np.abs(val), np.abs(Bf), np.abs(Gf), ref_arg)
+    assert np.all(np.abs(Bt.grad.float().cpu().numpy() - gm_ref) <= 1e-5 * gm_S + eps * np.abs(gm_ref) + tiny + 1e-30)
+    assert np.all(np.abs(v.grad.float().cpu().numpy() - gv_ref) <= 1e-5 * gv_S + 1e-30)
+
+
+@pytest.mark.parametrize("K", [128])
+def test_half_long_column_chunks_match_the_one_wave_walk(K):
+    """The same pass with and without the long-column workspace: grad_value is the same bits (every entry's dot is
+    computed the same way wherever it runs), grad_mat the same up to the order in which a long column's terms are added."""
+    from paddle_sparse_amd import SparseStorage, ops
+
+    M, N = 3000, 2500
+    row, rowptr, col, val = _hub_column_matrix(M, N, seed=3)
+    d = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()  # noqa: E731
+    st = SparseStorage(row=d(row), rowptr=d(rowptr), col=d(col), value=d(val), sparse_sizes=(M, N), is_sorted=True)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B = torch.randn(N, K, generator=g, device="cuda").to(torch.bfloat16)
+    G = torch.randn(M, K, generator=g, device="cuda").to(torch.bfloat16)
+    w = ops.gather_rows(st.value(), st.csr2csc())
+    gv1, gm1 = ops.spmm_half_sum_bw_csc(st.colptr(), st._row_in_csc_order(), w, B, G, True, long_columns=True)
+    gv0, gm0 = ops.spmm_half_sum_bw_csc(st.colptr(), st._row_in_csc_order(), w, B, G, True, long_columns=False)
+    assert torch.equal(gv1, gv0)
+    short = (st.colcount() <= 128)
+    assert torch.equal(gm1[short], gm0[short])
+    assert torch.allclose(gm1.float(), gm0.float(), rtol=2.0 ** -7, atol=1e-2)
