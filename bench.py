@@ -316,6 +316,21 @@ def power_law(device, F: int, reps: int):
                 step(reduce)
                 entry[f"spmm_{reduce}_fwd_bwd_trained_values_ms"] = round(event_ms(lambda: step(reduce), max(3, reps // 4)), 4)
             del t, v
+            # the same step with a bf16 dense operand: half-width forward (edge ranges), ONE half-width pass over the CSC
+            # view for both gradients with the hub rows' long columns in chunks — no fp32 copies of B / grad_out
+            vb = val.clone().requires_grad_()
+            Bb = B.to(torch.bfloat16).requires_grad_()
+            Gb = G.to(torch.bfloat16)
+            tb = SparseTensor(row=row, rowptr=rowptr, col=col, value=vb, sparse_sizes=(N, N), is_sorted=True, trust_data=True)
+
+            def half_step():
+                vb.grad = Bb.grad = None
+                tb.matmul(Bb, "sum").backward(Gb)
+
+            half_step()
+            half_step()
+            entry["spmm_sum_bf16_fwd_bwd_trained_values_ms"] = round(event_ms(half_step, max(3, reps // 4)), 4)
+            del tb, vb, Bb, Gb
             # ... and with a fixed adjacency (gradient wrt the dense operand only)
             fixed = SparseTensor(row=row, rowptr=rowptr, col=col, value=val, sparse_sizes=(N, N), is_sorted=True, trust_data=True)
 
@@ -331,7 +346,51 @@ def power_law(device, F: int, reps: int):
         entry["hot_column_copy_rows"] = 0 if a.storage._hot_columns() is None else int(a.storage._hot_columns()[0].numel())
         res["rmat21_relabelled_columns" if relabel else "rmat21_as_generated"] = entry
         del B
+    res["rmat24_as_generated"] = power_law_rmat24(device, F, max(3, reps // 2))
     return res
+
+
+def power_law_rmat24(device, F: int, reps: int):
+    """R-MAT scale 24, 100 M generated entries (the graph of BASELINE config 5): hub rows of ~140 k entries, beyond the
+    65 535 the two-byte row-local arg_out names — the min / max training step still keeps no int64 arg_out (the rows
+    concerned are reduced once more in pieces, matmul._huge_piece_winners)."""
+    from paddle_sparse_amd import SparseTensor
+
+    N, rowptr, row, col, val = rmat_graph(24, 100_000_000, device)
+    nnz = col.numel()
+    B = torch.randn(N, F, device=device)
+    G = torch.randn(N, F, device=device)
+    a = SparseTensor(row=row, rowptr=rowptr, col=col, value=val, sparse_sizes=(N, N), is_sorted=True, trust_data=True)
+    entry = {"nnz": nnz, "rows": N, "longest_row": a.storage._longest_row()}
+    hr = a.storage._huge_rows()
+    entry["rows_above_65535_entries"] = 0 if hr is None else int(hr["rows"].numel())
+    entry["entries_in_those_rows"] = 0 if hr is None else int(hr["ids"].numel())
+    with torch.no_grad():
+        for reduce in ("sum", "max"):
+            a.matmul(B, reduce)
+            entry[f"spmm_{reduce}_tensor_surface_ms"] = round(event_ms(lambda: a.matmul(B, reduce), reps), 4)
+    v = val.clone().requires_grad_()
+    Bt = B.clone().requires_grad_()
+    t = SparseTensor(row=row, rowptr=rowptr, col=col, value=v, sparse_sizes=(N, N), is_sorted=True, trust_data=True)
+
+    def step(reduce):
+        v.grad = Bt.grad = None
+        t.matmul(Bt, reduce).backward(G)
+
+    import paddle_sparse_amd.matmul  # noqa: F401  (the module; the package exports a function of the same name)
+    mm_mod = sys.modules["paddle_sparse_amd.matmul"]
+    for reduce in ("sum", "max"):
+        step(reduce)
+        step(reduce)
+        entry[f"spmm_{reduce}_fwd_bwd_trained_values_ms"] = round(event_ms(lambda: step(reduce), reps), 4)
+    mm_mod.HUGE_ROW_PIECES = False  # the route of round 3: int64 arg_out beside the one-byte form
+    try:
+        step("max")
+        entry["spmm_max_fwd_bwd_trained_values_int64_arg_out_ms"] = round(event_ms(lambda: step("max"), reps), 4)
+    finally:
+        mm_mod.HUGE_ROW_PIECES = True
+    entry["algo_chosen_by_row_stats"] = a.storage._spmm_algo()
+    return entry
 
 
 def visible_gpus() -> int:

@@ -31,13 +31,13 @@ for dtype in (torch.float32, torch.bfloat16, torch.float16):
     if dtype != torch.float32:
         st = a.storage
         w = ops.permute_apply(val, st._permute_plan("to_csc", force=True))
-        fn = lambda: ops.spmm_half_sum_bw_csc(st.colptr(), st._row_in_csc_order(), w, Bt.detach(), Gd, True)
+        fn = lambda: ops.spmm_half_sum_bw_csc(st.colptr(), st._row_in_csc_order(), w, Bt.detach(), Gd, True, long_columns=False)
         for _ in range(40):
             fn()
         ms = event_ms(fn, 20)
         nb = nnz * (8 + 4 + 2 * F + 4) + N * (8 + 4 * F)
         print(f"{str(dtype):16s} the half-width pass over the CSC view alone: {ms:7.3f} ms = {nb / ms / 1e6 / 8000:.3f} of 8 TB/s on {nb / 1e9:.2f} GB", flush=True)
-        fn2 = lambda: ops.spmm_half_sum_bw_csc(st.colptr(), st._row_in_csc_order(), w, Bt.detach(), Gd, False)
+        fn2 = lambda: ops.spmm_half_sum_bw_csc(st.colptr(), st._row_in_csc_order(), w, Bt.detach(), Gd, False, long_columns=False)
         for _ in range(40):
             fn2()
         print(f"{str(dtype):16s}   the same pass without grad_value (grad_mat only): {event_ms(fn2, 20):7.3f} ms", flush=True)
