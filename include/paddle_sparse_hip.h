@@ -187,7 +187,12 @@ int psa_spmm_coo(int reduce, const int64_t* rowptr, const int64_t* row,
  * 2 M x 2 M, 20 M entries, K = 128 moves 6.4 GB instead of 11.5 GB.
  * Needs K % 8 == 0 and 16-byte aligned mat / out (PSA_ERR_UNSUPPORTED
  * otherwise: callers widen to fp32 and use psa_spmm).  One wavefront per row,
- * rows of any length on their own wave (no long-row scratch, no workspace). */
+ * rows of any length on their own wave (no long-row scratch, no workspace).
+ * N IS A CONTRACT, not a hint: it must be the number of rows of mat and bound every
+ * column id (0 <= col[e] < N).  When N * K * 2 < 2^32 the kernels address mat with
+ * 32-bit byte offsets built from the low 32 bits of col; a stale or short N gives
+ * wrong gathers without any error (index values are never validated, as in the
+ * reference: csrc/cpu/convert_cpu.cpp:19-27). */
 int psa_spmm_half(int reduce, int dtype, const int64_t* rowptr,
                   const int64_t* col, const void* value, int value_dtype,
                   const void* mat, int64_t M, int64_t N, int64_t K, int64_t nnz,
@@ -249,7 +254,8 @@ int psa_spmm_half_sum_bw_csc(int dtype, const int64_t* colptr, const int64_t* ro
 
 /* Test/bench hook: 0 = default (one row per wave), 1 = several rows per wave for
  * K <= 128, 2 = one row per wave with 8 gather steps in flight, 3 = default
- * without the XCD mixing of the row blocks.  Returns the previous value. */
+ * without the XCD mixing of the row blocks, 4 = default with 64-bit addressing of the
+ * dense operands forced (the form operands of 4 GiB and more take).  Returns the previous value. */
 int psa_spmm_half_set_variant(int variant);
 
 /* Row-length statistics of a CSR pointer, for choosing psa_spmm_algo once per

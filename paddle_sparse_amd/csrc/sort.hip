@@ -674,9 +674,10 @@ os_pass_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict_
           continue;
         }
         if (++spins > spin_limit) {  // never expected; keeps a bug from hanging the GPU
-          // the returned value keeps the flag_incl store below behind this atomic: a tile that
-          // takes this tile's (wrong) prefix finds the fault word set
-          excl += atomicExch(err, 1u) & 0u;
+          // the fault word is set and made visible (agent scope) BEFORE the flag_incl store below: a
+          // tile that takes this tile's (wrong) prefix finds it set when it looks
+          __hip_atomic_store(err, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          __threadfence();
           s_fault = 1u;
           break;
         }

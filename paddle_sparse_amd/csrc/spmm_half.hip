@@ -782,9 +782,9 @@ extern "C" int psa_spmm_half_sum_bw_csc(int dtype, const int64_t* colptr, const 
   uint16_t* gm = static_cast<uint16_t*>(grad_mat);
   if (dtype == PSA_BF16)
     return dispatch_half_csc_bw<BF16>(colptr, row_csc, weight_csc, row_scale, m, g, gm, grad_value_csc, N, K, nnz, s, nullptr,
-                                      nullptr, M * K * 2 < (1ll << 32), workspace, workspace_bytes);
+                                      nullptr, g_half_variant != 4 && M * K * 2 < (1ll << 32), workspace, workspace_bytes);
   return dispatch_half_csc_bw<F16>(colptr, row_csc, weight_csc, row_scale, m, g, gm, grad_value_csc, N, K, nnz, s, nullptr,
-                                   nullptr, M * K * 2 < (1ll << 32), workspace, workspace_bytes);
+                                   nullptr, g_half_variant != 4 && M * K * 2 < (1ll << 32), workspace, workspace_bytes);
 }
 
 extern "C" size_t psa_spmm_half_bw_csc_workspace_bytes(int64_t K, int64_t nnz) { return half_long_bytes(K, nnz); }
@@ -798,7 +798,9 @@ extern "C" int psa_spmm_half_set_variant(int v) {
 extern "C" int psa_spmm_half_arg(int reduce, int dtype, const int64_t* rowptr, const int64_t* col, const void* value,
                                  int value_dtype, const void* mat, int64_t M, int64_t N, int64_t K, int64_t nnz,
                                  void* out, int64_t* arg_out, void* arg_bytes, int arg_width, psa_stream_t stream) {
-  const bool small = N > 0 && N * K * 2 < (1ll << 32);  // a row's byte offset fits 32 bits (N is the caller's bound on col)
+  // a row's byte offset fits 32 bits: N is the caller's bound on col AND the height of mat (only the low 32 bits of a
+  // column id are used then); variant 4 forces the 64-bit form (test hook)
+  const bool small = g_half_variant != 4 && N > 0 && N * K * 2 < (1ll << 32);
   PSA_REQUIRE(reduce >= PSA_SUM && reduce <= PSA_MAX, "bad reduce");
   PSA_REQUIRE(M >= 0 && K >= 0 && nnz >= 0, "negative size");
   if (dtype != PSA_F16 && dtype != PSA_BF16) {
@@ -865,7 +867,7 @@ extern "C" int psa_spmm_half_minmax_bw_csc(int dtype, const int64_t* colptr, con
   const uint8_t* tags = static_cast<const uint8_t*>(tag);
 #define PSA_MM(T, MW)                                                                                                  \
   return dispatch_half_csc_bw<T, MW>(colptr, row_csc, weight_csc, nullptr, m, g, gm, grad_value_csc, N, K, nnz, s, words, \
-                                     tags, M * K * 2 < (1ll << 32), workspace, workspace_bytes)
+                                     tags, g_half_variant != 4 && M * K * 2 < (1ll << 32), workspace, workspace_bytes)
   if (dtype == PSA_BF16) {
     if (arg_width == 2) PSA_MM(BF16, 2);
     PSA_MM(BF16, 1);

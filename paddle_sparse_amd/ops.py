@@ -348,6 +348,12 @@ def index_sort(keys: torch.Tensor, max_value: Optional[int] = None,
     check: read the sort's fault word afterwards (one host read, synchronises) and
     raise HipCoreError if a look-back wait gave up — for callers whose result no other
     host read follows (SparseStorage's constructor sort, csr2csc).
+    ONLY THE FAULT WORD IS AUTHORITATIVE: after a fault the outputs hold -1 where the
+    faulted tiles of the last pass sat, possibly valid-looking entries and untouched memory
+    elsewhere — the absence of -1 in a part of them proves nothing.  A caller that passes
+    check=False must read the word itself before it trusts the order: keep_scratch=True and
+    unique_sorted(after=...) (the coalesce path: the word comes back with the count, no
+    extra synchronisation) or index_sort_checked / sort_fault_word.
     """
     keys = _index(keys, "keys")
     n = keys.numel()

@@ -471,3 +471,39 @@ def test_half_long_column_chunks_match_the_one_wave_walk(K):
     short = (st.colcount() <= 128)
     assert torch.equal(gm1[short], gm0[short])
     assert torch.allclose(gm1.float(), gm0.float(), rtol=2.0 ** -7, atol=1e-2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("K", [64, 128])
+def test_half_64_bit_addressing_gives_the_bits_of_the_32_bit_form(dtype, K):
+    """operands below 4 GiB take 32-bit byte offsets (N bounds col and is mat's height — the header says
+    so); every committed test shape is that small, so the 64-bit instantiations (what a 4 GiB operand runs: config
+    4 in bf16) were never reached.  psa_spmm_half_set_variant(4) forces them: forward (sum, and max with the row-local
+    arg_out) and both passes over the CSC view (sum and masked, with grad_value, long columns in chunks) on the same
+    data must give the same bits."""
+    from paddle_sparse_amd import SparseStorage, _lib, ops
+
+    M, N = 3000, 2500
+    row, rowptr, col, val = _hub_column_matrix(M, N, seed=K + 7)
+    d = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()  # noqa: E731
+    st = SparseStorage(row=d(row), rowptr=d(rowptr), col=d(col), value=d(val), sparse_sizes=(M, N), is_sorted=True)
+    g = torch.Generator(device="cuda").manual_seed(K)
+    B = torch.randn(N, K, generator=g, device="cuda").to(dtype)
+    G = torch.randn(M, K, generator=g, device="cuda").to(dtype)
+    w = ops.gather_rows(st.value(), st.csr2csc())
+
+    def run():
+        out_sum = ops._spmm("sum", st.rowptr(), st.col(), st.value(), B)[0]
+        out_max, _, words = ops._spmm("max", st.rowptr(), st.col(), st.value(), B, want_arg=False, want_arg_bytes=2)
+        gv, gm = ops.spmm_half_sum_bw_csc(st.colptr(), st._row_in_csc_order(), w, B, G, True)
+        mv, mm = ops.spmm_half_minmax_bw_csc(st.colptr(), st._row_in_csc_order(), st._csc_edge_tags(2), w, B, G, words)
+        return out_sum, out_max, words, gv, gm, mv, mm
+
+    small = run()
+    _lib.load().psa_spmm_half_set_variant(4)
+    try:
+        wide = run()
+    finally:
+        _lib.load().psa_spmm_half_set_variant(0)
+    for a, b in zip(small, wide):
+        assert torch.equal(a, b)
