@@ -827,3 +827,5 @@ def main(argv=None) -> None:
 
 if __name__ == "__main__":
     main()
+else:  # imported (tools/, tests/perf/): the helpers above need numpy / torch; only the launcher process goes without
+    load_compute_modules()

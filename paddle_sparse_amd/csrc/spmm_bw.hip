@@ -42,8 +42,9 @@ __device__ __forceinline__ void load_vec(const float* p, float (&dst)[VEC]) {
 
 // out[e] = <mat[col[e], :], grow[:]> / denom for the edges [s, e) of ONE row
 // (grow = that row of gOut).  Called by the row wave for ordinary rows and by a
-// chunk wave for a 128-edge piece of a long row.
-template <int VEC, int LPR, int U>
+// chunk wave for a 128-edge piece of a long row.  ONE: K fits one tile of LPR * VEC floats (no tile loop, the
+// column ids are consumed where they are fetched: 72 -> 64 VGPRs at K = 128, 8 waves per SIMD).
+template <int VEC, int LPR, int U, bool ONE>
 __device__ __forceinline__ void value_bw_range(const int64_t* __restrict__ col,
                                                const float* __restrict__ mat,
                                                const float* __restrict__ grow,
@@ -54,12 +55,13 @@ __device__ __forceinline__ void value_bw_range(const int64_t* __restrict__ col,
   static_assert(64 % (G * U) == 0, "edge batch must divide the wave");
   const int g = lane / LPR;
   const int l = lane % LPR;
-  const int64_t ntiles = (K + TILE - 1) / TILE;
+  const int64_t ntiles = ONE ? 1 : (K + TILE - 1) / TILE;
+  const bool kact0 = l * VEC < K;
 
   float gr[VEC];
 #pragma unroll
   for (int i = 0; i < VEC; ++i) gr[i] = 0.f;
-  if (l * VEC < K) load_vec<VEC>(grow + l * VEC, gr);  // tile 0 stays in registers
+  if (kact0) load_vec<VEC>(grow + l * VEC, gr);  // tile 0 stays in registers
 
   for (int64_t base = s; base < e; base += 64) {
     const int n = (e - base) < 64 ? static_cast<int>(e - base) : 64;
@@ -68,37 +70,55 @@ __device__ __forceinline__ void value_bw_range(const int64_t* __restrict__ col,
     if (lane < n) c_l = col[base + lane];
     for (int j = 0; j < n; j += G * U) {
       float dot[U];
-      int64_t c[U];
-      bool ok[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int idx = j + u * G + g;
-        c[u] = __shfl(static_cast<long long>(c_l), idx);
-        ok[u] = idx < n;
-        dot[u] = 0.f;
-      }
-      for (int64_t t = 0; t < ntiles; ++t) {
-        const int64_t k0 = t * TILE + l * VEC;
-        const bool kact = k0 < K;
-        float gt[VEC];
-#pragma unroll
-        for (int i = 0; i < VEC; ++i) gt[i] = gr[i];
-        if (t > 0) {
-#pragma unroll
-          for (int i = 0; i < VEC; ++i) gt[i] = 0.f;
-          if (kact) load_vec<VEC>(grow + k0, gt);
-        }
+      if constexpr (ONE) {
         float b[U][VEC];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+          const int idx = j + u * G + g;
+          const int64_t c = __shfl(static_cast<long long>(c_l), idx);
 #pragma unroll
           for (int i = 0; i < VEC; ++i) b[u][i] = 0.f;
-          if (ok[u] && kact) load_vec<VEC>(mat + c[u] * K + k0, b[u]);
+          if (idx < n && kact0) load_vec<VEC>(mat + c * K + l * VEC, b[u]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+          dot[u] = 0.f;
 #pragma unroll
-          for (int i = 0; i < VEC; ++i) dot[u] += b[u][i] * gt[i];
+          for (int i = 0; i < VEC; ++i) dot[u] += b[u][i] * gr[i];
+        }
+      } else {
+        int64_t c[U];
+        bool ok[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int idx = j + u * G + g;
+          c[u] = __shfl(static_cast<long long>(c_l), idx);
+          ok[u] = idx < n;
+          dot[u] = 0.f;
+        }
+        for (int64_t t = 0; t < ntiles; ++t) {
+          const int64_t k0 = t * TILE + l * VEC;
+          const bool kact = k0 < K;
+          float gt[VEC];
+#pragma unroll
+          for (int i = 0; i < VEC; ++i) gt[i] = gr[i];
+          if (t > 0) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) gt[i] = 0.f;
+            if (kact) load_vec<VEC>(grow + k0, gt);
+          }
+          float b[U][VEC];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) b[u][i] = 0.f;
+            if (ok[u] && kact) load_vec<VEC>(mat + c[u] * K + k0, b[u]);
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) dot[u] += b[u][i] * gt[i];
+          }
         }
       }
       // Fold the U partial dots of this lane group together (lane_fold.h: DPP / permlane moves in the
@@ -115,7 +135,7 @@ __device__ __forceinline__ void value_bw_range(const int64_t* __restrict__ col,
   }
 }
 
-template <int VEC, int LPR, int U>
+template <int VEC, int LPR, int U, bool ONE>
 __global__ void __launch_bounds__(kThreads)
 spmm_value_bw_kernel(const int64_t* __restrict__ rowptr,
                      const int64_t* __restrict__ col,
@@ -135,12 +155,12 @@ spmm_value_bw_kernel(const int64_t* __restrict__ rowptr,
     return;
   }
   const float denom = (mean && e - s > 1) ? static_cast<float>(e - s) : 1.0f;
-  value_bw_range<VEC, LPR, U>(col, mat, grad + row * K, out, K, s, e, denom, lane);
+  value_bw_range<VEC, LPR, U, ONE>(col, mat, grad + row * K, out, K, s, e, denom, lane);
 }
 
 // One wave per 128-edge chunk of a long row; chunks write disjoint out[e], so
 // no combine step is needed.
-template <int VEC, int LPR, int U>
+template <int VEC, int LPR, int U, bool ONE>
 __global__ void __launch_bounds__(psa::kLongThreads)
 spmm_value_bw_long_kernel(const int64_t* __restrict__ rowptr,
                           const int64_t* __restrict__ col,
@@ -160,7 +180,7 @@ spmm_value_bw_long_kernel(const int64_t* __restrict__ rowptr,
     const int64_t s = rs + static_cast<int64_t>(c - ent.first_chunk) * psa::kLongChunk;
     const int64_t e = s + psa::kLongChunk < re ? s + psa::kLongChunk : re;
     const float denom = mean ? static_cast<float>(re - rs) : 1.0f;
-    value_bw_range<VEC, LPR, U>(col, mat, grad + ent.row * K, out, K, s, e, denom, lane);
+    value_bw_range<VEC, LPR, U, ONE>(col, mat, grad + ent.row * K, out, K, s, e, denom, lane);
   }
 }
 
@@ -268,12 +288,22 @@ int launch_value_bw(const int64_t* rowptr, const int64_t* col, const float* mat,
                     hipStream_t s) {
   const int64_t gx = psa::ceil_div(M, kWaves);
   PSA_REQUIRE(gx <= 0x7fffffff, "M too large for one launch");
-  hipLaunchKernelGGL((spmm_value_bw_kernel<VEC, LPR, U>),
-                     dim3(static_cast<unsigned>(gx)), dim3(kThreads), 0, s,
-                     rowptr, col, mat, grad, out, M, K, mean, ctr, list);
-  if (list) {
-    hipLaunchKernelGGL((spmm_value_bw_long_kernel<VEC, LPR, U>), dim3(psa::kLongBlocks),
-                       dim3(psa::kLongThreads), 0, s, rowptr, col, mat, grad, out, K, mean, ctr, list);
+  if (K <= static_cast<int64_t>(LPR) * VEC) {  // one tile
+    hipLaunchKernelGGL((spmm_value_bw_kernel<VEC, LPR, U, true>),
+                       dim3(static_cast<unsigned>(gx)), dim3(kThreads), 0, s,
+                       rowptr, col, mat, grad, out, M, K, mean, ctr, list);
+    if (list) {
+      hipLaunchKernelGGL((spmm_value_bw_long_kernel<VEC, LPR, U, true>), dim3(psa::kLongBlocks),
+                         dim3(psa::kLongThreads), 0, s, rowptr, col, mat, grad, out, K, mean, ctr, list);
+    }
+  } else {
+    hipLaunchKernelGGL((spmm_value_bw_kernel<VEC, LPR, U, false>),
+                       dim3(static_cast<unsigned>(gx)), dim3(kThreads), 0, s,
+                       rowptr, col, mat, grad, out, M, K, mean, ctr, list);
+    if (list) {
+      hipLaunchKernelGGL((spmm_value_bw_long_kernel<VEC, LPR, U, false>), dim3(psa::kLongBlocks),
+                         dim3(psa::kLongThreads), 0, s, rowptr, col, mat, grad, out, K, mean, ctr, list);
+    }
   }
   PSA_LAUNCH_CHECK();
   return PSA_OK;
