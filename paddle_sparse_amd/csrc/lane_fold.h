@@ -17,6 +17,9 @@ __device__ __forceinline__ float dpp_move(float x) {
 template <int BIT>
 __device__ __forceinline__ float lane_xor(float x) {
   static_assert(BIT == 1 || BIT == 2 || BIT == 8, "exact partners in the VALU: 1, 2, 8");
+#ifdef PSA_SHFL_FOLDS  // A/B build (python -m paddle_sparse_amd.build with PSA_EXTRA_HIPCC_FLAGS=-DPSA_SHFL_FOLDS): all through ds_bpermute
+  return __shfl_xor(x, BIT);
+#endif
   if constexpr (BIT == 1) return dpp_move<0xB1>(x);   // quad_perm [1, 0, 3, 2]
   if constexpr (BIT == 2) return dpp_move<0x4E>(x);   // quad_perm [2, 3, 0, 1]
   return dpp_move<0x128>(x);                          // row_ror:8
@@ -24,10 +27,16 @@ __device__ __forceinline__ float lane_xor(float x) {
 
 // x + x(lane ^ 16) / x + x(lane ^ 32): one swap of the 16- / 32-lane halves of two copies, then an add
 __device__ __forceinline__ float add_xor16(float x) {
+#ifdef PSA_SHFL_FOLDS
+  return x + __shfl_xor(x, 16);
+#endif
   const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float add_xor32(float x) {
+#ifdef PSA_SHFL_FOLDS
+  return x + __shfl_xor(x, 32);
+#endif
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
@@ -67,6 +76,9 @@ __device__ __forceinline__ void fold_lane_groups(float (&acc)[N]) {
 // holds one quantity (LOW == 1).  Anything else falls back to ds_bpermute.
 template <int BIT, int LPR, int LOW>
 __device__ __forceinline__ float group_sum_step(float x) {
+#ifdef PSA_SHFL_FOLDS
+  return x + __shfl_xor(x, BIT);
+#endif
   if constexpr (BIT == 1 || BIT == 2) return x + lane_xor<BIT>(x);
   else if constexpr (BIT == 4 && LPR >= 16) return x + dpp_move<0x124>(x);        // row_ror:4 (completed by BIT = 8)
   else if constexpr (BIT == 4 && LPR == 8 && LOW == 1) return x + dpp_move<0x141>(x);  // row_half_mirror
