@@ -50,7 +50,7 @@ def _compile(src: Path, force: bool, verbose: bool) -> Path:
     dep_mtime = max(src.stat().st_mtime, _newest_header_mtime())
     if not force and obj.exists() and obj.stat().st_mtime >= dep_mtime:
         return obj
-    extra = os.environ.get("PSA_EXTRA_HIPCC_FLAGS", "").split()  # A/B builds of a kernel variant (tools/fold_ab.sh)
+    extra = os.environ.get("PSA_EXTRA_HIPCC_FLAGS", "").split()  # A/B builds of a kernel variant (-D...)
     cmd = [hipcc(), *HIPCC_FLAGS, *extra, f"-I{INCLUDE}", f"-I{CSRC}", "-c", str(src),
            "-o", str(obj)]
     if verbose:

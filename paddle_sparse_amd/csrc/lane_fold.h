@@ -1,7 +1,10 @@
 // Cross-lane sums in the VALU (gfx950): DPP row operations and the v_permlane16/32_swap pair instead of
-// ds_bpermute (__shfl_xor), which occupies the LDS pipe and needs its address computed.  The SpMM backward
-// kernels fold U partial dot products per lane group and step: on ~10-entry rows they are bound by
-// instruction issue, not by bytes (profiles/r03_pmc_half.json: 34 LDS-pipe instructions per column).
+// ds_bpermute (__shfl_xor).  Used by the half-width kernels (spmm_half.hip) and spmm_value_bw, where it saved
+// registers (half-width pass over the CSC view 78 -> 70 VGPRs, 6 -> 7 waves per SIMD) and time (1.30 -> 1.23 ms
+// at config 3, 1.66 -> 1.55 ms on R-MAT 21).  NOT used by the fp32 passes of spmm.hip: with the hub rows in
+// cache-resident copies those are bound by VALU issue on power-law graphs, and moving the folds from the
+// (idle) LDS pipe into the VALU took the sum pass from 1.91 to 2.72 ms on R-MAT 21 (profiles/r04_fold_ab.txt,
+// produced at commit 0290f97 with a -DPSA_SHFL_FOLDS build).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -17,9 +20,6 @@ __device__ __forceinline__ float dpp_move(float x) {
 template <int BIT>
 __device__ __forceinline__ float lane_xor(float x) {
   static_assert(BIT == 1 || BIT == 2 || BIT == 8, "exact partners in the VALU: 1, 2, 8");
-#ifdef PSA_SHFL_FOLDS  // A/B build (python -m paddle_sparse_amd.build with PSA_EXTRA_HIPCC_FLAGS=-DPSA_SHFL_FOLDS): all through ds_bpermute
-  return __shfl_xor(x, BIT);
-#endif
   if constexpr (BIT == 1) return dpp_move<0xB1>(x);   // quad_perm [1, 0, 3, 2]
   if constexpr (BIT == 2) return dpp_move<0x4E>(x);   // quad_perm [2, 3, 0, 1]
   return dpp_move<0x128>(x);                          // row_ror:8
@@ -27,16 +27,10 @@ __device__ __forceinline__ float lane_xor(float x) {
 
 // x + x(lane ^ 16) / x + x(lane ^ 32): one swap of the 16- / 32-lane halves of two copies, then an add
 __device__ __forceinline__ float add_xor16(float x) {
-#ifdef PSA_SHFL_FOLDS
-  return x + __shfl_xor(x, 16);
-#endif
   const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float add_xor32(float x) {
-#ifdef PSA_SHFL_FOLDS
-  return x + __shfl_xor(x, 32);
-#endif
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
@@ -76,9 +70,6 @@ __device__ __forceinline__ void fold_lane_groups(float (&acc)[N]) {
 // holds one quantity (LOW == 1).  Anything else falls back to ds_bpermute.
 template <int BIT, int LPR, int LOW>
 __device__ __forceinline__ float group_sum_step(float x) {
-#ifdef PSA_SHFL_FOLDS
-  return x + __shfl_xor(x, BIT);
-#endif
   if constexpr (BIT == 1 || BIT == 2) return x + lane_xor<BIT>(x);
   else if constexpr (BIT == 4 && LPR >= 16) return x + dpp_move<0x124>(x);        // row_ror:4 (completed by BIT = 8)
   else if constexpr (BIT == 4 && LPR == 8 && LOW == 1) return x + dpp_move<0x141>(x);  // row_half_mirror

@@ -11,8 +11,6 @@
 //                          CSC-ordered weights that turn gB = A^T gOut into a
 //                          plain psa_spmm over (colptr, row[csr2csc], w').
 //   psa_spmm_minmax_bw     scatter through arg_out with float atomics.
-#include <cstdlib>
-
 #include "common.h"
 #include "lane_fold.h"
 #include "long_rows.h"
@@ -355,11 +353,9 @@ int psa_spmm_value_bw(int reduce, const int64_t* rowptr, const int64_t* col,
     if (q <= 4) PSA_VBW(4, 4, 1);
     if (q <= 8) PSA_VBW(4, 8, 1);
     if (q <= 16) PSA_VBW(4, 16, 2);
-    if (q <= 32) {
-      static const bool u8 = getenv("PSA_VBW_U8") != nullptr;  // EXPERIMENT (tools/fold_ab.sh): 16 gathers in flight per wave
-      if (u8) PSA_VBW(4, 32, 8);
-      PSA_VBW(4, 32, 4);
-    }
+    // K = 128: 16 gathers in flight per wave (the single-tile form needs 37 VGPRs at U = 4, so 8 waves per SIMD stay):
+    // 1.85 -> 1.62 ms at config 3 (profiles/r04_fold_ab.txt)
+    if (q <= 32) PSA_VBW(4, 32, 8);
     PSA_VBW(4, 64, 8);
   }
   if (K <= 4) PSA_VBW(1, 4, 1);
