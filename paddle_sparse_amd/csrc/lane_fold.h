@@ -25,18 +25,16 @@ __device__ __forceinline__ float lane_xor(float x) {
   return dpp_move<0x128>(x);                          // row_ror:8
 }
 
-// x + x(lane ^ 16) / x + x(lane ^ 32): one swap of the 16- / 32-lane halves of two copies, then an add
-__device__ __forceinline__ float add_xor16(float x) {
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-__device__ __forceinline__ float add_xor32(float x) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
+// x + x(lane ^ 16) / x + x(lane ^ 32).  Through ds_bpermute on purpose: v_permlane16/32_swap exchanges the halves of
+// TWO registers in place, so a sum costs two copies, the swap and the add — four VALU instructions where the shuffle
+// costs one (the add) plus one on the LDS pipe, which idles in these kernels while the VALU is their busiest unit
+// (profiles/r04_pmc_half.json: the permlane form took the half-width forward from 422 M to 468 M VALU instructions
+// per launch for no change in time).  DPP moves fuse into the add (v_add_f32_dpp) and stay.
+__device__ __forceinline__ float add_xor16(float x) { return x + __shfl_xor(x, 16); }
+__device__ __forceinline__ float add_xor32(float x) { return x + __shfl_xor(x, 32); }
 
 // x + x(lane ^ OFF) with the bits of x + __shfl_xor(x, OFF) (float addition commutes): the fold of the
-// 64 / LPR lane groups of a wave at the end of a row.  OFF = 8, 16, 32 stay in the VALU.
+// 64 / LPR lane groups of a wave at the end of a row.  OFF = 8 is a DPP row rotation.
 template <int OFF>
 __device__ __forceinline__ float add_xor(float x) {
   if constexpr (OFF == 8) return x + lane_xor<8>(x);

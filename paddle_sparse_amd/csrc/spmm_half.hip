@@ -124,18 +124,12 @@ spmm_half_row_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restri
       c_l = col[base + lane];
       if (val != nullptr) v_l = VAL32 ? static_cast<const float*>(val)[base + lane] : widen1<T>(val, base + lane);
     }
-    // One step = up to U slots per lane group, G * U edges per wave.  The last step of a row is issued with only
-    // the slots it has edges for (UU = 1 .. U): a slot costs its gather, eight widening operations and eight FMAs
-    // whether an edge sits in it or not, the kernel is bound by VALU issue (profiles/r03_pmc_half.json), and at
-    // ~10 entries per row a full 16-slot step leaves six slots idle.  The edges a group sees, and their order,
-    // are the same either way (the dropped slots held no edge).
-    auto step = [&](auto uu_tag, int j) {
-      constexpr int UU = decltype(uu_tag)::value;
-      uint4 raw[UU];
-      float w[UU];
-      bool ok[UU];
+    for (int j = 0; j < n; j += G * U) {
+      uint4 raw[U];
+      float w[U];
+      bool ok[U];
 #pragma unroll
-      for (int u = 0; u < UU; ++u) {
+      for (int u = 0; u < U; ++u) {
         const int idx = j + u * G + g;  // < 64
         w[u] = __shfl(v_l, idx);
         ok[u] = (idx < n) && kact;
@@ -150,7 +144,7 @@ spmm_half_row_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restri
         }
       }
 #pragma unroll
-      for (int u = 0; u < UU; ++u) {
+      for (int u = 0; u < U; ++u) {
         float b[8];
         widen8<T>(raw[u], b);
         if (RED == R_SUM) {
@@ -168,21 +162,6 @@ spmm_half_row_kernel(const int64_t* __restrict__ rowptr, const int64_t* __restri
             }
           }
         }
-      }
-    };
-    for (int j = 0; j < n; j += G * U) {
-      const int slots = (n - j + G - 1) / G;  // wave-uniform
-      if (slots >= U) {
-        step(std::integral_constant<int, U>{}, j);
-      } else if constexpr (U == 4) {
-        if (slots == 1) step(std::integral_constant<int, 1>{}, j);
-        else if (slots == 2) step(std::integral_constant<int, 2>{}, j);
-        else step(std::integral_constant<int, 3>{}, j);
-      } else if constexpr (U >= 2) {
-        if (slots <= U / 2) step(std::integral_constant<int, U / 2>{}, j);
-        else step(std::integral_constant<int, U>{}, j);
-      } else {
-        step(std::integral_constant<int, U>{}, j);
       }
     }
   }
@@ -386,16 +365,13 @@ __device__ __forceinline__ void half_csc_bw_range(const int64_t* __restrict__ ro
       if constexpr (MW == 1) t_l = tags[base + lane];
       if constexpr (MW == 2) t_l = reinterpret_cast<const uint16_t*>(tags)[base + lane];
     }
-    using Words = typename std::conditional<MW == 2, uint4, uint2>::type;  // the 8 entries of words[r, k0 ..]: 8 or 16 bytes
-    // a step with UU <= U slots in use (see spmm_half_row_kernel: the last step of a column takes only the slots it
-    // has entries for); the dots of the unused slots are 0 and fold away
-    auto step = [&](auto uu_tag, int j) {
-      constexpr int UU = decltype(uu_tag)::value;
-      uint4 raw[UU];
-      Words wd[UU];
-      bool ok[UU];
+    for (int j = 0; j < n; j += G * U) {
+      uint4 raw[U];
+      using Words = typename std::conditional<MW == 2, uint4, uint2>::type;  // the 8 entries of words[r, k0 ..]: 8 or 16 bytes
+      Words wd[U];
+      bool ok[U];
 #pragma unroll
-      for (int u = 0; u < UU; ++u) {
+      for (int u = 0; u < U; ++u) {
         const int idx = j + u * G + g;  // < 64
         ok[u] = (idx < n) && kact;
         raw[u] = make_uint4(0u, 0u, 0u, 0u);
@@ -417,9 +393,7 @@ __device__ __forceinline__ void half_csc_bw_range(const int64_t* __restrict__ ro
       }
       float dot[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) dot[u] = 0.f;
-#pragma unroll
-      for (int u = 0; u < UU; ++u) {
+      for (int u = 0; u < U; ++u) {
         const int idx = j + u * G + g;
         float w = __shfl(v_l, idx);  // fetched after the gathers are out
         if (row_scale != nullptr) w *= __shfl(s_l, idx);
@@ -457,21 +431,6 @@ __device__ __forceinline__ void half_csc_bw_range(const int64_t* __restrict__ ro
         const unsigned rel = static_cast<unsigned>(lane - j);
         const float got = __shfl(dot[0], static_cast<int>(((rel % G) * LPR + rel / G) & 63u));
         if (rel < static_cast<unsigned>(G * U)) gv_keep = got;
-      }
-    };
-    for (int j = 0; j < n; j += G * U) {
-      const int slots = (n - j + G - 1) / G;  // wave-uniform
-      if (slots >= U) {
-        step(std::integral_constant<int, U>{}, j);
-      } else if constexpr (U == 4) {
-        if (slots == 1) step(std::integral_constant<int, 1>{}, j);
-        else if (slots == 2) step(std::integral_constant<int, 2>{}, j);
-        else step(std::integral_constant<int, 3>{}, j);
-      } else if constexpr (U >= 2) {
-        if (slots <= U / 2) step(std::integral_constant<int, U / 2>{}, j);
-        else step(std::integral_constant<int, U>{}, j);
-      } else {
-        step(std::integral_constant<int, U>{}, j);
       }
     }
     if (GV && lane < n) __builtin_nontemporal_store(gv_keep * s_l, grad_value + base + lane);

@@ -55,6 +55,23 @@ def steps(name, row, rowptr, col, val, M, N):
                                           long_columns=st._csc_view()._longest_row() > 128)
     hb()
     print(f"[{tag}] {name}: bf16 sum pass over the CSC view (both gradients): {event_ms(hb, 10):7.3f} ms", flush=True)
+    if st._longest_row() <= 65_535 and st._spmm_algo() == "row_waves":  # the masked half-width pass (min / max), as autograd feeds it
+        width = 2 if st._longest_row() > 128 else 1
+        _, _, words = ops._spmm("max", rowptr, col, val, Bb.detach(), want_arg=False, want_arg_bytes=width)
+        tags = st._csc_edge_tags(width)
+        mb = lambda: ops.spmm_half_minmax_bw_csc(st.colptr(), st._row_in_csc_order(), tags, w, Bb.detach(), Gb, words,
+                                                 long_columns=st._csc_view()._longest_row() > 128)
+        mb()
+        print(f"[{tag}] {name}: bf16 masked pass over the CSC view (max, both gradients): {event_ms(mb, 10):7.3f} ms", flush=True)
+        fm = lambda: ops._spmm("max", rowptr, col, val, Bb.detach(), want_arg=False, want_arg_bytes=width)
+        fm()
+        print(f"[{tag}] {name}: bf16 max forward leaving the row-local arg_out: {event_ms(fm, 10):7.3f} ms", flush=True)
+        def step_max():
+            v.grad = Bb.grad = None
+            a.matmul(Bb, "max").backward(Gb)
+        for _ in range(6):
+            step_max()
+        print(f"[{tag}] {name}: spmm_max fwd + bwd, trained values, bf16: {event_ms(step_max, 10):7.3f} ms", flush=True)
 
 
 M = N = 2_000_000
