@@ -1,10 +1,10 @@
-// Cross-lane sums in the VALU (gfx950): DPP row operations and the v_permlane16/32_swap pair instead of
-// ds_bpermute (__shfl_xor).  Used by the half-width kernels (spmm_half.hip) and spmm_value_bw, where it saved
-// registers (half-width pass over the CSC view 78 -> 70 VGPRs, 6 -> 7 waves per SIMD) and time (1.30 -> 1.23 ms
-// at config 3, 1.66 -> 1.55 ms on R-MAT 21).  NOT used by the fp32 passes of spmm.hip: with the hub rows in
-// cache-resident copies those are bound by VALU issue on power-law graphs, and moving the folds from the
-// (idle) LDS pipe into the VALU took the sum pass from 1.91 to 2.72 ms on R-MAT 21 (profiles/r04_fold_ab.txt,
-// produced at commit 0290f97 with a -DPSA_SHFL_FOLDS build).
+// Cross-lane sums for the SpMM backward kernels (gfx950): DPP row operations — fused into the add, v_add_f32_dpp — for
+// partners 1, 2, 4 and 8 lanes away, and a choice between ds_bpermute and the v_permlane16/32_swap pair for 16 and 32.
+// Used by the half-width kernels (spmm_half.hip: pass over the CSC view 78 -> 70 VGPRs, 6 -> 7 waves per SIMD,
+// 1.27 -> 1.15 ms at config 3) and by spmm_value_bw.  NOT used by the fp32 passes of spmm.hip: with the hub rows in
+// cache-resident copies those are bound by VALU issue on power-law graphs, and moving their folds from the (idle) LDS
+// pipe into the VALU took the sum pass from 1.91 to 2.72 ms on R-MAT 21 (profiles/r04_fold_ab.txt, produced at commit
+// 0290f97 with a -DPSA_SHFL_FOLDS build).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -25,21 +25,39 @@ __device__ __forceinline__ float lane_xor(float x) {
   return dpp_move<0x128>(x);                          // row_ror:8
 }
 
-// x + x(lane ^ 16) / x + x(lane ^ 32).  Through ds_bpermute on purpose: v_permlane16/32_swap exchanges the halves of
-// TWO registers in place, so a sum costs two copies, the swap and the add — four VALU instructions where the shuffle
-// costs one (the add) plus one on the LDS pipe, which idles in these kernels while the VALU is their busiest unit
-// (profiles/r04_pmc_half.json: the permlane form took the half-width forward from 422 M to 468 M VALU instructions
-// per launch for no change in time).  DPP moves fuse into the add (v_add_f32_dpp) and stay.
-__device__ __forceinline__ float add_xor16(float x) { return x + __shfl_xor(x, 16); }
-__device__ __forceinline__ float add_xor32(float x) { return x + __shfl_xor(x, 32); }
+// x + x(lane ^ 16) / x + x(lane ^ 32), two ways.  SWAP = false: ds_bpermute.  SWAP = true: v_permlane16/32_swap, which
+// exchanges the halves of TWO registers in place — a sum costs two copies, the swap and the add, four VALU instructions
+// where the shuffle costs one (the add) plus one on the LDS pipe.  Which is faster depends on the kernel's busiest unit
+// (same box, profiles/r04_fold_hybrid_ab.txt): the half-width kernels are bound by VALU issue and lose with the swap
+// (pass over the CSC view 1.21 vs 1.15 ms; the forward went from 422 M to 468 M VALU instructions per launch for no change
+// in time), spmm_value_bw waits on memory with few registers and gains (1.63 vs 1.77 ms).  DPP moves fuse into the add
+// (v_add_f32_dpp) and are used either way.
+template <bool SWAP>
+__device__ __forceinline__ float add_xor16(float x) {
+  if constexpr (SWAP) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  } else {
+    return x + __shfl_xor(x, 16);
+  }
+}
+template <bool SWAP>
+__device__ __forceinline__ float add_xor32(float x) {
+  if constexpr (SWAP) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  } else {
+    return x + __shfl_xor(x, 32);
+  }
+}
 
 // x + x(lane ^ OFF) with the bits of x + __shfl_xor(x, OFF) (float addition commutes): the fold of the
 // 64 / LPR lane groups of a wave at the end of a row.  OFF = 8 is a DPP row rotation.
-template <int OFF>
+template <int OFF, bool SWAP = false>
 __device__ __forceinline__ float add_xor(float x) {
   if constexpr (OFF == 8) return x + lane_xor<8>(x);
-  else if constexpr (OFF == 16) return add_xor16(x);
-  else if constexpr (OFF == 32) return add_xor32(x);
+  else if constexpr (OFF == 16) return add_xor16<SWAP>(x);
+  else if constexpr (OFF == 32) return add_xor32<SWAP>(x);
   else return x + __shfl_xor(x, OFF);
 }
 
@@ -66,14 +84,14 @@ __device__ __forceinline__ void fold_lane_groups(float (&acc)[N]) {
 // with l + 4 — right as long as the step for BIT = 8 follows (LPR >= 16: both rotations stay inside the group
 // and together cover the row); in an 8-lane group the mirror of the half row (l <-> 7 - l) serves when the quad
 // holds one quantity (LOW == 1).  Anything else falls back to ds_bpermute.
-template <int BIT, int LPR, int LOW>
+template <int BIT, int LPR, int LOW, bool SWAP = false>
 __device__ __forceinline__ float group_sum_step(float x) {
   if constexpr (BIT == 1 || BIT == 2) return x + lane_xor<BIT>(x);
   else if constexpr (BIT == 4 && LPR >= 16) return x + dpp_move<0x124>(x);        // row_ror:4 (completed by BIT = 8)
   else if constexpr (BIT == 4 && LPR == 8 && LOW == 1) return x + dpp_move<0x141>(x);  // row_half_mirror
   else if constexpr (BIT == 8) return x + lane_xor<8>(x);
-  else if constexpr (BIT == 16) return add_xor16(x);
-  else if constexpr (BIT == 32) return add_xor32(x);
+  else if constexpr (BIT == 16) return add_xor16<SWAP>(x);
+  else if constexpr (BIT == 32) return add_xor32<SWAP>(x);
   else return x + __shfl_xor(x, BIT);
 }
 
@@ -81,7 +99,7 @@ __device__ __forceinline__ float group_sum_step(float x) {
 // dots, transposing as it goes: after log2(U) exchange steps lane l keeps ONE partial, of slot u = l % U; the
 // remaining bits add up.  Lane l (< U) of the group ends with the whole dot of slot l in dot[0].
 // U - 1 + log2(LPR / U) cross-lane moves for U dots instead of U * log2(LPR).
-template <int LPR, int U>
+template <int LPR, int U, bool SWAP = false>
 __device__ __forceinline__ void fold_group_dots(float (&dot)[U], int l) {
   static_assert((U & (U - 1)) == 0 && U <= LPR, "U must be a power of two <= LPR");
   int cnt = U;
@@ -101,8 +119,8 @@ __device__ __forceinline__ void fold_group_dots(float (&dot)[U], int l) {
   if constexpr (U <= 2 && LPR > 2) x = group_sum_step<2, LPR, U>(x);
   if constexpr (U <= 4 && LPR > 4) x = group_sum_step<4, LPR, U>(x);
   if constexpr (U <= 8 && LPR > 8) x = group_sum_step<8, LPR, U>(x);
-  if constexpr (U <= 16 && LPR > 16) x = group_sum_step<16, LPR, U>(x);
-  if constexpr (U <= 32 && LPR > 32) x = group_sum_step<32, LPR, U>(x);
+  if constexpr (U <= 16 && LPR > 16) x = group_sum_step<16, LPR, U, SWAP>(x);
+  if constexpr (U <= 32 && LPR > 32) x = group_sum_step<32, LPR, U, SWAP>(x);
   dot[0] = x;
 }
 

@@ -123,7 +123,7 @@ __device__ __forceinline__ void value_bw_range(const int64_t* __restrict__ col,
       }
       // Fold the U partial dots of this lane group together (lane_fold.h: DPP / permlane moves in the
       // VALU, no ds_bpermute): lane l < U of group g ends up with the whole dot of edge slot j + l * G + g.
-      psa::fold_group_dots<LPR, U>(dot, l);
+      psa::fold_group_dots<LPR, U, true>(dot, l);  // bits 16 / 32 by permlane swaps: this kernel waits on memory, not on the VALU
       // It is handed to the lane that loaded that edge (lane == slot) and stored once per 64-edge batch —
       // 256 contiguous bytes instead of G * U floats per step (partial-line writes: 199 MB written for 80 MB
       // of grad_value at config 3, profiles/r03_pmc_backward.json).
