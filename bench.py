@@ -313,7 +313,8 @@ def power_law(device, F: int, reps: int):
                 t.matmul(Bt, reduce).backward(G)
 
             for reduce in ("sum", "max"):
-                step(reduce)
+                for _ in range(3):  # the storage builds its planned routes on the SECOND request: keep that out of the timed steps
+                    step(reduce)
                 entry[f"spmm_{reduce}_fwd_bwd_trained_values_ms"] = round(event_ms(lambda: step(reduce), max(3, reps // 4)), 4)
             del t, v
             # the same step with a bf16 dense operand: half-width forward (edge ranges), ONE half-width pass over the CSC
@@ -327,8 +328,8 @@ def power_law(device, F: int, reps: int):
                 vb.grad = Bb.grad = None
                 tb.matmul(Bb, "sum").backward(Gb)
 
-            half_step()
-            half_step()
+            for _ in range(3):
+                half_step()
             entry["spmm_sum_bf16_fwd_bwd_trained_values_ms"] = round(event_ms(half_step, max(3, reps // 4)), 4)
             del tb, vb, Bb, Gb
             # ... and with a fixed adjacency (gradient wrt the dense operand only)
@@ -380,8 +381,8 @@ def power_law_rmat24(device, F: int, reps: int):
     import paddle_sparse_amd.matmul  # noqa: F401  (the module; the package exports a function of the same name)
     mm_mod = sys.modules["paddle_sparse_amd.matmul"]
     for reduce in ("sum", "max"):
-        step(reduce)
-        step(reduce)
+        for _ in range(3):
+            step(reduce)
         entry[f"spmm_{reduce}_fwd_bwd_trained_values_ms"] = round(event_ms(lambda: step(reduce), reps), 4)
     mm_mod.HUGE_ROW_PIECES = False  # the route of round 3: int64 arg_out beside the one-byte form
     try:

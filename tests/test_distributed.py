@@ -414,6 +414,15 @@ def test_row_partitioned_spmm_world1_on_the_device():
             raw = pd.RowPartitionedSpMM.from_global(t_rp, t_c, t_v, N2, exchange=exchange, plan=False)
             S = ops._spmm("sum", t_rp, t_c, t_v.abs(), B2.abs())[0]
             assert bool(((raw(b_local) - want.detach()).abs() <= 1e-5 * S + 1e-30).all())
+            # plan=False with a half-width operand and an output the object keeps / column slices — the
+            # half-width kernels take no `out`, the raw branch must copy like the planned one
+            raw_kept = pd.RowPartitionedSpMM.from_global(t_rp, t_c, t_v, N2, exchange=exchange, plan=False, keep_output=True)
+            bh = b_local.to(torch.bfloat16)
+            want_h = tensor.matmul(B2.to(torch.bfloat16)).float()
+            for chunks in (1, 2):
+                got_h = raw_kept(bh, feature_chunks=chunks)
+                assert got_h.dtype == torch.bfloat16
+                assert bool(((got_h.float() - want_h).abs() <= 2.0 ** -7 * want_h.abs() + 1e-5 * S + 1e-30).all())
             # backward through the step: reduce_scatter (full) / the halo run backwards
             bl = b_local.clone().requires_grad_(True)
             op.apply(bl).backward(G2)
