@@ -1,10 +1,12 @@
 // Cross-lane sums for the SpMM backward kernels (gfx950): DPP row operations — fused into the add, v_add_f32_dpp — for
 // partners 1, 2, 4 and 8 lanes away, and a choice between ds_bpermute and the v_permlane16/32_swap pair for 16 and 32.
-// Used by the half-width kernels (spmm_half.hip: pass over the CSC view 78 -> 70 VGPRs, 6 -> 7 waves per SIMD,
-// 1.27 -> 1.15 ms at config 3) and by spmm_value_bw.  NOT used by the fp32 passes of spmm.hip: with the hub rows in
-// cache-resident copies those are bound by VALU issue on power-law graphs, and moving their folds from the (idle) LDS
-// pipe into the VALU took the sum pass from 1.91 to 2.72 ms on R-MAT 21 (profiles/r04_fold_ab.txt, produced at commit
-// 0290f97 with a -DPSA_SHFL_FOLDS build).
+// The DPP form replaces {ds_bpermute, v_add} by one v_add_f32_dpp: never more VALU work, less on the LDS pipe, fewer
+// registers (half-width pass over the CSC view 78 -> 70 VGPRs, 6 -> 7 waves per SIMD, 1.27 -> 1.15 ms at config 3; fp32
+// sum pass on R-MAT 21 1.89 -> 1.78 ms, profiles/r04_spmm_dpp_ab.txt).  The permlane pair is NOT free: see add_xor16.
+// A first form that put EVERY fold of the fp32 passes into the VALU — permlane swaps for 16 / 32 and for the lane groups'
+// sums at the end of every row — took the sum pass on R-MAT 21 from 1.91 to 2.72 ms (profiles/r04_fold_ab.txt, commit
+// 0290f97 with a -DPSA_SHFL_FOLDS build as the other arm): with the hub rows in cache-resident copies that pass is bound
+// by VALU issue, and most of its rows are empty or tiny, so the per-row fold is what it executes most.
 #pragma once
 
 #include <hip/hip_runtime.h>

@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "lane_fold.h"
 #include "long_rows.h"
 #include "spmm_eb.h"
 #include "vec_io.h"
@@ -317,23 +318,9 @@ __device__ __forceinline__ void reduce_edge_range(
 #pragma unroll
             for (int i = 0; i < VEC; ++i) dot[u] += b[u][i] * mr[i];
           }
-          // fold the U partial dots of the lane group: lane l ends up with the whole dot of edge slot
-          // u = l % U.  Through ds_bpermute on purpose: with the hub rows in cache-resident copies this pass
-          // is bound by VALU issue on power-law graphs, and the DPP / permlane form of lane_fold.h (VALU
-          // work instead of LDS-pipe work) took it from 1.91 to 2.72 ms on R-MAT 21 (profiles/r04_fold_ab.txt)
-          int cnt = U;
-#pragma unroll
-          for (int bit = 1; bit < U; bit <<= 1, cnt >>= 1) {
-            const bool up = (l & bit) != 0;
-#pragma unroll
-            for (int i = 0; i < cnt / 2; ++i) {
-              const float keep = up ? dot[2 * i + 1] : dot[2 * i];
-              const float send = up ? dot[2 * i] : dot[2 * i + 1];
-              dot[i] = keep + __shfl_xor(send, bit);
-            }
-          }
-#pragma unroll
-          for (int bit = U; bit < LPR; bit <<= 1) dot[0] += __shfl_xor(dot[0], bit);
+          // fold the U partial dots of the lane group: lane l ends up with the whole dot of edge slot u = l % U
+          // (lane_fold.h: partners 1, 2, 4, 8 lanes away as DPP operands of the add, 16 by ds_bpermute)
+          psa::fold_group_dots<LPR, U>(dot, l);
           // Lane l < U of group g now holds the dot of edge slot j + l * G + g.  It is handed to
           // the lane that loaded that edge (lane == slot) and stored once per 64-edge batch, 256
           // contiguous bytes, instead of 8 floats per step (partial-line writes).  The store goes to
