@@ -316,6 +316,8 @@ def power_law(device, F: int, reps: int):
                 for _ in range(3):  # the storage builds its planned routes on the SECOND request: keep that out of the timed steps
                     step(reduce)
                 entry[f"spmm_{reduce}_fwd_bwd_trained_values_ms"] = round(event_ms(lambda: step(reduce), max(3, reps // 4)), 4)
+            # the max forward as autograd runs it (out + the two-byte row-local arg_out), against out only above
+            entry["spmm_max_forward_under_autograd_ms"] = round(event_ms(lambda: t.matmul(Bt, "max"), reps), 4)
             del t, v
             # the same step with a bf16 dense operand: half-width forward (edge ranges), ONE half-width pass over the CSC
             # view for both gradients with the hub rows' long columns in chunks — no fp32 copies of B / grad_out
@@ -384,6 +386,7 @@ def power_law_rmat24(device, F: int, reps: int):
         for _ in range(3):
             step(reduce)
         entry[f"spmm_{reduce}_fwd_bwd_trained_values_ms"] = round(event_ms(lambda: step(reduce), reps), 4)
+    entry["spmm_max_forward_under_autograd_ms"] = round(event_ms(lambda: t.matmul(Bt, "max"), reps), 4)  # incl. the pieces
     mm_mod.HUGE_ROW_PIECES = False  # the route of round 3: int64 arg_out beside the one-byte form
     try:
         step("max")

@@ -108,6 +108,13 @@ def test_sum_mean_backward_properties(c3, reduce):
     sc_v = terms.abs().sum(1) / (deg[row[e]].double() if reduce == "mean" else 1.0)
     assert bool(((gv1[e].double() - ref_v).abs() <= 1e-5 * sc_v + 1e-30).all())
     assert bool(((gv12 - (gv1 + 2 * gv2)).abs() <= 1e-4 * (gv1.abs() + 2 * gv2.abs()) + 1e-4).all())
+    # values only (trained edge values over fixed input features: a first GNN layer): autograd takes spmm_value_bw, the
+    # CSR-side pass that reads grad_out[row] once per row and gathers mat[col] — same numbers as the one-pass kernel
+    # up to the order of the K-term dot, and the float64 sample again
+    v = val.clone().requires_grad_()
+    a.set_value(v, layout="coo").matmul(B, reduce).backward(G)
+    assert bool(((v.grad[e].double() - ref_v).abs() <= 1e-5 * sc_v + 1e-30).all())
+    assert bool(((v.grad - gv1).abs() <= 2e-5 * (v.grad.abs() + gv1.abs()) + 1e-4).all())
 
 
 @pytest.mark.parametrize("reduce", ["max", "min"])
@@ -353,3 +360,45 @@ def test_rmat24_minmax_training_step_takes_the_bytes_only_route(reduce):
         del a, out, v, Bt
     for x, y in zip(*res):
         assert torch.equal(x, y)
+
+
+def test_power_law_bf16_training_step_stays_half_width(rmat):
+    """VERDICT r03 #4 at full size: R-MAT 21 with trained values and a bf16 dense operand — the transpose is power-law
+    (hub rows of 41 677 entries = long columns of the CSC view), and the step still runs the half-width kernels end to
+    end: no fp32 pass is called, no fp32 copy of B / grad_out is made (the half-width pass takes long columns in chunks),
+    and both gradients are the fp32 route's on the same rounded operands up to bf16 rounding of grad_mat."""
+    from paddle_sparse_amd import SparseTensor, ops
+
+    size, row, col, rowptr = rmat["size"], rmat["row"], rmat["col"], rmat["rowptr"]
+    Bh = rmat["B"].to(torch.bfloat16)
+    Gh = rmat["G"].to(torch.bfloat16)
+
+    def run(B_, G_):
+        v = rmat["val"].clone().requires_grad_(True)
+        Bt = B_.clone().requires_grad_(True)
+        a = SparseTensor(row=row, rowptr=rowptr, col=col, value=v, sparse_sizes=(size, size), is_sorted=True, trust_data=True)
+        a.matmul(Bt, "sum").backward(G_)
+        return a, v.grad, Bt.grad
+
+    called = []
+    names = ("spmm_sum_bw_csc", "spmm_value_bw")  # (value[csr2csc], an nnz-float gather, is not a dense pass)
+    real = {n: getattr(ops, n) for n in names}
+    real_spmm = ops._spmm
+    for n in names:
+        setattr(ops, n, (lambda n_: lambda *x, **k: called.append(n_) or real[n_](*x, **k))(n))
+    ops._spmm = lambda reduce, rp, c, v_, mat, *x, **k: (called.append("fp32 forward") if mat.dtype == torch.float32 else None) or real_spmm(reduce, rp, c, v_, mat, *x, **k)
+    try:
+        a, gv_h, gm_h = run(Bh, Gh)
+    finally:
+        for n in names:
+            setattr(ops, n, real[n])
+        ops._spmm = real_spmm
+    assert called == [], called
+    assert a.storage._csc_view()._longest_row() > 128 and gm_h.dtype == torch.bfloat16 and gv_h.dtype == torch.float32
+    _, gv_f, gm_f = run(Bh.float(), Gh.float())  # the fp32 route on the same rounded operands
+    scale_m = SparseTensor(row=row, rowptr=rowptr, col=col, value=rmat["val"].abs(), sparse_sizes=(size, size), is_sorted=True,
+                           trust_data=True).t().matmul(Gh.float().abs())
+    assert bool(((gm_h.float() - gm_f).abs() <= 2.0 ** -8 * gm_f.abs() + 1e-5 * scale_m + 1e-30).all())
+    e = torch.randint(0, col.numel(), (200_000,), device="cuda")
+    mag_v = (Bh[col[e]].float().abs() * Gh[row[e]].float().abs()).sum(1)
+    assert bool(((gv_h[e] - gv_f[e]).abs() <= 1e-5 * mag_v + 1e-30).all())
