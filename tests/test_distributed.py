@@ -208,7 +208,7 @@ def _worker_strong_split(rank, world, port, M, N, F):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,M,N", [(4, 90, 64), (4, 3, 10), (3, 50, 31)])
+@pytest.mark.parametrize("world,M,N", [(4, 90, 64), (4, 3, 10), (3, 50, 31), (8, 400, 203)])  # 8: the rank count of the real job
 def test_strong_split_every_exchange_more_ranks_gloo(world, M, N):
     import oracle
 
