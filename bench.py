@@ -326,13 +326,14 @@ def power_law(device, F: int, reps: int):
             Gb = G.to(torch.bfloat16)
             tb = SparseTensor(row=row, rowptr=rowptr, col=col, value=vb, sparse_sizes=(N, N), is_sorted=True, trust_data=True)
 
-            def half_step():
+            def half_step(reduce="sum"):
                 vb.grad = Bb.grad = None
-                tb.matmul(Bb, "sum").backward(Gb)
+                tb.matmul(Bb, reduce).backward(Gb)
 
-            for _ in range(3):
-                half_step()
-            entry["spmm_sum_bf16_fwd_bwd_trained_values_ms"] = round(event_ms(half_step, max(3, reps // 4)), 4)
+            for reduce in ("sum", "max"):  # max: the edge-range forward leaves the two-byte row-local arg_out in half width too
+                for _ in range(3):
+                    half_step(reduce)
+                entry[f"spmm_{reduce}_bf16_fwd_bwd_trained_values_ms"] = round(event_ms(lambda: half_step(reduce), max(3, reps // 4)), 4)
             del tb, vb, Bb, Gb
             # ... and with a fixed adjacency (gradient wrt the dense operand only)
             fixed = SparseTensor(row=row, rowptr=rowptr, col=col, value=val, sparse_sizes=(N, N), is_sorted=True, trust_data=True)

@@ -208,14 +208,17 @@ int psa_spmm_half(int reduce, int dtype, const int64_t* rowptr,
  * psa_spmm_half_workspace_bytes(reduce, K, nnz) bytes, 16-byte aligned.  Sums are
  * taken in edge order inside a range, rows that cross ranges are folded from fp32
  * partials: sum / mean may differ from psa_spmm_half in the last bit of the
- * 2-byte result; min / max / arg_out are identical. */
+ * 2-byte result; min / max / arg_out are identical.  arg_bytes / arg_width (MIN / MAX): the
+ * row-local form of arg_out as in psa_spmm_coo ([M, K] entries of 1 or 2 bytes, or NULL) — what the
+ * half-width masked pass over the CSC view reads (psa_spmm_half_minmax_bw_csc), so that min / max
+ * training on a power-law matrix needs neither an int64 arg_out nor fp32 copies of the operands. */
 size_t psa_spmm_half_workspace_bytes(int reduce, int64_t K, int64_t nnz);
 int psa_spmm_half_coo(int reduce, int dtype, const int64_t* rowptr,
                       const int64_t* row, const int64_t* col, const float* value,
                       const void* mat, const void* hot_rows, int64_t num_hot,
                       int64_t M, int64_t N, int64_t K, int64_t nnz, void* out,
-                      int64_t* arg_out, int algo, void* workspace,
-                      size_t workspace_bytes, psa_stream_t stream);
+                      int64_t* arg_out, void* arg_bytes, int arg_width, int algo,
+                      void* workspace, size_t workspace_bytes, psa_stream_t stream);
 
 /* sum / mean backward with BOTH gradients in one pass over the CSC view, half-width dense
  * operands (the fp32 form is psa_spmm_sum_bw_csc): mat f16/bf16 [N, K] (the forward's dense

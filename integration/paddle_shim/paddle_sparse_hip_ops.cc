@@ -234,7 +234,7 @@ std::vector<paddle::Tensor> spmm_half_coo(paddle::Tensor& rowptr, paddle::Tensor
   PSA_CALL(psa_spmm_half_coo(static_cast<int>(reduce), dtype_id_of(mat), i64(rowptr), i64_or_null(row), i64(col),
                              f32_or_null(value), mat.data(), hot_rows ? hot_rows.get().data() : nullptr,
                              hot_rows ? hot_rows.get().shape()[0] : 0, M, N, K, nnz, out.data(),
-                             minmax && want_arg ? arg.data<int64_t>() : nullptr, static_cast<int>(algo),
+                             minmax && want_arg ? arg.data<int64_t>() : nullptr, nullptr, 1, static_cast<int>(algo),
                              ws_bytes > 0 ? ws.data<uint8_t>() : nullptr, ws_bytes, stream_of(mat)));
   return {out, arg};
 }

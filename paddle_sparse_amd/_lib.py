@@ -38,8 +38,8 @@ SIGNATURES = {
                              c_size_t, c_void_p]),
     "psa_spmm_half_workspace_bytes": (c_size_t, [c_int, c_int64, c_int64]),
     "psa_spmm_half_coo": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
-                                  c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
-                                  c_void_p]),
+                                  c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                                  c_size_t, c_void_p]),
     "psa_spmm_half": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int64, c_int64,
                               c_int64, c_void_p, c_void_p, c_void_p]),
     "psa_spmm_half_sum_bw_csc": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64,

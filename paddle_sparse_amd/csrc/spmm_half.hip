@@ -884,8 +884,8 @@ extern "C" size_t psa_spmm_half_workspace_bytes(int reduce, int64_t K, int64_t n
 
 extern "C" int psa_spmm_half_coo(int reduce, int dtype, const int64_t* rowptr, const int64_t* row, const int64_t* col,
                                  const float* value, const void* mat, const void* hot_rows, int64_t num_hot, int64_t M,
-                                 int64_t N, int64_t K, int64_t nnz, void* out, int64_t* arg_out, int algo,
-                                 void* workspace, size_t workspace_bytes, psa_stream_t stream) {
+                                 int64_t N, int64_t K, int64_t nnz, void* out, int64_t* arg_out, void* arg_bytes,
+                                 int arg_width, int algo, void* workspace, size_t workspace_bytes, psa_stream_t stream) {
   PSA_REQUIRE(reduce >= PSA_SUM && reduce <= PSA_MAX, "bad reduce");
   PSA_REQUIRE(algo >= PSA_SPMM_AUTO && algo <= PSA_SPMM_EDGE_RANGES, "bad algo");
   PSA_REQUIRE(num_hot >= 0 && (num_hot == 0 || hot_rows != nullptr), "hot_rows is NULL");
@@ -903,10 +903,14 @@ extern "C" int psa_spmm_half_coo(int reduce, int dtype, const int64_t* rowptr, c
                      "K % 8 == 0, 16-byte aligned operands, a workspace)");
       return PSA_ERR_UNSUPPORTED;
     }
-    return psa_spmm_half(reduce, dtype, rowptr, col, value, PSA_F32, mat, M, N, K, nnz, out, arg_out, stream);
+    return psa_spmm_half_arg(reduce, dtype, rowptr, col, value, PSA_F32, mat, M, N, K, nnz, out, arg_out, arg_bytes,
+                             arg_width, stream);
   }
+  PSA_REQUIRE(arg_bytes == nullptr || ((arg_width == 1 || arg_width == 2) && psa::aligned(arg_bytes, 8)),
+              "arg_bytes: width 1 or 2, 8-byte aligned");
   PSA_REQUIRE(rowptr != nullptr && col != nullptr && mat != nullptr && out != nullptr, "NULL pointer");
   const int red = reduce == PSA_MIN ? R_MIN : (reduce == PSA_MAX ? R_MAX : R_SUM);
-  return psa::launch_spmm_eb(red, reduce == PSA_MEAN, rowptr, row, col, value, mat, out, K, arg_out, nullptr, 1, M, N, K,
+  return psa::launch_spmm_eb(red, reduce == PSA_MEAN, rowptr, row, col, value, mat, out, K, arg_out,
+                             static_cast<uint8_t*>(arg_bytes), arg_bytes != nullptr ? arg_width : 1, M, N, K,
                              nnz, hot_rows, num_hot, workspace, workspace_bytes, false, 0, 0, psa::as_stream(stream), half);
 }

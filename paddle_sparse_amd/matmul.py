@@ -60,10 +60,9 @@ def _streamed_values(st: SparseStorage, value: Optional[torch.Tensor], plan="ask
 
 def _half_minmax_bw_ok(st: SparseStorage, K: int) -> bool:
     """Will the half-width masked pass over the CSC view serve the min / max backward of this matrix?  K in one
-    tile, an exact row-local form (no row above 65 535 entries) and a forward of the row-wave family (the one that
-    leaves that form behind in half width).  The transpose may be anything: long columns run in chunks."""
-    return (ops.half_sum_bw_csc_supported(K) and st._longest_row() <= ops.ARG_WORDS_EXACT_ROW
-            and st._spmm_algo() == "row_waves")
+    tile and an exact row-local form (no row above 65 535 entries).  Both forward families leave that form behind in
+    half width, and the transpose may be anything: long columns run in chunks."""
+    return ops.half_sum_bw_csc_supported(K) and st._longest_row() <= ops.ARG_WORDS_EXACT_ROW
 
 
 def _huge_piece_winners(st: SparseStorage, reduce: str, value: Optional[torch.Tensor], mat: torch.Tensor) -> torch.Tensor:
@@ -142,13 +141,15 @@ class _SpMM(torch.autograd.Function):
                     hot_rows, col = ops._gather_rows_raw(mat.detach(), plan[0]), plan[1]
             arg_bytes = None
             need_mat = track and ctx.needs_input_grad[1]
-            if (reduce in ("min", "max") and need and need_mat and algo == "auto" and _half_minmax_bw_ok(storage, mat.shape[1])
+            if (reduce in ("min", "max") and need and need_mat and _half_minmax_bw_ok(storage, mat.shape[1])
                     and (value is None or value.dtype in (torch.float32, mat.dtype))):
                 # min / max whose backward will be the half-width masked pass over the CSC view: the forward leaves the
                 # row-local form of arg_out only (1 byte per element up to 128-entry rows, 2 up to 65 535) — no int64
-                # arg_out (8 bytes per element against the 2 of `out` itself)
+                # arg_out (8 bytes per element against the 2 of `out` itself); on a power-law matrix from the
+                # edge-range kernels with the hub-row copy
                 width = 2 if storage._longest_row() > ops.ARG_BYTES_EXACT_ROW else 1
-                out, arg, arg_bytes = ops._spmm(reduce, rowptr, col, value, mat, want_arg=False, want_arg_bytes=width)
+                out, arg, arg_bytes = ops._spmm(reduce, rowptr, col, value, mat, want_arg=False, want_arg_bytes=width,
+                                                row=row, algo=algo, hot_rows=hot_rows)
             else:
                 out, arg = ops._spmm(reduce, rowptr, col, value, mat, want_arg=need and reduce in ("min", "max"), row=row,
                                      algo=algo, hot_rows=hot_rows)

@@ -220,8 +220,8 @@ def _spmm_half(reduce: str, rowptr, col, value, mat, want_arg: bool = True, row=
         if value.dtype not in (torch.float32, mat.dtype) or value.dim() != 1 or value.numel() != nnz:
             raise ValueError("value must be float32[nnz] or mat's dtype[nnz]")
         value = value.contiguous()
-    if want_arg_bytes and (K % 8 != 0 or algo == "edge_ranges"):
-        raise ValueError("the half-width SpMM writes arg_bytes on the row-wave kernels only (K % 8 == 0)")
+    if want_arg_bytes and K % 8 != 0:
+        raise ValueError("the half-width SpMM writes arg_bytes for K % 8 == 0 only")
     if K % 8 != 0:
         res = _spmm(reduce, rowptr, col, None if value is None else value.float(), mat.float(), want_arg=want_arg)
         return res[0].to(mat.dtype), res[1]
@@ -236,10 +236,15 @@ def _spmm_half(reduce: str, rowptr, col, value, mat, want_arg: bool = True, row=
             num_hot = hot_rows.shape[0]
         lib = _lib.load()
         ws = _workspace(lib.psa_spmm_half_workspace_bytes(rid, K, nnz), mat.device)
+        eb_bytes, eb_width = None, 2 if want_arg_bytes == 2 else 1
+        if want_arg_bytes and minmax:  # the row-local form, from the edge-range kernels (power-law matrices)
+            eb_bytes = torch.empty((M, K), dtype=torch.int16 if eb_width == 2 else torch.uint8, device=mat.device)
         with _on(mat.device):
             check(lib.psa_spmm_half_coo(rid, _DTYPE_ID[mat.dtype], _ptr(rowptr), _ptr(row), _ptr(col), _ptr(value), _ptr(mat),
                                         _ptr(hot_rows) if num_hot else None, num_hot, M, N, K, nnz, _ptr(out), _ptr(arg),
-                                        _lib.SPMM_ALGO_ID[algo], _ptr(ws), ws.numel(), _stream()))
+                                        _ptr(eb_bytes), eb_width, _lib.SPMM_ALGO_ID[algo], _ptr(ws), ws.numel(), _stream()))
+        if want_arg_bytes:
+            return out, arg, eb_bytes
         return out, arg
     if hot_rows is not None:
         raise ValueError("hot_rows needs algo='edge_ranges' and fp32 (or no) values")

@@ -405,6 +405,72 @@ def _hub_column_matrix(M, N, seed):
     return row, oracle.ind2ptr(row, M), col, val
 
 
+def _power_law_matrix(M, N, seed):
+    """Rows and columns drawn with a cubic skew: most rows hold at most two entries (the edge-range forward is chosen),
+    a few hold hundreds, and the transpose has long columns."""
+    rng = np.random.default_rng(seed)
+    n = 30_000
+    row = np.minimum((rng.random(n) ** 3 * M).astype(np.int64), M - 1)
+    col = np.minimum((rng.random(n) ** 3 * N).astype(np.int64), N - 1)
+    key = np.unique(row * N + col)
+    row, col = key // N, key % N
+    val = rng.standard_normal(row.size).astype(np.float32)
+    return row, oracle.ind2ptr(row, M), col, val
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("reduce", ["sum", "mean", "max", "min"])
+@pytest.mark.parametrize("K", [64, 128])
+def test_half_training_step_on_a_power_law_matrix_stays_half_width(dtype, reduce, K):
+    """VERDICT r03 #4, the other half: a power-law matrix takes the edge-range FORWARD, which now leaves the row-local
+    arg_out behind in half width too (psa_spmm_half_coo(arg_bytes)), so min / max — like sum / mean — train without an
+    int64 arg_out and without fp32 copies of the operands: no fp32 pass is called, gradients against the oracle."""
+    from paddle_sparse_amd import SparseTensor, ops
+
+    M, N = 20_000, 8_000
+    row, rowptr, col, val = _power_law_matrix(M, N, seed=K)
+    rng = np.random.default_rng(K + 1)
+    d = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()  # noqa: E731
+    Bd, Bf = rounded(rng.standard_normal((N, K)).astype(np.float32), dtype)
+    Gd, Gf = rounded(rng.standard_normal((M, K)).astype(np.float32), dtype)
+    v = d(val).requires_grad_()
+    Bt = Bd.clone().requires_grad_()
+    a = SparseTensor(row=d(row), col=d(col), value=v, sparse_sizes=(M, N), is_sorted=True)
+    assert a.storage._spmm_algo() == "edge_ranges" and 128 < a.storage._longest_row() <= 65_535
+    assert a.storage._csc_view()._longest_row() > 128
+    called, wanted = [], []
+    names = ("spmm_sum_bw_csc", "spmm_value_bw", "spmm_minmax_bw_csc", "spmm_minmax_bw", "spmm_minmax_bw_eb")
+    real = {n: getattr(ops, n) for n in names}
+    real_half = ops._spmm_half
+    for n in names:
+        setattr(ops, n, (lambda n_: lambda *x, **k: called.append(n_) or real[n_](*x, **k))(n))
+    ops._spmm_half = lambda *x, **k: wanted.append((k.get("algo"), k.get("want_arg", x[5] if len(x) > 5 else True), k.get("want_arg_bytes", False))) or real_half(*x, **k)
+    try:
+        out = a.matmul(Bt, reduce)
+        out.backward(Gd)
+    finally:
+        for n in names:
+            setattr(ops, n, real[n])
+        ops._spmm_half = real_half
+    assert called == [], called
+    if reduce in ("max", "min"):  # the forward: edge ranges, two-byte row-local winners, no int64 arg_out
+        assert wanted[0] == ("edge_ranges", False, 2), wanted
+    eps, tiny = EPS[dtype], TINY[dtype]
+    ref_out, ref_arg = oracle.spmm(reduce, rowptr, col, val, Bf)
+    S = oracle.spmm_abs_sum(rowptr, col, val, Bf) if reduce in ("sum", "mean") else 0.0
+    assert np.all(np.abs(out.detach().float().cpu().numpy() - ref_out) <= eps * np.abs(ref_out) + 1e-5 * S + tiny)
+    if reduce in ("sum", "mean"):
+        gm_ref = oracle.spmm_mat_bw(reduce, row, rowptr, col, val, Gf, N)
+        gm_S = oracle.spmm_mat_bw(reduce, row, rowptr, col, np.abs(val), np.abs(Gf), N)
+        gv_ref = oracle.spmm_value_bw(reduce, row, rowptr, col, Bf, Gf)
+        gv_S = oracle.spmm_value_bw(reduce, row, rowptr, col, np.abs(Bf), np.abs(Gf))
+    else:
+        gv_ref, gm_ref = oracle.spmm_minmax_bw(col, val, Bf, Gf, ref_arg)
+        gv_S, gm_S = oracle.spmm_minmax_bw(col, np.abs(val), np.abs(Bf), np.abs(Gf), ref_arg)
+    assert np.all(np.abs(Bt.grad.float().cpu().numpy() - gm_ref) <= 1e-5 * gm_S + eps * np.abs(gm_ref) + tiny + 1e-30)
+    assert np.all(np.abs(v.grad.float().cpu().numpy() - gv_ref) <= 1e-5 * gv_S + 1e-30)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("reduce", ["sum", "mean", "max", "min"])
 @pytest.mark.parametrize("K", [64, 128, 512])
