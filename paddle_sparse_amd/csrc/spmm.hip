@@ -618,86 +618,6 @@ spmm_long_chunk_kernel(const int64_t* __restrict__ rowptr,
 // ---------------------------------------------------------------------------
 // (kFusedChunkBlocksDefault = 768, x 4 waves: ~3/8 of the chip's wave slots)
 
-constexpr int kFindIters = 4;   // x 256 rows per workgroup of find_long_rows_kernel
-
-// Builds the long-row list {row, first chunk, chunks}, list order = chunk order =
-// row order inside a workgroup.  ONE atomic per workgroup of 1024 rows reserves
-// {long rows, chunks} for all of them: atomics on the single counter complete
-// one after the other (~3 ns each), and a power-law graph has tens of thousands
-// of long rows (R-MAT scale 21: 63 us with one atomic per row or per wave).
-// Pass 1 counts per (trip, wave), lane 0 of the block scans those 64 pairs and
-// reserves; pass 2 recomputes the (L2-hot) degrees and writes the entries.
-__global__ void __launch_bounds__(kThreads)
-find_long_rows_kernel(const int64_t* __restrict__ rowptr, int64_t M,
-                      unsigned long long* __restrict__ ctr, LongEntry* __restrict__ list) {
-  __shared__ uint32_t s_rows[kFindIters][kWaves];
-  __shared__ uint32_t s_chunks[kFindIters][kWaves];
-  __shared__ uint32_t s_any;
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  const int64_t base = static_cast<int64_t>(blockIdx.x) * (kThreads * kFindIters);
-  if (threadIdx.x == 0) s_any = 0;
-  __syncthreads();
-  bool any = false;
-  for (int it = 0; it < kFindIters; ++it) {
-    const int64_t r = base + it * kThreads + threadIdx.x;
-    const int64_t deg = r < M ? rowptr[r + 1] - rowptr[r] : 0;
-    const bool is_long = deg > kLongRow;
-    uint32_t chunks = is_long ? static_cast<uint32_t>((deg + kLongChunk - 1) / kLongChunk) : 0u;
-    const unsigned long long mask = __ballot(is_long);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) chunks += __shfl_xor(chunks, off);
-    if (lane == 0) {
-      s_rows[it][wave] = static_cast<uint32_t>(__popcll(mask));
-      s_chunks[it][wave] = chunks;
-    }
-    any |= mask != 0;
-  }
-  if (any && lane == 0) s_any = 1;
-  __syncthreads();
-  if (s_any == 0) return;  // block-uniform: no atomic at all for blocks of short rows
-  if (threadIdx.x == 0) {
-    uint32_t nrows = 0, nchunks = 0;
-    for (int it = 0; it < kFindIters; ++it) {
-      for (int w = 0; w < kWaves; ++w) {  // exclusive prefixes in (trip, wave) = row order
-        const uint32_t a = s_rows[it][w], b = s_chunks[it][w];
-        s_rows[it][w] = nrows;
-        s_chunks[it][w] = nchunks;
-        nrows += a;
-        nchunks += b;
-      }
-    }
-    const unsigned long long old = atomicAdd(ctr, (static_cast<unsigned long long>(nrows) << 32) | nchunks);
-    for (int it = 0; it < kFindIters; ++it) {
-      for (int w = 0; w < kWaves; ++w) {
-        s_rows[it][w] += static_cast<uint32_t>(old >> 32);
-        s_chunks[it][w] += static_cast<uint32_t>(old & 0xffffffffull);
-      }
-    }
-  }
-  __syncthreads();
-  for (int it = 0; it < kFindIters; ++it) {
-    const int64_t r = base + it * kThreads + threadIdx.x;
-    const int64_t deg = r < M ? rowptr[r + 1] - rowptr[r] : 0;
-    const bool is_long = deg > kLongRow;
-    const unsigned long long mask = __ballot(is_long);
-    if (mask == 0) continue;  // wave-uniform
-    const uint32_t chunks = is_long ? static_cast<uint32_t>((deg + kLongChunk - 1) / kLongChunk) : 0u;
-    uint32_t incl = chunks;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const uint32_t o = __shfl_up(incl, off);
-      if (lane >= off) incl += o;
-    }
-    if (is_long) {
-      LongEntry e;
-      e.row = r;
-      e.first_chunk = s_chunks[it][wave] + incl - chunks;
-      e.num_chunks = chunks;
-      list[s_rows[it][wave] + __popcll(mask & ((1ull << lane) - 1ull))] = e;
-    }
-  }
-}
 
 template <int VEC, int LPR, int RED, int U, int MODE = M_PLAIN, int AW = 1, bool HOT = false>
 __global__ void __launch_bounds__(kThreads)
@@ -1030,7 +950,7 @@ int launch_fused(int red, const int64_t* rowptr, const int64_t* col, const float
   PSA_REQUIRE(gx <= 0x7fffffff, "M too large for one launch");
   PSA_REQUIRE(k_tiles >= 1 && k_tiles <= 65535, "too many K tiles");
   const dim3 block(kThreads), grid(static_cast<unsigned>(gx), static_cast<unsigned>(k_tiles));
-  hipLaunchKernelGGL(find_long_rows_kernel, dim3(static_cast<unsigned>(psa::ceil_div(M, kThreads * kFindIters))),
+  hipLaunchKernelGGL(psa::find_long_rows_kernel, dim3(static_cast<unsigned>(psa::ceil_div(M, psa::kFindThreads * psa::kFindIters))),
                      block, 0, s, rowptr, M, w.ctr, w.list);
   const dim3 cgrid(kLongBlocks), cblock(psa::kLongThreads);
   MaskArgs plain;
@@ -1080,7 +1000,7 @@ int launch_fused_masked(const int64_t* colptr, const int64_t* row_csc, const flo
   MaskArgs mask = mask_in;
   mask.mix_xcds = g_variant != 27;
   mask.chunk_blocks = kFusedChunkBlocks;
-  hipLaunchKernelGGL(find_long_rows_kernel, dim3(static_cast<unsigned>(psa::ceil_div(N, kThreads * kFindIters))),
+  hipLaunchKernelGGL(psa::find_long_rows_kernel, dim3(static_cast<unsigned>(psa::ceil_div(N, psa::kFindThreads * psa::kFindIters))),
                      block, 0, s, colptr, N, w.ctr, w.list);
   // instantiations by what the pass needs: the one-byte form keeps its second phase (exact test
   // against arg_out), the two-byte form and the hub-row copies have none of it — 76 VGPRs instead

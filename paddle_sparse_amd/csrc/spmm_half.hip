@@ -452,33 +452,70 @@ __device__ __forceinline__ void half_load_mat_row(const uint16_t* __restrict__ m
   }
 }
 
-// One wave per column.  long_list != NULL: columns above psa::kLongRow entries are handed to chunk waves
-// (long_rows.h) instead — a hub row of a power-law graph is a 40 000-entry column of the CSC view, which one wave
-// would walk for milliseconds.
-template <typename T, int LPR, int U, bool GV, int MW = 0, bool SMALL = false>
-__global__ void __launch_bounds__(kThreads, (MW != 0 && GV) ? 5 : 6)  // sum: 78 VGPRs without spilling at 6 waves per SIMD (81 / 5 unconstrained); masked + grad_value: 5
+// One wave per column.  FUSED (the caller brought the long-column workspace): columns above psa::kLongRow entries — a hub
+// row of a power-law graph is a 40 000-entry column of the CSC view, which one wave would walk for milliseconds — are
+// listed by a pre-pass over colptr (psa::find_long_rows_kernel) and the launch runs TWO ROLES, as the fp32 passes do
+// (spmm.hip): the first `chunk_blocks` workgroups take 128-entry chunks of the long columns (grid-stride; a chunk's fp32
+// partial of grad_mat[c, :] goes to part[chunk, :], its grad_value entries are final: chunks own disjoint entries), all
+// the others take ordinary columns and skip the long ones.  On R-MAT 21 60 % of the entries sit in long columns: chunk
+// waves bound by HBM and column waves bound by per-column latency then overlap instead of running back to back
+// (three launches in a row: 1.55 ms for the sum pass).
+template <typename T, int LPR, int U, bool GV, int MW = 0, bool SMALL = false, bool FUSED = false>
+__global__ void __launch_bounds__(kThreads, (MW != 0 && GV) ? 5 : 7)  // sum + grad_value: 70-73 VGPRs unconstrained, 72 fit 7 waves per SIMD; masked + grad_value: 5
 spmm_half_csc_bw_kernel(const int64_t* __restrict__ colptr, const int64_t* __restrict__ row_csc,
                         const float* __restrict__ w_csc, const float* __restrict__ row_scale,
                         const uint16_t* __restrict__ mat, const uint16_t* __restrict__ grad,
                         uint16_t* __restrict__ grad_mat, float* __restrict__ grad_value, int64_t N, int64_t K,
                         int mix_xcds, const uint8_t* __restrict__ words = nullptr,
-                        const uint8_t* __restrict__ tags = nullptr, unsigned long long* __restrict__ long_ctr = nullptr,
-                        psa::LongEntry* __restrict__ long_list = nullptr) {
+                        const uint8_t* __restrict__ tags = nullptr,
+                        const unsigned long long* __restrict__ long_ctr = nullptr,
+                        const psa::LongEntry* __restrict__ long_list = nullptr, float* __restrict__ part = nullptr,
+                        int chunk_blocks = 0) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  int64_t rb = blockIdx.x;
-  if (mix_xcds) rb ^= static_cast<int64_t>((static_cast<uint32_t>(rb >> 3) * 0x9E3779B1u) >> 29);
-  const int64_t c = rb * kWaves + wave;
-  if (c >= N) return;
   const int g = lane / LPR;
   const int l = lane % LPR;
   const int64_t k0 = static_cast<int64_t>(l) * 8;
   const bool kact = k0 < K;
-  const int64_t s = colptr[c], e = colptr[c + 1];
-  if (long_list != nullptr && e - s > psa::kLongRow) {  // wave-uniform
-    if (lane == 0) psa::push_long_row(long_ctr, long_list, c, e - s);
-    return;
+  if constexpr (FUSED) {
+    if (static_cast<int>(blockIdx.x) < chunk_blocks) {  // chunk role (block-uniform)
+      const unsigned long long ctr = *long_ctr;
+      const uint32_t total = static_cast<uint32_t>(ctr & 0xffffffffull);
+      const int ncols = static_cast<int>(ctr >> 32);
+      const uint32_t num_waves = static_cast<uint32_t>(chunk_blocks) * kWaves;
+      for (uint32_t ch = blockIdx.x * kWaves + wave; ch < total; ch += num_waves) {
+        const psa::LongEntry ent = psa::find_long_entry(long_list, ncols, ch);
+        const int64_t cs = colptr[ent.row], ce = colptr[ent.row + 1];
+        const int64_t s = cs + static_cast<int64_t>(ch - ent.first_chunk) * psa::kLongChunk;
+        const int64_t e = s + psa::kLongChunk < ce ? s + psa::kLongChunk : ce;
+        F2 acc[4], mr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = F2{0.f, 0.f};
+        half_load_mat_row<T, GV>(mat, ent.row, K, k0, kact, mr);
+        half_csc_bw_range<T, LPR, U, GV, MW, SMALL>(row_csc, w_csc, row_scale, grad, grad_value, K, k0, kact, lane, s, e,
+                                                     words, tags, mr, acc);
+        float a8[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          a8[2 * i] = acc[i][0];
+          a8[2 * i + 1] = acc[i][1];
+        }
+        psa::fold_lane_groups<LPR, 8>(a8);
+        if (g == 0 && kact) {
+          float* dst = part + static_cast<int64_t>(ch) * K + k0;
+          *reinterpret_cast<float4*>(dst) = make_float4(a8[0], a8[1], a8[2], a8[3]);
+          *reinterpret_cast<float4*>(dst + 4) = make_float4(a8[4], a8[5], a8[6], a8[7]);
+        }
+      }
+      return;
+    }
   }
+  int64_t rb = static_cast<int64_t>(blockIdx.x) - (FUSED ? chunk_blocks : 0);
+  if (mix_xcds) rb ^= static_cast<int64_t>((static_cast<uint32_t>(rb >> 3) * 0x9E3779B1u) >> 29);
+  const int64_t c = rb * kWaves + wave;
+  if (c >= N) return;
+  const int64_t s = colptr[c], e = colptr[c + 1];
+  if (FUSED && e - s > psa::kLongRow) return;  // wave-uniform: a chunk wave's work (listed by the pre-pass)
   // sums and products as pairs: v_pk_fma_f32 does two fp32 FMAs per issue slot, and a wave64 VALU
   // instruction takes 4 issue cycles on this chip — with ~10 entries per column the pass is bound by
   // instruction issue, not by bytes (profiles/r03_half_train_step.txt)
@@ -494,7 +531,7 @@ spmm_half_csc_bw_kernel(const int64_t* __restrict__ colptr, const int64_t* __res
     a8[2 * i] = acc[i][0];
     a8[2 * i + 1] = acc[i][1];
   }
-  psa::fold_lane_groups<LPR, 8>(a8);  // the lane groups' sums: permlane swaps / DPP, the bits of the xor shuffles
+  psa::fold_lane_groups<LPR, 8>(a8);  // the lane groups' sums (lane_fold.h), the bits of the xor shuffles
   if (g == 0 && kact) {
     const uint4 packed = narrow8<T>(a8);
     typedef unsigned int U4 __attribute__((ext_vector_type(4)));
@@ -504,51 +541,6 @@ spmm_half_csc_bw_kernel(const int64_t* __restrict__ colptr, const int64_t* __res
     st[2] = packed.z;
     st[3] = packed.w;
     __builtin_nontemporal_store(st, reinterpret_cast<U4*>(grad_mat + c * K + k0));
-  }
-}
-
-// One wave per 128-entry chunk of a long column (grid-stride over the chunk list): its fp32 partial of
-// grad_mat[c, :] goes to part[chunk, :]; its grad_value entries are final (chunks own disjoint entries).
-template <typename T, int LPR, int U, bool GV, int MW, bool SMALL>
-__global__ void __launch_bounds__(psa::kLongThreads)
-spmm_half_csc_bw_chunk_kernel(const int64_t* __restrict__ colptr, const int64_t* __restrict__ row_csc,
-                              const float* __restrict__ w_csc, const float* __restrict__ row_scale,
-                              const uint16_t* __restrict__ mat, const uint16_t* __restrict__ grad,
-                              float* __restrict__ grad_value, int64_t K, const uint8_t* __restrict__ words,
-                              const uint8_t* __restrict__ tags, const unsigned long long* __restrict__ long_ctr,
-                              const psa::LongEntry* __restrict__ long_list, float* __restrict__ part) {
-  const int lane = threadIdx.x & 63;
-  const unsigned long long ctr = *long_ctr;
-  const uint32_t total = static_cast<uint32_t>(ctr & 0xffffffffull);
-  const int ncols = static_cast<int>(ctr >> 32);
-  const int g = lane / LPR;
-  const int l = lane % LPR;
-  const int64_t k0 = static_cast<int64_t>(l) * 8;
-  const bool kact = k0 < K;
-  const uint32_t num_waves = gridDim.x * (blockDim.x >> 6);
-  for (uint32_t ch = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); ch < total; ch += num_waves) {
-    const psa::LongEntry ent = psa::find_long_entry(long_list, ncols, ch);
-    const int64_t cs = colptr[ent.row], ce = colptr[ent.row + 1];
-    const int64_t s = cs + static_cast<int64_t>(ch - ent.first_chunk) * psa::kLongChunk;
-    const int64_t e = s + psa::kLongChunk < ce ? s + psa::kLongChunk : ce;
-    F2 acc[4], mr[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = F2{0.f, 0.f};
-    half_load_mat_row<T, GV>(mat, ent.row, K, k0, kact, mr);
-    half_csc_bw_range<T, LPR, U, GV, MW, SMALL>(row_csc, w_csc, row_scale, grad, grad_value, K, k0, kact, lane, s, e,
-                                                 words, tags, mr, acc);
-    float a8[8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      a8[2 * i] = acc[i][0];
-      a8[2 * i + 1] = acc[i][1];
-    }
-    psa::fold_lane_groups<LPR, 8>(a8);
-    if (g == 0 && kact) {
-      float* dst = part + static_cast<int64_t>(ch) * K + k0;
-      *reinterpret_cast<float4*>(dst) = make_float4(a8[0], a8[1], a8[2], a8[3]);
-      *reinterpret_cast<float4*>(dst + 4) = make_float4(a8[4], a8[5], a8[6], a8[7]);
-    }
   }
 }
 
@@ -696,18 +688,26 @@ size_t half_long_bytes(int64_t K, int64_t nnz) {
   return psa::long_list_bytes(nnz) + psa::align256(sizeof(float) * static_cast<size_t>(psa::max_long_chunks(nnz)) * K);
 }
 
+constexpr int kHalfChunkBlocks = 768;  // workgroups in the chunk role (x 4 waves; the fp32 passes use 768 as well)
+
 template <typename T, int LPR, int U, bool GV, int MW, bool SMALL>
 int launch_half_csc_bw(const int64_t* colptr, const int64_t* row_csc, const float* w_csc, const float* row_scale,
                        const uint16_t* mat, const uint16_t* grad, uint16_t* grad_mat, float* grad_value, int64_t N,
                        int64_t K, hipStream_t s, const uint8_t* words, const uint8_t* tags, const HalfLong& w) {
   const int64_t gx = psa::ceil_div(psa::ceil_div(N, kWaves), 8) * 8;
-  PSA_REQUIRE(gx <= 0x7fffffff, "problem too large for one launch");
-  hipLaunchKernelGGL((spmm_half_csc_bw_kernel<T, LPR, U, GV, MW, SMALL>), dim3(static_cast<unsigned>(gx)), dim3(kThreads), 0, s,
-                     colptr, row_csc, w_csc, row_scale, mat, grad, grad_mat, grad_value, N, K, 1, words, tags, w.ctr, w.list);
-  if (w.list != nullptr) {  // columns above 128 entries: chunk waves, then their partials in chunk order
-    hipLaunchKernelGGL((spmm_half_csc_bw_chunk_kernel<T, LPR, U, GV, MW, SMALL>), dim3(psa::kLongBlocks),
-                       dim3(psa::kLongThreads), 0, s, colptr, row_csc, w_csc, row_scale, mat, grad, grad_value, K, words,
-                       tags, w.ctr, w.list, w.part);
+  PSA_REQUIRE(gx + kHalfChunkBlocks <= 0x7fffffff, "problem too large for one launch");
+  if (w.list == nullptr) {
+    hipLaunchKernelGGL((spmm_half_csc_bw_kernel<T, LPR, U, GV, MW, SMALL, false>), dim3(static_cast<unsigned>(gx)),
+                       dim3(kThreads), 0, s, colptr, row_csc, w_csc, row_scale, mat, grad, grad_mat, grad_value, N, K, 1,
+                       words, tags);
+  } else {  // columns above 128 entries: list pre-pass, both roles in one launch, then the partials in chunk order
+    hipLaunchKernelGGL(psa::find_long_rows_kernel,
+                       dim3(static_cast<unsigned>(psa::ceil_div(N, psa::kFindThreads * psa::kFindIters))),
+                       dim3(psa::kFindThreads), 0, s, colptr, N, w.ctr, w.list);
+    hipLaunchKernelGGL((spmm_half_csc_bw_kernel<T, LPR, U, GV, MW, SMALL, true>),
+                       dim3(static_cast<unsigned>(gx + kHalfChunkBlocks)), dim3(kThreads), 0, s, colptr, row_csc, w_csc,
+                       row_scale, mat, grad, grad_mat, grad_value, N, K, 1, words, tags, w.ctr, w.list, w.part,
+                       kHalfChunkBlocks);
     hipLaunchKernelGGL((spmm_half_csc_bw_combine_kernel<T>), dim3(psa::kLongBlocks), dim3(psa::kLongThreads), 0, s, K,
                        w.ctr, w.list, w.part, grad_mat);
   }
