@@ -428,12 +428,22 @@ __device__ __forceinline__ void half_csc_bw_range(const int64_t* __restrict__ ro
         // in the VALU): lane l < U of group g then holds the dot of edge slot j + l * G + g; the lane that
         // loaded that edge (lane == slot) keeps it for one 256-byte store per 64-edge batch
         psa::fold_group_dots<LPR, U>(dot, l);
-        const unsigned rel = static_cast<unsigned>(lane - j);
-        const float got = __shfl(dot[0], static_cast<int>(((rel % G) * LPR + rel / G) & 63u));
-        if (rel < static_cast<unsigned>(G * U)) gv_keep = got;
+        if constexpr (MW != 0) {
+          // masked form (94 VGPRs, 5 waves per SIMD): the lanes that hold the dots store them themselves — 4-byte
+          // stores in G * U pieces per step instead of one 256-byte store per batch, but no hand-over shuffle and
+          // no value kept across the steps: spmm_max bf16 step 3.39 -> 3.20 ms (the sum form gains nothing from it)
+          if (l < U) {
+            const int idx = j + l * G + g;
+            if (idx < n) grad_value[base + idx] = dot[0];
+          }
+        } else {
+          const unsigned rel = static_cast<unsigned>(lane - j);
+          const float got = __shfl(dot[0], static_cast<int>(((rel % G) * LPR + rel / G) & 63u));
+          if (rel < static_cast<unsigned>(G * U)) gv_keep = got;
+        }
       }
     }
-    if (GV && lane < n) __builtin_nontemporal_store(gv_keep * s_l, grad_value + base + lane);
+    if (GV && MW == 0 && lane < n) __builtin_nontemporal_store(gv_keep * s_l, grad_value + base + lane);
   }
 }
 
