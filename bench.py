@@ -492,8 +492,9 @@ def main(argv=None) -> None:
                                                            "instead of the block's per-matrix plan")
     args = ap.parse_args(argv)
 
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # typed without a launcher: become the launcher (before anything initialises the GPU in this process)
+    if args.gpus > 1 and "LOCAL_RANK" not in os.environ and os.environ.get("WORLD_SIZE", "1") != str(args.gpus):
+        # typed without a launcher (torch.distributed.run gives every rank LOCAL_RANK; a stray WORLD_SIZE=1 in the
+        # environment is not one): become the launcher, before anything initialises the GPU in this process
         raise SystemExit(self_launch(args, argv))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -80,3 +80,13 @@ def test_two_result_lines_is_an_error(tmp_path):
 def test_a_child_past_the_limit_is_stopped_and_reported(tmp_path):
     p, _ = run_parent(tmp_path, ["--gpus", "2"], STUB_GPUS=2, STUB_SLEEP=30, PSA_BENCH_LAUNCH_TIMEOUT=1)
     assert p.returncode == 124 and "ran past" in p.stderr and p.stdout.strip() == ""
+
+
+def test_a_stray_world_size_of_one_is_not_a_launcher(tmp_path):
+    """WORLD_SIZE=1 exported by some environment, no LOCAL_RANK: still typed without a launcher."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK")}
+    env.update(PYTHONPATH=str(STUB), STUB_RECORD=str(tmp_path / "argv.json"), STUB_GPUS="4", WORLD_SIZE="1")
+    p = subprocess.run([sys.executable, "-c", RUNNER.format(bench=str(ROOT / "bench.py")), "--gpus", "4"],
+                       capture_output=True, text=True, env=env, timeout=120)
+    assert p.returncode == 0, p.stderr
+    assert json.loads((tmp_path / "argv.json").read_text())["argv"][2] == "4"
