@@ -599,9 +599,11 @@ int psa_coalesce_write(const void* value, int dtype, int64_t D, int64_t n, int64
         return PSA_ERR_UNSUPPORTED;
     }
   }
+  const bool rode = rides(value, dtype, D);
+  if (rode && (dtype == PSA_F32 || dtype == PSA_I32))  // index and reduced values in one launch
+    return psa::unique_write_reduce_packed(reduce, dtype, w.b, n, N, w.uniq_ws, w.status, index_out, w.perm, value_out, s);
   int st = psa::unique_write_packed(w.b, n, N, w.uniq_ws, w.status, w.ptr, index_out, s);
   if (st != PSA_OK || value == nullptr || D == 0) return st;
-  const bool rode = rides(value, dtype, D);
   return psa::segment_reduce_dev(reduce, dtype, rode ? static_cast<const void*>(w.perm) : value,
                                  rode ? nullptr : w.perm, w.ptr, bound, w.status, D, 0, value_out, s);
 }

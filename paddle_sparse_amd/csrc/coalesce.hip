@@ -197,6 +197,62 @@ segment_reduce_kernel(const T* __restrict__ src, const int64_t* __restrict__ per
   Acc<T>::store(out + g, acc);
 }
 
+// unique_write_kernel (packed index, no ptr) and segment_reduce_kernel in one launch, for 4-byte values that rode
+// the sort as its payload: the thread that writes a distinct (row, col) pair also reduces the pair's run of the sorted
+// payload — sequentially, in run order, i.e. with segment_reduce_kernel's order and bits.  Runs average 1.05 entries on
+// the inputs this is for; a heavily duplicated input serialises on its few long runs exactly as the thread-per-segment
+// reducer does (the run count is not known to the host when the launch is enqueued, so that is the reducer it gets).
+// One launch and one ptr array (8 bytes per entry written and read) less per coalesce.
+template <typename T, int RED>
+__global__ void __launch_bounds__(kThreads)
+unique_write_reduce_kernel(const int64_t* __restrict__ keys, int64_t n, int64_t N,
+                           const uint32_t* __restrict__ block_offsets, const int64_t* __restrict__ count,
+                           int64_t* __restrict__ row_out, const T* __restrict__ payload, T* __restrict__ out) {
+  using A = typename Acc<T>::type;
+  __shared__ uint32_t wsum[kWaves];
+  int64_t* col_out = row_out + *count;  // [2, count] index: the col row follows the row row
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const int64_t chunk = static_cast<int64_t>(blockIdx.x) * kTile + wave * (kItems * 64);
+  HeadScan hs(keys, n, chunk, lane);
+  unsigned long long masks[kItems];
+  int64_t key[kItems];
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int j = 0; j < kItems; ++j) {
+    int64_t i;
+    masks[j] = hs.row(j, key[j], i);
+    cnt += static_cast<uint32_t>(__popcll(masks[j]));
+  }
+  if (lane == 0) wsum[wave] = cnt;
+  __syncthreads();
+  uint32_t base = block_offsets[blockIdx.x];
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+#pragma unroll
+  for (int j = 0; j < kItems; ++j) {
+    const int64_t i = chunk + static_cast<int64_t>(j) * 64 + lane;
+    if ((masks[j] >> lane) & 1ull) {
+      const int64_t s = static_cast<int64_t>(base) + __popcll(masks[j] & lt_mask);
+      const int64_t r = key[j] / N;
+      row_out[s] = r;
+      col_out[s] = key[j] - r * N;
+      A acc = Acc<T>::load(payload + i);
+      int64_t k = i + 1;
+      while (k < n && keys[k] == key[j]) {
+        const A x = Acc<T>::load(payload + k);
+        if (RED == R_MIN) acc = x < acc ? x : acc;
+        else if (RED == R_MAX) acc = x > acc ? x : acc;
+        else acc = acc + x;
+        ++k;
+      }
+      if (RED == R_MEAN) acc = mean_div<A>(acc, k - i);
+      Acc<T>::store(out + s, acc);
+    }
+    base += static_cast<uint32_t>(__popcll(masks[j]));
+  }
+}
+
 // One wave per segment, D == 1, for long segments (row reductions of skewed
 // matrices): lanes stride the segment, shuffle tree at the end.
 template <typename T, int RED>
@@ -309,6 +365,32 @@ int unique_write_packed(const int64_t* sorted_keys, int64_t n, int64_t N, const 
   hipLaunchKernelGGL(unique_write_kernel, dim3(static_cast<unsigned>(nb)), dim3(kThreads), 0, s, sorted_keys, n, N,
                      static_cast<const uint32_t*>(workspace), count, ptr_out, index_out,
                      static_cast<int64_t*>(nullptr), 1);
+  PSA_LAUNCH_CHECK();
+  return PSA_OK;
+}
+
+int unique_write_reduce_packed(int reduce, int dtype, const int64_t* sorted_keys, int64_t n, int64_t N,
+                               const void* workspace, const int64_t* count, int64_t* index_out, const void* payload,
+                               void* value_out, hipStream_t s) {
+  PSA_REQUIRE(n > 0 && N > 0, "empty input");
+  PSA_REQUIRE(sorted_keys && workspace && count && index_out && payload && value_out, "NULL pointer");
+  PSA_REQUIRE(dtype == PSA_F32 || dtype == PSA_I32, "the fused write takes 4-byte values that rode the sort");
+  const dim3 grid(static_cast<unsigned>(ceil_div(n, kTile))), block(kThreads);
+  const uint32_t* bo = static_cast<const uint32_t*>(workspace);
+#define PSA_UWR(T, R)                                                                                             \
+  hipLaunchKernelGGL((unique_write_reduce_kernel<T, R>), grid, block, 0, s, sorted_keys, n, N, bo, count, index_out, \
+                     static_cast<const T*>(payload), static_cast<T*>(value_out))
+#define PSA_UWR_T(T)                           \
+  do {                                         \
+    if (reduce == PSA_SUM) PSA_UWR(T, R_SUM);  \
+    else if (reduce == PSA_MEAN) PSA_UWR(T, R_MEAN); \
+    else if (reduce == PSA_MIN) PSA_UWR(T, R_MIN);   \
+    else PSA_UWR(T, R_MAX);                    \
+  } while (0)
+  if (dtype == PSA_F32) PSA_UWR_T(float);
+  else PSA_UWR_T(int32_t);
+#undef PSA_UWR_T
+#undef PSA_UWR
   PSA_LAUNCH_CHECK();
   return PSA_OK;
 }

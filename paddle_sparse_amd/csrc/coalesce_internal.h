@@ -13,6 +13,13 @@ namespace psa {
 int unique_write_packed(const int64_t* sorted_keys, int64_t n, int64_t N, const void* workspace,
                         const int64_t* count, int64_t* ptr_out, int64_t* index_out, hipStream_t s);
 
+// unique_write_packed and segment_reduce_dev in ONE launch for 4-byte values (PSA_F32 / PSA_I32) that rode the sort as its
+// payload: the thread that
+// writes a distinct pair reduces its run of `payload` (sorted order) into value_out; no ptr array.
+int unique_write_reduce_packed(int reduce, int dtype, const int64_t* sorted_keys, int64_t n, int64_t N,
+                               const void* workspace, const int64_t* count, int64_t* index_out, const void* payload,
+                               void* value_out, hipStream_t s);
+
 // psa_segment_reduce whose segment count lives on the device: the grid is sized
 // for nseg_bound segments, segments at or beyond *nseg_dev are skipped.
 int segment_reduce_dev(int reduce, int dtype, const void* src, const int64_t* perm,
