@@ -677,6 +677,18 @@ int psa_unique_write(const int64_t* sorted_keys, int64_t n, int64_t N,
                      int64_t* ptr_out, int64_t* row_out, int64_t* col_out,
                      psa_stream_t stream);
 
+/* psa_unique_write (packed index, no ptr) and psa_segment_reduce in ONE launch, for 4-byte values
+ * (PSA_F32 / PSA_I32) that are in SORTED order already — they rode the sort as its payload
+ * (psa_sort_pairs_u32) or the input was sorted: index_out int64[2 * count] = the distinct rows, then the
+ * distinct columns (the [2, nnz'] index of coalesce.py:29); value_out[count] = the reduction of every run
+ * of equal keys, taken sequentially in run order (psa_segment_reduce's order and bits).  The thread that
+ * writes a pair reduces its run: meant for inputs whose runs are short (count * 32 > n); a heavily
+ * duplicated input is better served by psa_unique_write + psa_segment_reduce, whose reducer then takes a
+ * wave per run.  Other dtypes: PSA_ERR_UNSUPPORTED. */
+int psa_unique_write_reduce(int reduce, int dtype, const int64_t* sorted_keys, int64_t n, int64_t N,
+                            const void* workspace, const int64_t* count, int64_t* index_out,
+                            const void* payload, void* value_out, psa_stream_t stream);
+
 /* out[s, :] = REDUCE_{i in [ptr[s], ptr[s+1])} src[perm ? perm[i] : i, :]
  * for src rows of D elements of `dtype` (psa_dtype).  Stands in for
  * paddle_scatter.segment_csr at storage.py:471 (with perm = the sort

@@ -692,6 +692,44 @@ PD_BUILD_OP(unique_sorted)
     .Attrs({"N: int64_t"})
     .SetKernelFn(PD_KERNEL(unique_sorted));
 
+// unique_sorted + segment_csr for 4-byte scalar values already in the keys' sorted order (they rode the sort as its
+// payload): the [2, count] index and the reduced values; one launch for both when the runs are short (count * 32 > n),
+// else psa_unique_write + psa_segment_reduce (a wave per run) — as paddle_sparse_amd/ops.py::unique_sorted_reduce
+std::vector<paddle::Tensor> unique_sorted_reduce(paddle::Tensor& sorted_keys, paddle::Tensor& payload, int64_t N,
+                                                 int64_t reduce) {
+  CHECK_GPU(sorted_keys);
+  CHECK_I64(sorted_keys);
+  const int64_t n = sorted_keys.numel();
+  PD_CHECK(payload.numel() == n && (payload.dtype() == paddle::DataType::FLOAT32 || payload.dtype() == paddle::DataType::INT32),
+           "unique_sorted_reduce: payload must be float32[n] or int32[n]");
+  const auto place = sorted_keys.place();
+  void* s = stream_of(sorted_keys);
+  const size_t ws_bytes = psa_unique_workspace_bytes(n);
+  auto ws = scratch(ws_bytes, place);
+  auto count = i64_empty(1, place);
+  PSA_CALL(psa_unique_count(i64(sorted_keys), n, ws.data<uint8_t>(), ws_bytes, count.data<int64_t>(), s));
+  const int64_t distinct = read_i64(count, 0, 1)[0];
+  auto index = paddle::empty({2, distinct}, paddle::DataType::INT64, place);
+  auto value = paddle::empty({distinct}, payload.dtype(), place);
+  if (n == 0) return {index, value};
+  if (distinct < n && distinct * 32 > n) {
+    PSA_CALL(psa_unique_write_reduce(static_cast<int>(reduce), dtype_id_of(payload), i64(sorted_keys), n, N, ws.data<uint8_t>(),
+                                     i64(count), index.data<int64_t>(), payload.data(), value.data(), s));
+    return {index, value};
+  }
+  auto ptr = i64_empty(distinct + 1, place);
+  PSA_CALL(psa_unique_write(i64(sorted_keys), n, N, ws.data<uint8_t>(), i64(count), ptr.data<int64_t>(),
+                            index.data<int64_t>(), index.data<int64_t>() + distinct, s));
+  PSA_CALL(psa_segment_reduce(static_cast<int>(reduce), dtype_id_of(payload), payload.data(), nullptr, ptr.data<int64_t>(),
+                              distinct, 1, n, value.data(), s));
+  return {index, value};
+}
+PD_BUILD_OP(unique_sorted_reduce)
+    .Inputs({"sorted_keys", "payload"})
+    .Outputs({"index", "value"})
+    .Attrs({"N: int64_t", "reduce: int64_t"})
+    .SetKernelFn(PD_KERNEL(unique_sorted_reduce));
+
 // scatter: paddle_scatter.scatter(src, index, 0, None, dim_size, reduce) of reduce.py:42
 std::vector<paddle::Tensor> scatter(paddle::Tensor& src, paddle::Tensor& index, int64_t dim_size, int64_t reduce) {
   CHECK_GPU(src);

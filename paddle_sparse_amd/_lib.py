@@ -119,6 +119,8 @@ SIGNATURES = {
     "psa_unique_count": (c_int, [c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_void_p]),
     "psa_unique_write": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p]),
+    "psa_unique_write_reduce": (c_int, [c_int, c_int, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p]),
     "psa_segment_reduce": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64,
                                    c_int64, c_int64, c_void_p, c_void_p]),
     "psa_scatter_workspace_bytes": (c_size_t, [c_int64]),

@@ -48,6 +48,14 @@ def _coalesce_sorted_stream(row, col, value, m: int, n: int, op: str):
             keys, value, scratch = ops.sort_pairs(keys, value, m * n, keep_scratch=True)
         else:
             keys, perm, scratch = ops.index_sort(keys, m * n, with_sorted_inputs=True, keep_scratch=True)
+    if (value is not None and perm is None and value.dim() == 1 and value.dtype in (torch.float32, torch.int32)
+            and not ops.needs_grad(value)):
+        # values in sorted order (they rode the sort, or the input was sorted): index and reduced values from one
+        # launch when the runs are short — no ptr array (24 -> 16 bytes written per distinct entry, 8 fewer read)
+        count, new_row, new_col, value_out = ops.unique_sorted_reduce(keys, n, value, op, after=scratch)
+        if count == nnz and was_sorted:
+            return row, col, value
+        return new_row, new_col, value_out
     # the count read below also brings back the sort's look-back diagnostic
     count, ptr, new_row, new_col = ops.unique_sorted(keys, n, after=scratch)
     if count == nnz and was_sorted:

@@ -491,6 +491,20 @@ int psa_unique_write(const int64_t* sorted_keys, int64_t n, int64_t N,
   return PSA_OK;
 }
 
+int psa_unique_write_reduce(int reduce, int dtype, const int64_t* sorted_keys, int64_t n, int64_t N,
+                            const void* workspace, const int64_t* count, int64_t* index_out, const void* payload,
+                            void* value_out, psa_stream_t stream) {
+  PSA_REQUIRE(n >= 0, "negative size");
+  PSA_REQUIRE(reduce >= PSA_SUM && reduce <= PSA_MAX, "bad reduce");
+  if (n == 0) return PSA_OK;
+  if (dtype != PSA_F32 && dtype != PSA_I32) {
+    psa::set_error("psa_unique_write_reduce: 4-byte values only (PSA_F32 / PSA_I32); use psa_unique_write + psa_segment_reduce");
+    return PSA_ERR_UNSUPPORTED;
+  }
+  return psa::unique_write_reduce_packed(reduce, dtype, sorted_keys, n, N, workspace, count, index_out, payload, value_out,
+                                         psa::as_stream(stream));
+}
+
 int psa_segment_reduce(int reduce, int dtype, const void* src,
                        const int64_t* perm, const int64_t* ptr, int64_t nseg,
                        int64_t D, int64_t n_hint, void* out,

@@ -814,17 +814,10 @@ def _segment_csr_raw(src: torch.Tensor, indptr: torch.Tensor, reduce: str = "sum
     return out
 
 
-def unique_sorted(sorted_keys: torch.Tensor, N: int, want_ptr: bool = True,
-                  want_rowcol: bool = True, after: Optional[SortScratch] = None):
-    """Run-length structure of SORTED keys (storage.py:455-470 without the
-    bool-mask selects).  Returns (count, ptr | None, row | None, col | None)
-    with row = key // N, col = key % N of each distinct key.  One host sync
-    (reading the count to size the outputs) — the reference has three.
-    after: the SortScratch of the sort that produced the keys; its look-back
-    diagnostic comes back with the count (HipCoreError if a wait gave up)."""
-    sorted_keys = _index(sorted_keys, "sorted_keys")
-    n = sorted_keys.numel()
-    dev = sorted_keys.device
+def _unique_count(sorted_keys: torch.Tensor, after: Optional["SortScratch"]):
+    """Phase 1 of unique_sorted: run heads counted per block and scanned; the ONE host read of the count (with the
+    preceding sort's look-back diagnostic when `after` is given).  Returns (count, scratch, device count word)."""
+    n, dev = sorted_keys.numel(), sorted_keys.device
     lib = _lib.load()
     ws = _workspace(lib.psa_unique_workspace_bytes(n), dev)
     count_d = torch.empty(2, dtype=torch.int64, device=dev)
@@ -838,6 +831,23 @@ def unique_sorted(sorted_keys: torch.Tensor, N: int, want_ptr: bool = True,
         else:
             check(lib.psa_unique_count(_ptr(sorted_keys), n, _ptr(ws), ws.numel(), _ptr(count_d), _stream()))
             count = int(count_d[0].item())
+    return count, ws, count_d
+
+
+def unique_sorted(sorted_keys: torch.Tensor, N: int, want_ptr: bool = True,
+                  want_rowcol: bool = True, after: Optional[SortScratch] = None, _counted=None):
+    """Run-length structure of SORTED keys (storage.py:455-470 without the
+    bool-mask selects).  Returns (count, ptr | None, row | None, col | None)
+    with row = key // N, col = key % N of each distinct key.  One host sync
+    (reading the count to size the outputs) — the reference has three.
+    after: the SortScratch of the sort that produced the keys; its look-back
+    diagnostic comes back with the count (HipCoreError if a wait gave up)."""
+    sorted_keys = _index(sorted_keys, "sorted_keys")
+    n = sorted_keys.numel()
+    dev = sorted_keys.device
+    lib = _lib.load()
+    count, ws, count_d = _counted if _counted is not None else _unique_count(sorted_keys, after)
+    with _on(dev):
         ptr = torch.empty(count + 1, dtype=torch.int64, device=dev) if want_ptr else None
         # row and col are the two rows of ONE [2, count] buffer, so the
         # functional API's `stack([row, col])` (coalesce.py:29) is `row._base`
@@ -850,6 +860,31 @@ def unique_sorted(sorted_keys: torch.Tensor, N: int, want_ptr: bool = True,
         elif want_ptr:
             ptr.zero_()
     return count, ptr, row, col
+
+
+def unique_sorted_reduce(sorted_keys: torch.Tensor, N: int, payload: torch.Tensor, reduce: str = "sum",
+                         after: Optional[SortScratch] = None):
+    """unique_sorted + segment_csr for 4-byte scalar values that are in the keys' sorted order already (they rode the
+    sort as its payload, or the input was sorted): returns (count, row, col, value') with value'[s] = the reduction of
+    run s.  When the runs are short (count * 32 > n) the index and the reduced values come from ONE launch and no
+    ptr array is written (psa_unique_write_reduce); otherwise the two-launch form, whose reducer takes a wave per run."""
+    sorted_keys = _index(sorted_keys, "sorted_keys")
+    _gpu(payload, "payload")
+    n, dev = sorted_keys.numel(), sorted_keys.device
+    if payload.dim() != 1 or payload.numel() != n or payload.dtype not in (torch.float32, torch.int32):
+        raise ValueError("payload must be float32[n] or int32[n]")
+    counted = _unique_count(sorted_keys, after)
+    count, ws, count_d = counted
+    if 0 < count < n and count * 32 > n:
+        payload = payload.contiguous()
+        index = torch.empty((2, count), dtype=torch.int64, device=dev)
+        value = torch.empty(count, dtype=payload.dtype, device=dev)
+        with _on(dev):
+            check(_lib.load().psa_unique_write_reduce(REDUCE_ID[reduce], _DTYPE_ID[payload.dtype], _ptr(sorted_keys), n, int(N),
+                                                      _ptr(ws), _ptr(count_d), _ptr(index), _ptr(payload), _ptr(value), _stream()))
+        return count, index[0], index[1], value
+    count, ptr, row, col = unique_sorted(sorted_keys, N, want_ptr=count < n, _counted=counted)
+    return count, row, col, (payload if count == n else _segment_csr_raw(payload, ptr, reduce))
 
 
 # ---------------------------------------------------------------------------
