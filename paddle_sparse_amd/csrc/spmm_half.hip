@@ -424,8 +424,8 @@ __device__ __forceinline__ void half_csc_bw_range(const int64_t* __restrict__ ro
         dot[u] = d2[0] + d2[1];
       }
       if constexpr (GV) {
-        // fold the U partial dots of the lane group transposing as it goes (lane_fold.h: DPP / permlane moves
-        // in the VALU): lane l < U of group g then holds the dot of edge slot j + l * G + g; the lane that
+        // fold the U partial dots of the lane group transposing as it goes (lane_fold.h: DPP operands of the adds,
+        // ds_bpermute for 16 / 32): lane l < U of group g then holds the dot of edge slot j + l * G + g; the lane that
         // loaded that edge (lane == slot) keeps it for one 256-byte store per 64-edge batch
         psa::fold_group_dots<LPR, U>(dot, l);
         if constexpr (MW != 0) {

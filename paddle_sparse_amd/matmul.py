@@ -129,8 +129,10 @@ class _SpMM(torch.autograd.Function):
                 storage: SparseStorage, reduce: str, track: bool = True):
         rowptr, col = storage.rowptr(), storage.col()
         if mat.dtype in (torch.float16, torch.bfloat16):
-            # half-width dense operand: 2-byte gathers and stores, fp32 sums (psa_spmm_half).  The
-            # backward runs the fp32 kernels on widened operands and narrows the gradients.
+            # half-width dense operand: 2-byte gathers and stores, fp32 sums (psa_spmm_half / psa_spmm_half_coo).
+            # The backward stays half width too — the forward over the CSC view (fixed adjacency), one pass over
+            # it for both gradients (trained values), the masked pass for min / max — and widens to fp32 only for
+            # what those do not take: K % 8 != 0, K > 512, rows above 65 535 entries with min / max.
             need = track and (ctx.needs_input_grad[1] or (value is not None and ctx.needs_input_grad[0]))
             algo, row, hot_rows = "auto", None, None
             if mat.shape[1] % 8 == 0 and (value is None or value.dtype == torch.float32) and storage._spmm_algo() == "edge_ranges":
