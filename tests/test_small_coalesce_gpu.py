@@ -201,3 +201,87 @@ def test_chain_replays_from_a_hip_graph():
             e_i, e_v, _ = ops.coalesce_chain(row, col, val, M, N, "add")
             assert count == e_i.shape[1]
             assert torch.equal(index[:2 * count].view(2, count), e_i) and torch.equal(out[:count], e_v)
+
+
+# ---- above the chain's limit (2^20 entries): keys -> pair sort -> run lengths -> ONE launch for index + reduced values ----
+
+@pytest.mark.parametrize("op", ["add", "mean", "min", "max"])
+@pytest.mark.parametrize("npdtype", [np.float32, np.int32])
+@pytest.mark.parametrize("shape", ["short runs", "long runs", "no duplicates", "sorted input with duplicates"])
+def test_coalesce_above_the_chain_limit_equals_the_oracle(op, npdtype, shape):
+    """coalesce() of 1.2 M entries (the Python-level path: psa_make_keys_checked, psa_sort_pairs_u32,
+    psa_unique_count_after_sort, then psa_unique_write_reduce — index and reduced values from one launch, no ptr array —
+    when the runs are short, psa_unique_write + psa_segment_reduce when they are long) against the numpy oracle, bit for
+    bit: sums of a run are taken in run order by both forms."""
+    import paddle_sparse_amd as ps
+    from paddle_sparse_amd import ops
+
+    n = 1_200_000
+    rng = np.random.default_rng(len(shape) + len(op))
+    if shape == "short runs":
+        M, N = 3000, 3500
+        row, col = rng.integers(0, M, n), rng.integers(0, N, n)
+    elif shape == "long runs":  # 6 000 distinct pairs: 200 entries per run, the wave-per-run reducer
+        M, N = 60, 100
+        row, col = rng.integers(0, M, n), rng.integers(0, N, n)
+    elif shape == "no duplicates":
+        M, N = 2000, 1000
+        key = rng.permutation(M * N)[:n]
+        row, col = key // N, key % N
+    else:
+        M, N = 3000, 3500
+        key = np.sort(rng.integers(0, M * N, n))
+        row, col = key // N, key % N
+    val = rng.integers(-9, 10, n).astype(npdtype)
+    if npdtype is np.float32 and op != "mean":
+        val = val + rng.random(n).astype(np.float32)  # fp32 sums in run order: the same order on both sides
+    index = np.stack([row, col])
+    ref_i, ref_v = so.coalesce(index, val, M, N, op)
+    called = []
+    real = ops.unique_sorted_reduce
+    ops.unique_sorted_reduce = lambda *a, **k: called.append(1) or real(*a, **k)
+    try:
+        got_i, got_v = ps.coalesce(idx(index), torch.from_numpy(val).cuda(), M, N, op)
+    finally:
+        ops.unique_sorted_reduce = real
+    assert called == [1]
+    assert np.array_equal(got_i.cpu().numpy(), ref_i)
+    if npdtype is np.float32 and op in ("mean", "add"):
+        # at this size the oracle reduces with ufunc.reduceat, whose order inside a run is its own: a tolerance here,
+        # the run-order bits in test_unique_sorted_reduce_sums_in_run_order below
+        _, S = so.coalesce(index, np.abs(val), M, N, op)  # the fp32 bar of the path: 1e-5 * sum |terms| of the run
+        assert np.all(np.abs(got_v.cpu().numpy() - ref_v) <= 1e-5 * S + 1e-30)
+    else:
+        assert np.array_equal(got_v.cpu().numpy(), ref_v)
+
+
+@pytest.mark.parametrize("op", ["add", "mean"])
+def test_unique_sorted_reduce_sums_in_run_order(op):
+    """The one-launch form adds a run's values sequentially, in run order — the bits of the oracle's sequential
+    segment_csr (and of psa_segment_reduce's thread-per-segment kernel)."""
+    from paddle_sparse_amd import ops
+
+    rng = np.random.default_rng(3)
+    n, N = 200_000, 300
+    keys = np.sort(rng.integers(0, 60_000, n))  # runs of ~3.3 entries
+    val = (rng.integers(-9, 10, n) + rng.random(n)).astype(np.float32)
+    count, row, col, out = ops.unique_sorted_reduce(idx(keys), N, torch.from_numpy(val).cuda(), op)
+    uniq, start = np.unique(keys, return_index=True)
+    ref = so.segment_csr(val, np.concatenate([start, [n]]), op)
+    assert count == uniq.size and np.array_equal(out.cpu().numpy(), ref)
+    assert np.array_equal(row.cpu().numpy(), uniq // N) and np.array_equal(col.cpu().numpy(), uniq % N)
+
+
+def test_unique_sorted_reduce_edge_cases():
+    from paddle_sparse_amd import ops
+
+    for keys, N in (([5], 3), ([0, 0, 0, 0], 1), ([1, 1, 2, 2, 2, 9], 4), (list(range(100)), 10)):
+        k = np.asarray(keys, np.int64)
+        v = np.arange(1, k.size + 1, dtype=np.float32)
+        count, row, col, out = ops.unique_sorted_reduce(idx(k), N, torch.from_numpy(v).cuda(), "sum")
+        uniq, start = np.unique(k, return_index=True)
+        assert count == uniq.size
+        assert np.array_equal(row.cpu().numpy(), uniq // N) and np.array_equal(col.cpu().numpy(), uniq % N)
+        assert np.array_equal(out.cpu().numpy(), np.add.reduceat(v, start))
+    with pytest.raises(ValueError):
+        ops.unique_sorted_reduce(idx([1, 2]), 3, torch.zeros(2, dtype=torch.float64, device="cuda"))
