@@ -351,8 +351,9 @@ int psa_spmm_value_bw(int reduce, const int64_t* rowptr, const int64_t* col,
   if (v4) {
     const int64_t q = K / 4;
     if (q <= 4) PSA_VBW(4, 4, 1);
-    if (q <= 8) PSA_VBW(4, 8, 1);
-    if (q <= 16) PSA_VBW(4, 16, 2);
+    // 16 edges per step at every width (the single-tile form has the registers for it): K = 32 0.71 -> 0.65 ms at config-3 size
+    if (q <= 8) PSA_VBW(4, 8, 2);
+    if (q <= 16) PSA_VBW(4, 16, 4);
     // K = 128: 16 gathers in flight per wave (the single-tile form needs 37 VGPRs at U = 4, so 8 waves per SIMD stay):
     // 1.85 -> 1.62 ms at config 3 (profiles/r04_fold_ab.txt)
     if (q <= 32) PSA_VBW(4, 32, 8);
