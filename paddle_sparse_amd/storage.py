@@ -521,12 +521,19 @@ class SparseStorage(object):
             return self
         N = self._sparse_sizes[1]
         keys, _ = ops.make_keys(self.row(), self._col, N)
-        count, ptr, row, col = ops.unique_sorted(keys, N)
-        if count == nnz:  # already coalesced (storage.py:459)
-            return self
         value = self._value
-        if value is not None:
-            value = ops.segment_csr(value, ptr, reduce)
+        if (value is not None and value.dim() == 1 and value.dtype in (torch.float32, torch.int32)
+                and not ops.needs_grad(value)):
+            # 4-byte scalar values of a sorted storage: index and reduced values from one launch, no ptr array
+            count, row, col, value = ops.unique_sorted_reduce(keys, N, value, reduce)
+            if count == nnz:
+                return self
+        else:
+            count, ptr, row, col = ops.unique_sorted(keys, N)
+            if count == nnz:  # already coalesced (storage.py:459)
+                return self
+            if value is not None:
+                value = ops.segment_csr(value, ptr, reduce)
         return SparseStorage(row=row, col=col, value=value, sparse_sizes=self._sparse_sizes,
                              is_sorted=True, trust_data=True)
 
