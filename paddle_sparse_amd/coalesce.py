@@ -84,6 +84,10 @@ def _coalesce_two_sorted(row_a, col_a, value_a, row_b, col_b, value_b, n: int, o
     keys, source, value = ops.merge_sorted(keys_a, keys_b, value_a.contiguous() if rides else None,
                                            value_b.contiguous() if rides else None,
                                            want_source=has_value and not rides)
+    if rides and value.dtype in (torch.float32, torch.int32):
+        # merged values are in key order already: index and reduced values from one launch, no ptr array
+        _, row, col, value = ops.unique_sorted_reduce(keys, n, value, op)
+        return row, col, value
     count, ptr, row, col = ops.unique_sorted(keys, n)
     if not has_value:
         return row, col, None
