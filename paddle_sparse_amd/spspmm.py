@@ -58,6 +58,10 @@ def _spspmm_csr(rowA, colA, valueA, rowptrB, colB, valueB, m: int, n: int):
         perm = None
     else:
         keys, perm, scratch = ops.index_sort(keys, m * n, with_sorted_inputs=True, keep_scratch=True)
+    if vals is not None and perm is None and vals.dtype in (torch.float32, torch.int32):
+        # products in key order: index and summed values from one launch, no ptr array
+        _, row, col, vals = ops.unique_sorted_reduce(keys, n, vals, "sum", after=scratch)
+        return row, col, vals
     count, ptr, row, col = ops.unique_sorted(keys, n, after=scratch)  # the sort's fault word rides the count
     if vals is not None:
         if count < total:
@@ -93,6 +97,9 @@ def _spspmm_by_column(a, b):
                                    owner, total, -1, dtype)
     del owner, offsets, counts
     keys, vals, scratch = ops.sort_pairs_field(keys, vals, 32, m, keep_scratch=True)
+    if vals.dtype in (torch.float32, torch.int32):  # index and summed values from one launch, no ptr array
+        _, row, col, vals = ops.unique_sorted_reduce(keys, 1 << 32, vals, "sum", after=scratch)
+        return row, col, vals
     count, ptr, row, col = ops.unique_sorted(keys, 1 << 32, after=scratch)
     if count < total:
         vals = ops.segment_csr(vals, ptr, "sum")
