@@ -51,3 +51,33 @@ print("max backward, one CSC pass vs atomics: max |d grad_mat| =", float((gm_c -
       " max |d grad_value| =", float((gv_c - gv_a).abs().max()), " (|grad_mat| max", float(gm_a.abs().max()), ")")
 torch.cuda.synchronize()
 print("peak HBM in use: %.1f GB" % (torch.cuda.max_memory_allocated() / 1e9))
+
+# ---- half-width operands of 5.1 GB each (>= 4 GiB: the 64-bit addressing instantiations run for real) ----
+del out, arg, gv_c, gm_c, gv_a, gm_a
+torch.cuda.empty_cache()
+Bh, Gh = B.to(torch.bfloat16), G.to(torch.bfloat16)
+print(f"bf16 operands: {Bh.numel() * 2 / 2**30:.2f} GiB each")
+out_h = ops._spmm("sum", rowptr, col, val, Bh)[0]
+ref_h = ops.spmm_sum(rowptr, col, val, Bh.float())
+mag = ops.spmm_sum(rowptr, col, val.abs(), Bh.float().abs())
+print("bf16 spmm_sum vs the fp32 kernel on the same rounded operand: max err / (2^-8 |ref| + 1e-5 sum|terms|) =",
+      float(((out_h.float() - ref_h).abs() / (2.0 ** -8 * ref_h.abs() + 1e-5 * mag + 1e-30)).max()))
+del ref_h, mag, out_h
+w = ops.gather_rows(val, csr2csc)
+gv_h, gm_h = ops.spmm_half_sum_bw_csc(colptr, row_csc, w, Bh, Gh, True)
+gv_f, gm_f = ops.spmm_sum_bw_csc(colptr, row_csc, csr2csc, val, Bh.float(), Gh.float(), True, csc2csr=csc2csr)
+gv_hc = ops.gather_rows(gv_h, csc2csr)
+mag_m = ops.spmm_sum(colptr, row_csc, w.abs(), Gh.float().abs())
+print("bf16 pass over the CSC view vs the fp32 pass on the rounded operands: grad_mat max err / (2^-8 |ref| + 1e-5 sum|terms|) =",
+      float(((gm_h.float() - gm_f).abs() / (2.0 ** -8 * gm_f.abs() + 1e-5 * mag_m + 1e-30)).max()),
+      " grad_value max |d| / max |ref| =", float((gv_hc - gv_f).abs().max() / gv_f.abs().max()))
+del gm_h, gm_f, gv_h, gv_f, gv_hc, mag_m
+out_m, _, words = ops._spmm("max", rowptr, col, val, Bh, want_arg=False, want_arg_bytes=1)
+ref_m, arg_m = ops.spmm_max(rowptr, col, val, Bh.float())
+deg = rowptr[1:] - rowptr[:-1]
+local = (arg_m - rowptr[:-1, None]).clamp(max=255)
+want = torch.where(arg_m < col.numel(), local, torch.full_like(local, 255)).to(torch.uint8)
+print("bf16 spmm_max: out == rounded fp32 out:", bool(torch.equal(out_m, ref_m.to(torch.bfloat16))),
+      " row-local winners == int64 arg_out's:", bool(torch.equal(words, want)), " (longest row", int(deg.max()), ")")
+torch.cuda.synchronize()
+print("peak HBM in use: %.1f GB" % (torch.cuda.max_memory_allocated() / 1e9))
