@@ -397,6 +397,21 @@ def test_power_law_bf16_training_step_stays_half_width(rmat, reduce):
         ops._spmm = real_spmm
     assert called == [], called
     assert a.storage._csc_view()._longest_row() > 128 and gm_h.dtype == torch.bfloat16 and gv_h.dtype == torch.float32
+    # the same through the allocator: a step on the storage whose plans exist by now peaks at its outputs (out and grad_mat
+    # in bf16: 0.54 GB each at [2 M, 128]) plus nnz-sized arrays and the chunk scratch — far below what fp32 copies of
+    # mat and grad_out (1.07 GB each) and fp32 gradients would add
+    v2 = rmat["val"].clone().requires_grad_(True)
+    Bt2 = Bh.clone().requires_grad_(True)
+    step_input = a.set_value(v2, layout="coo")
+    step_input.matmul(Bt2, reduce).backward(Gh)  # second request: the planned routes get built
+    v2.grad = Bt2.grad = None
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base = torch.cuda.memory_allocated()
+    step_input.matmul(Bt2, reduce).backward(Gh)
+    torch.cuda.synchronize()
+    fp32_dense = size * K * 4
+    assert torch.cuda.max_memory_allocated() - base < 1.9 * fp32_dense, (torch.cuda.max_memory_allocated() - base) / fp32_dense
     _, gv_f, gm_f = run(Bh.float(), Gh.float())  # the fp32 route on the same rounded operands
     # sum of absolute terms (for max: an upper bound — only the winners' terms are summed)
     scale_m = SparseTensor(row=row, rowptr=rowptr, col=col, value=rmat["val"].abs(), sparse_sizes=(size, size), is_sorted=True,
