@@ -90,3 +90,51 @@ def test_backward_passes_over_the_csc_view_replay_from_a_hip_graph():
         torch.cuda.synchronize()
         for got, want in zip(captured, step()):
             assert torch.equal(got, want)
+
+
+def test_half_width_step_with_long_columns_replays_from_a_hip_graph():
+    """Round 4: the half-width passes over the CSC view with the long-column workspace (list pre-pass, the two-role
+    launch, the combine) and the edge-range forward that leaves the row-local arg_out read nothing on the host either:
+    a bf16 forward + backward step — sum and max, hub columns of 3 000 entries — replays from a HIP graph."""
+    from paddle_sparse_amd import SparseStorage, ops
+
+    g = torch.Generator(device="cuda").manual_seed(2)
+    M, N, K = 20_000, 9_000, 64
+    row = torch.randint(0, M, (150_000,), generator=g, device="cuda")
+    col = torch.randint(0, N, (150_000,), generator=g, device="cuda")
+    col[:3000], col[3000:3700] = 7, N - 1  # two long columns of the CSC view
+    key = torch.unique(row * N + col)
+    row, col = torch.div(key, N, rounding_mode="floor"), key % N
+    val = torch.randn(row.numel(), generator=g, device="cuda")
+    st = SparseStorage(row=row, col=col, value=val, sparse_sizes=(M, N), is_sorted=True, trust_data=True)
+    rowptr, colptr, row_csc = st.rowptr(), st.colptr(), st._row_in_csc_order()
+    assert st._csc_view()._longest_row() > 128
+    w = ops.gather_rows(val, st.csr2csc())
+    tags = st._csc_edge_tags(2)
+    coo_row = st.row()
+    B = torch.randn(N, K, generator=g, device="cuda").to(torch.bfloat16)
+    G = torch.randn(M, K, generator=g, device="cuda").to(torch.bfloat16)
+
+    def step():
+        out = ops._spmm("sum", rowptr, col, val, B)[0]
+        gv, gm = ops.spmm_half_sum_bw_csc(colptr, row_csc, w, B, G, True)
+        out_max, _, words = ops._spmm("max", rowptr, col, val, B, want_arg=False, want_arg_bytes=2, row=coo_row,
+                                      algo="edge_ranges")
+        gv2, gm2 = ops.spmm_half_minmax_bw_csc(colptr, row_csc, tags, w, B, G, words)
+        return out, gv, gm, out_max, words, gv2, gm2
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        step()
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        captured = step()
+    for trial in range(3):
+        B.copy_(torch.randn(N, K, generator=g, device="cuda").to(torch.bfloat16))
+        G.copy_(torch.randn(M, K, generator=g, device="cuda").to(torch.bfloat16))
+        graph.replay()
+        torch.cuda.synchronize()
+        for got, want in zip(captured, step()):
+            assert torch.equal(got, want)
