@@ -17,7 +17,7 @@ case $WHAT in
   half)
     for c in "SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE" "SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS"; do
       tag=r04_half_$(echo $c | tr ' ' '_' | cut -c1-24)
-      bash tools/prof_pmc.sh $tag "$c" $REPO/tools/half_train_step_probe.py | grep -A6 "spmm_half_row_kernel<BF16, 16, 0, 4\|spmm_half_csc_bw_kernel<BF16, 16, 4, true" | tee -a gpurun_out/r04_half_pmc.txt
+      bash tools/prof_pmc.sh $tag "$c" $REPO/tools/half_train_step_probe.py | grep -A6 "spmm_half_row_kernel<[a-z_:]*BF16, 16, 0, 4\|spmm_half_csc_bw_kernel<[a-z_:]*BF16, 16, 4, true" | tee -a gpurun_out/r04_half_pmc.txt
     done ;;
   traffic)
     # HBM bytes of the headline kernel: separate FETCH_SIZE / WRITE_SIZE / TCC passes over the bench command
