@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Timings that feel the cross-lane folds (lane_fold.h): the passes over the CSC view on config 3 and on R-MAT 21,
-spmm_value_bw, the half-width pass, and the forward.  Run once per build (tools/fold_ab.sh builds the library with and
-without -DPSA_SHFL_FOLDS and runs this after each)."""
+"""Timings that feel the cross-lane folds (csrc/lane_fold.h) and the step structure of the backward kernels: training
+steps in fp32 / bf16, spmm_value_bw, the passes over the CSC view (fp32, bf16, masked bf16) and the forwards, on config 3
+and on R-MAT 21.  Run once per build:  python tools/fold_ab.py <tag>.  Two builds inside ONE gpurun call (the second
+made on the box, e.g. with PSA_EXTRA_HIPCC_FLAGS=-D... python -m paddle_sparse_amd.build --force, or with an alternative
+source file copied over) give a same-box A/B: profiles/r04_fold_ab.txt, r04_fold_hybrid_ab.txt, r04_tail_ab.txt,
+r04_spmm_dpp_ab.txt."""
 import sys
 from pathlib import Path
 
